@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF on CPU.
+
+Runs only in the build container, where /root/reference exists (it does not exist on the GPU
+box; nothing in tests/, smoke() or bench.py reads it at run time).  The fixtures are data only:
+seeds + small arrays of inputs and the reference's outputs.  Usage:
+
+    SAE_DISABLE_TRITON=1 python tests/golden/make_golden.py [--full]
+
+`--full` additionally writes the d=4096 / N=131072 fixture (needs ~12 GB RAM, ~1 min).
+
+Import recipe: stub the packages the reference imports but this image
+lacks (simple_parsing, natsort, torchtyping), neutralise the import-time
+LlavaNextProcessor.from_pretrained default argument (features/cache.py:321), and import
+sae_auto_interp.features.cache under a synthetic parent package so features/__init__.py (which
+needs blobfile/orjson/torchvision) is not executed.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+os.environ["SAE_DISABLE_TRITON"] = "1"  # triton_decode raises "0 active drivers" on CPU tensors
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO / "tests"))
+import synth  # noqa: E402
+
+
+def _install_stubs():
+    sp = types.ModuleType("simple_parsing")
+
+    class Serializable:
+        def to_dict(self):
+            return dataclasses.asdict(self)
+
+    sp.Serializable = Serializable
+    sp.list_field = lambda *a, **k: dataclasses.field(default_factory=lambda: list(a))
+    sp.field = lambda *a, default=None, **k: dataclasses.field(default=default)
+    sp.parse = lambda *a, **k: None
+    sys.modules["simple_parsing"] = sp
+    ns = types.ModuleType("natsort")
+    ns.natsorted = lambda seq, key=None: sorted(seq, key=key)
+    sys.modules["natsort"] = ns
+    tt = types.ModuleType("torchtyping")
+
+    class _TT:
+        def __class_getitem__(cls, item):
+            return torch.Tensor
+
+    tt.TensorType = _TT
+    sys.modules["torchtyping"] = tt
+    import transformers
+
+    transformers.LlavaNextProcessor.from_pretrained = classmethod(lambda cls, *a, **k: None)
+
+
+def _import_reference():
+    _install_stubs()
+    sys.path.insert(0, str(REF))
+    from sae_auto_interp.sae import Sae, SaeConfig  # noqa
+    from sae_auto_interp.sae.utils import eager_decode  # noqa
+
+    # features.cache without features/__init__.py
+    pkg = types.ModuleType("sae_auto_interp.features")
+    pkg.__path__ = [str(REF / "sae_auto_interp" / "features")]
+    sys.modules["sae_auto_interp.features"] = pkg
+    spec = importlib.util.spec_from_file_location(
+        "sae_auto_interp.features.cache", REF / "sae_auto_interp" / "features" / "cache.py")
+    cache_mod = importlib.util.module_from_spec(spec)
+    sys.modules["sae_auto_interp.features.cache"] = cache_mod
+    spec.loader.exec_module(cache_mod)
+    return Sae, SaeConfig, eager_decode, cache_mod
+
+
+def _make_ref_sae(Sae, SaeConfig, d, N, k, seed, multi_topk=False):
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed)
+    sae = Sae(d, SaeConfig(num_latents=N, k=k, multi_topk=multi_topk), device="cpu")
+    with torch.no_grad():
+        sae.encoder.weight.copy_(torch.from_numpy(W_enc))
+        sae.encoder.bias.copy_(torch.from_numpy(b_enc))
+        sae.W_dec.copy_(torch.from_numpy(W_dec))
+        sae.b_dec.copy_(torch.from_numpy(b_dec))
+    return sae
+
+
+def _canon(vals: torch.Tensor, idx: torch.Tensor):
+    """Reorder a top-k result to (value desc, index asc)."""
+    v, i = vals.numpy().astype(np.float32), idx.numpy().astype(np.int64)
+    order = np.lexsort((i, -v.astype(np.float64)), axis=-1)
+    return np.take_along_axis(v, order, -1), np.take_along_axis(i, order, -1).astype(np.int32)
+
+
+def encode_decode_fixture(Sae, SaeConfig, name, d, N, ks, T, wseed, xseed):
+    out = {"d": d, "N": N, "T": T, "wseed": wseed, "xseed": xseed, "ks": np.array(ks)}
+    x = torch.from_numpy(synth.activations(T, d, xseed)).to(torch.bfloat16)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, ks[0], wseed)
+    with torch.no_grad():
+        pre = sae.pre_acts(x)  # sae.py:172
+        out["pre_slice"] = pre[:8, :256].numpy()
+        out["pre_rowsum"] = pre.double().sum(-1).numpy()
+        out["pre_nnz"] = (pre > 0).sum(-1).numpy()
+        for k in ks:
+            sae.cfg.k = k
+            top = sae.select_topk(pre)  # sae.py:179
+            v, i = _canon(top.top_acts, top.top_indices)
+            out[f"k{k}_acts"], out[f"k{k}_idx"] = v, i
+            # gap between the k-th and (k+1)-th pre-activation: rows where index equality is
+            # tolerance-dependent are identifiable
+            kk = pre.topk(k + 1, sorted=True).values
+            out[f"k{k}_gap"] = (kk[:, k - 1] - kk[:, k]).numpy()
+            out[f"k{k}_recon"] = sae.decode(top.top_acts, top.top_indices).numpy()  # sae.py:187
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def decode_seam_fixture(eager_decode):
+    """train/sae/tests/test_decode.py:6-20 restated with fixed inputs (CPU)."""
+    g = torch.Generator().manual_seed(0)
+    latents = torch.rand(2, 100, generator=g)
+    W_dec = torch.randn(100, 50, generator=g)
+    top_vals, top_idx = latents.topk(10)
+    res = eager_decode(top_idx, top_vals, W_dec.mT)
+    np.savez_compressed(HERE / "g3_decode_seam.npz", latents=latents.numpy(), W_dec=W_dec.numpy(),
+                        top_vals=top_vals.numpy(), top_idx=top_idx.numpy().astype(np.int32),
+                        eager=res.numpy())
+    print("wrote g3_decode_seam")
+
+
+def cache_fixture(Sae, SaeConfig, cache_mod):
+    """Cache.add / get_nonzeros / save_splits / concate_safetensors / _generate_split_indices."""
+    from safetensors.torch import load_file
+
+    d, N, k = 16, 64, 4
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=7)
+    x = torch.from_numpy(synth.activations(2 * 3, d, 5, n_outlier=0).reshape(2, 3, d))
+    out = {"x": x.numpy(), "wseed": 7, "d": d, "N": N, "k": k}
+    module = "model.layers.24"
+    for tag, filt in (("nofilter", None), ("filter", torch.tensor([1, 5, 9, 20, 33, 40, 41, 63]))):
+        cache = cache_mod.Cache(shard_size=100, filters=None if filt is None else {module: filt},
+                                batch_size=2)
+        with torch.no_grad():
+            lat = sae.pre_acts(x)
+            topk = torch.topk(lat, k=k, dim=-1)  # cache.py:210
+            result = torch.zeros_like(lat)
+            result.scatter_(-1, topk.indices, topk.values)  # cache.py:214-216
+            cache.add(result, 5, module)  # cache.py:217
+        cache.save()
+        out[f"{tag}_locations"] = cache.feature_locations[module].numpy()
+        out[f"{tag}_activations"] = cache.feature_activations[module].numpy()
+        if filt is not None:
+            out["filter_features"] = filt.numpy()
+
+    # split naming + per-rank files + rank-0 concat through the reference's own writer
+    fc = cache_mod.FeatureCache.__new__(cache_mod.FeatureCache)
+    fc.width = N
+    cache = cache_mod.Cache(shard_size=0, filters=None, batch_size=2)
+    cache.feature_locations[module] = torch.from_numpy(out["nofilter_locations"])
+    cache.feature_activations[module] = torch.from_numpy(out["nofilter_activations"])
+    fc.cache = cache
+    with tempfile.TemporaryDirectory() as td:
+        fc.save_splits(4, td, rank=0)
+        names = sorted(os.listdir(f"{td}/{module}"))
+        out["split_rank_files"] = np.array(names)
+        fc.concate_safetensors(4, td)
+        names2 = sorted(os.listdir(f"{td}/{module}"))
+        out["split_concat_files"] = np.array(names2)
+        for nm in names2:
+            dat = load_file(f"{td}/{module}/{nm}")
+            out[f"split_{nm}_locations"] = dat["locations"].numpy()
+            out[f"split_{nm}_activations"] = dat["activations"].numpy()
+    for width, n in ((64, 4), (131072, 128), (131072, 8), (4096, 3)):
+        fc.width = width
+        si = fc._generate_split_indices(n)  # cache.py:243-247
+        out[f"splits_{width}_{n}"] = np.array([[int(a), int(b)] for a, b in si], dtype=np.int64)
+    np.savez_compressed(HERE / "g4_cache.npz", **out)
+    print("wrote g4_cache", out["nofilter_locations"][:3].tolist(), out["split_rank_files"])
+
+
+def hook_fixture(Sae, SaeConfig):
+    """Steering hook body (features/steering.py:105-124) and attribution hook body
+    (features/patching/utils.py:33-58), executed line for line on the reference Sae."""
+    d, N, k = 64, 1024, 8
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=9)
+    out = {"d": d, "N": N, "k": k, "wseed": 9}
+    for S in (5, 1):
+        x = torch.from_numpy(synth.activations(S, d, 20 + S, n_outlier=1)).to(torch.float16)[None]
+        feature, clamp = 77, 10.0
+        with torch.no_grad():
+            latents = sae.pre_acts(x)
+            if latents.shape[1] != 1:
+                latents[:, :, feature] = clamp
+            top_acts, top_indices = sae.select_topk(latents)
+            sae_out = sae.decode(top_acts[0], top_indices[0]).unsqueeze(0).to(torch.float16)
+        out[f"steer_S{S}_x"] = x.numpy()
+        out[f"steer_S{S}_out"] = sae_out.numpy()
+        out[f"steer_S{S}_feature"], out[f"steer_S{S}_clamp"] = feature, clamp
+    x = torch.from_numpy(synth.activations(2 * 3, d, 31, n_outlier=1)).to(torch.float16)
+    x = x.reshape(2, 3, d)
+    with torch.no_grad():
+        lat0 = sae.pre_acts(x.flatten(0, 1))
+        off = int(lat0[0].argmax())  # a feature that is certainly active for token 0
+    for tag, off_features in (("none", None), ("off", off)):
+        with torch.no_grad():
+            bs, seq_len, dim = x.shape
+            latents = sae.pre_acts(x.flatten(0, 1))
+            if off_features is not None:
+                mask = torch.ones_like(latents)
+                mask[:, off_features] = 0
+                latents = latents * mask
+            top_acts, top_indices = sae.select_topk(latents)
+            sae_out = sae.decode(top_acts, top_indices).to(torch.float16).view(bs, seq_len, dim)
+        out[f"attr_{tag}_out"] = sae_out.numpy()
+    out["attr_x"], out["attr_off_feature"] = x.numpy(), off
+    np.savez_compressed(HERE / "g5_hooks.npz", **out)
+    print("wrote g5_hooks")
+
+
+def train_fixture(Sae, SaeConfig):
+    """Sae.forward with dead_mask / multi_topk (sae.py:193-247) and decode grads via eager
+    autograd (the contract TritonDecoder.backward implements, kernels.py:411-429)."""
+    d, N, k = 64, 1024, 8
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=11, multi_topk=True)
+    x = torch.from_numpy(synth.activations(24, d, 40, n_outlier=1, bf16=False))
+    dead = torch.zeros(N, dtype=torch.bool)
+    dead[::7] = True
+    fo = sae(x, dead)
+    fo.fvu.backward(retain_graph=True)
+    out = {"d": d, "N": N, "k": k, "wseed": 11, "x": x.numpy(), "dead_mask": dead.numpy(),
+           "fvu": fo.fvu.item(), "auxk_loss": fo.auxk_loss.item(),
+           "multi_topk_fvu": fo.multi_topk_fvu.item(), "sae_out": fo.sae_out.detach().numpy()}
+    # decode grads alone
+    sae.zero_grad()
+    acts = torch.rand(5, k, dtype=torch.float32).requires_grad_()
+    idx = torch.stack([torch.randperm(N)[:k] for _ in range(5)])
+    g = torch.from_numpy(synth.normalish(77, 5 * d).reshape(5, d))
+    y = sae.decode(acts, idx)
+    y.backward(g)
+    out.update(dec_acts=acts.detach().numpy(), dec_idx=idx.numpy().astype(np.int32), dec_gout=g.numpy(),
+               dec_grad_acts=acts.grad.numpy(), dec_grad_Wdec_rows=sae.W_dec.grad[idx.flatten()].numpy(),
+               dec_grad_Wdec_nnzrows=int((sae.W_dec.grad.abs().sum(1) > 0).sum()),
+               dec_grad_bdec=sae.b_dec.grad.numpy())
+    np.savez_compressed(HERE / "g7_train.npz", **out)
+    print("wrote g7_train", out["fvu"], out["auxk_loss"], out["multi_topk_fvu"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Sae, SaeConfig, eager_decode, cache_mod = _import_reference()
+    encode_decode_fixture(Sae, SaeConfig, "g1_c1_d768_n4096", 768, 4096, [32], 64, 1, 0)
+    encode_decode_fixture(Sae, SaeConfig, "g2_d4096_n16384", 4096, 16384, [32, 256], 16, 2, 3)
+    decode_seam_fixture(eager_decode)
+    cache_fixture(Sae, SaeConfig, cache_mod)
+    hook_fixture(Sae, SaeConfig)
+    train_fixture(Sae, SaeConfig)
+    if args.full:
+        encode_decode_fixture(Sae, SaeConfig, "g2_c2_d4096_n131072", 4096, 131072, [32, 256], 16, 3, 4)
+
+
+if __name__ == "__main__":
+    main()
