@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- tokens/sec through SAE encode + TopK + decode (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens T] [--k 32] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of T synthetic activations already resident in
+HBM: fused Sae.encode (bf16 MFMA candidate GEMM + exact f32 re-score + TopK) followed by the
+k-sparse decode.  Workload = BASELINE.json configs[1]: d_model=4096, width=131072, k=32, bf16
+activations shaped like a residual stream (a few x20 outlier dims), random-init unit-norm weights.
+
+N > 1 (configs[2]): the 131072-feature axis is sharded over the ranks (N/G rows of W_enc each);
+every rank encodes the SAME T tokens against its shard, the per-shard top-k pairs are exchanged with
+one RCCL all-gather (256 B/token/rank) and merged, and the decode is token-sharded with an
+all-gather of the reconstruction.  Total work is fixed as G grows: "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+for p in (REPO, REPO / "multimodal-sae_amd", REPO / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+D_MODEL, WIDTH = 4096, 131072
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+STAGES = ["prep", "sample_gemm", "threshold_topk", "main_gemm", "select_rescore", "exact_fallback"]
+
+
+def make_inputs(dev, T, d, N, seed=0, rows=None):
+    """Synthetic SAE + activations.  `rows` = (lo, hi) slice of the feature axis held by this rank."""
+    g = torch.Generator(device=dev).manual_seed(1234 + seed)
+    lo, hi = rows if rows else (0, N)
+    # generate per 8192-row block so every rank draws identical values for its slice
+    W_enc = torch.empty(hi - lo, d, device=dev)
+    W_dec = torch.empty(hi - lo, d, device=dev)
+    blk = 8192
+    for b0 in range(0, N, blk):
+        gb = torch.Generator(device=dev).manual_seed(977 * (b0 // blk) + 5)
+        we = torch.randn(blk, d, generator=gb, device=dev)
+        wd = torch.randn(blk, d, generator=gb, device=dev)
+        s0, s1 = max(b0, lo), min(b0 + blk, hi)
+        if s0 < s1:
+            we = we / we.norm(dim=1, keepdim=True)
+            wd = wd / wd.norm(dim=1, keepdim=True)
+            W_enc[s0 - lo:s1 - lo] = we[s0 - b0:s1 - b0]
+            W_dec[s0 - lo:s1 - lo] = wd[s0 - b0:s1 - b0]
+        del we, wd
+    b_enc = (torch.randn(N, generator=g, device=dev) * 0.02)[lo:hi].contiguous()
+    b_dec = torch.randn(d, generator=g, device=dev) * 0.1
+    x = torch.randn(T, d, generator=g, device=dev) + 0.25 * torch.randn(d, generator=g, device=dev)
+    for j in range(4):
+        x[:, (j * 977 + 13) % d] *= 20.0
+    return W_enc, b_enc, W_dec, b_dec, x.to(torch.bfloat16)
+
+
+def cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, sample_T=256, reps=5):
+    """The reference algorithm on torch-CPU operators (oracle.RefPort), timed on the host cores."""
+    from oracle import oracle
+
+    port = oracle.RefPort(W_enc.cpu(), b_enc.cpu(), W_dec.cpu(), b_dec.cpu(), k)
+    xs = x[:sample_T].cpu()
+    port.forward(xs)  # warm-up
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        port.forward(xs)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return {"value": sample_T / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"T={sample_T} tokens of the same workload, median of {reps} calls of "
+                      f"RefPort.forward (F.linear+relu, topk, eager scatter+matmul decode), f32, "
+                      f"{t * 1e3:.0f} ms/call"}
+
+
+def load_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary, if any."""
+    f = REPO / "profiles" / "pmc_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(kernel)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=8192, help="tokens per step (whole job)")
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from msae import _hip, ops
+    from msae.parallel import ShardedSae
+
+    lib = _hip.load()
+    T, d, N, k = args.tokens, D_MODEL, WIDTH, args.k
+    n_loc = N // world
+    W_enc, b_enc, W_dec_shard, b_dec, x = make_inputs(dev, T, d, N, rows=(rank * n_loc, (rank + 1) * n_loc))
+    if world > 1:
+        # decode is token-sharded with a replicated W_dec (2 GiB of 288 GB)
+        _, _, W_dec, _, _ = make_inputs(dev, 1, d, N)
+    else:
+        W_dec = W_dec_shard
+    del W_dec_shard
+    engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world,
+                        group=dist.group.WORLD if world > 1 else None)
+
+    def step():
+        return engine.forward(x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # stage events are recorded on the launch stream during the timed region
+    lib.msae_profile_begin(args.steps)
+    dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    engine.decode_events = dec_ev
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stage_ms = (ctypes.c_float * (args.steps * 6))()
+    n_steps = ctypes.c_int(0)
+    lib.msae_profile_end(stage_ms, ctypes.byref(n_steps))
+    stage = np.array(stage_ms[:]).reshape(args.steps, 6)[: n_steps.value]
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev[: engine.decode_event_i]])) \
+        if engine.decode_event_i else float("nan")
+    engine.decode_events = None
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = T * args.steps / elapsed
+        res = {
+            "metric": "tokens/sec through SAE encode+TopK+decode, d=4096 width=131072",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "bf16 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: d_model=4096 width=131072 k=%d, T=%d bf16 "
+                                   "activations/step resident in HBM, random-init unit-norm f32 weights"
+                                   % (k, T),
+                       "tokens_per_step": T, "k": k,
+                       "parallelism": "single GPU" if world == 1 else f"feature-sharded x{world} (RCCL all-gather merge)"},
+        }
+        if len(stage):
+            mean = stage.mean(0)
+            t_gemm = float(mean[3]) * 1e-3
+            flops = 2.0 * T * d * n_loc
+            ach = flops / t_gemm / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<THRESH>", "achieved": ach,
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                               "traffic": load_traffic("gemm_bf16_kernel"), "launch_ms": float(mean[3])}
+            res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
+            res["stage_ms"]["decode"] = dec_ms
+            bytes_dec = (T // world) * (k * d * 4 + k * 8 + d * 4)
+            res["decode_hbm"] = {"achieved": bytes_dec / (dec_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": bytes_dec / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            st = out["status"]
+            res["fast_path_verified_frac"] = float((st == 0).float().mean().item())
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * msae.h -- C ABI of libmsae_hip.so: the MI355X (gfx950) native SAE encode / TopK / decode /
+ * cache-sparsify path.  Plain pointers and sizes only; no torch types.
+ *
+ * Every pointer is a DEVICE pointer unless stated otherwise.  Every call is asynchronous on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream), never synchronises the
+ * device, and allocates nothing: workspaces are sized by the *_ws_bytes() helpers and owned by the
+ * caller (the reference calls this path inside an HF forward hook on the model's stream,
+ * features/cache.py:187-204, so ops must be stream-ordered).
+ *
+ * Return value: 0 on success, a positive hipError_t from the HIP runtime, or a negative
+ * MSAE_E* code for argument errors (the reference raises Python AssertionError on the same
+ * conditions: sae/kernels.py:28-36,194-197,303-309; the Python host layer turns any non-zero
+ * code into RuntimeError).  msae_error_string() describes a code.
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference):
+ *   msae_pre_acts_f32        Sae.pre_acts                  sae_auto_interp/sae/sae.py:172-177
+ *   msae_topk_f32            Sae.select_topk / torch.topk  sae_auto_interp/sae/sae.py:179-181,
+ *                                                          features/cache.py:210-212
+ *   msae_encode_topk         Sae.encode (fused)            sae_auto_interp/sae/sae.py:183-185
+ *                            + hook edits                  features/steering.py:113-114,
+ *                                                          features/patching/utils.py:43-48
+ *   msae_decode_f32          Sae.decode / decoder_impl     sae_auto_interp/sae/sae.py:187-191,
+ *                            TritonDecoder.forward         sae/utils.py:115-129, sae/kernels.py:178-284
+ *   msae_decode_bwd_acts_f32 TritonDecoder.backward (acts) sae/kernels.py:421-425,287-400
+ *   msae_decode_bwd_wdec_f32 TritonDecoder.backward (W)    sae/kernels.py:417-419,10-175
+ *   msae_sparsify_*          scatter_ + Cache.add/get_nonzeros  features/cache.py:214-217,42-92
+ *
+ * Numerics contract: all dot products are ascending-k f32 fused
+ * multiply-add chains (v_mfma_f32_32x32x2_f32 / v_fma_f32), bit-identical to oracle/sae_oracle.c.
+ * msae_encode_topk selects candidates with a bf16 MFMA pass and re-scores them with the exact f32
+ * chain, so its outputs are bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever its
+ * per-token guard band holds; tokens where it does not are reported in `status` and recomputed
+ * by the exact path inside the same call.
+ */
+#ifndef MSAE_H_
+#define MSAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSAE_ABI_VERSION 1
+
+/* element type of the activation tensor x handed over by the LLM hook (sae.py:174 up-casts) */
+enum { MSAE_F32 = 0, MSAE_BF16 = 1, MSAE_F16 = 2 };
+
+/* argument errors */
+enum {
+  MSAE_EINVAL = -1,   /* bad shape / k / dtype code */
+  MSAE_EALIGN = -2,   /* pointer or leading dimension not aligned as required */
+  MSAE_EWS = -3,      /* workspace too small */
+  MSAE_ENOTIMPL = -4  /* shape outside what this build supports */
+};
+
+int msae_abi_version(void);
+const char *msae_error_string(int code);
+/* Name of the device architecture the kernels were compiled for ("gfx950"). */
+const char *msae_target_arch(void);
+
+/* ---- exact f32 path ------------------------------------------------------------------ */
+
+/* out[T][N] = relu((x[T][d] - b_dec[d]) @ W_enc[N][d]^T + b_enc[N]), f32, row-major, dense.
+ * x is row-major with element type x_dtype.  b_enc / b_dec may be NULL (treated as zeros).
+ * relu != 0 applies the ReLU (Sae.pre_acts always does). */
+int msae_pre_acts_f32(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                      const float *b_dec, int T, int d, int N, int relu, float *out, void *stream);
+
+/* Canonical top-k of each row of latents[T][N]: vals[T][k] descending, ties by ascending index.
+ * idx is int32 (the host layer widens to int64 where the reference API returns int64). */
+size_t msae_topk_ws_bytes(int T, int N, int k);
+int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_t *idx, void *ws,
+                  size_t ws_bytes, void *stream);
+
+/* ---- fused encoder: bf16 MFMA candidate pass + exact f32 re-score ------------------------ */
+
+/* One-time preparation of the encoder weights (bf16 copy of W_enc + a strided sample of its rows
+ * used to set the per-token candidate threshold).  `prepared` must hold
+ * msae_encoder_prepared_bytes(N, d) bytes and stay valid while the encoder is used. */
+size_t msae_encoder_prepared_bytes(int N, int d);
+int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream);
+
+/* Fused Sae.encode: vals/idx[T][k] = canonical top-k of relu((x - b_dec) W_enc^T + b_enc), with
+ * the reference hooks' edits of the dense latents applied before TopK:
+ *   set_feature >= 0 : latents[:, set_feature] = set_value       (steering.py:113-114)
+ *   zero_feature >= 0: latents[:, zero_feature] = 0               (patching/utils.py:43-48)
+ * status (optional, int32[T]): 0 = fast path verified; 1 = token recomputed by the exact path. */
+size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k);
+int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                     const float *b_dec, const void *prepared, int T, int d, int N, int k,
+                     int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
+                     int32_t *status, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- k-sparse decoder -------------------------------------------------------------------- */
+
+/* out[A][d] = sum_j acts[A][j] * W_dec[idx[A][j]][:] + b_dec  (j-ordered f32 fma chain, entries
+ * with acts == 0 skipped, kernels.py:277).  Indices outside [0, N) are skipped and, when
+ * `status` (int32[1], optional) is given, flagged there (kernels.py:276 device_assert). */
+int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec, const float *b_dec,
+                    int A, int k, int N, int d, float *out, int32_t *status, void *stream);
+
+/* g_acts[A][k] = grad_out[A][:] . W_dec[idx[A][j]][:]   (dense-dense-sparse-out matmul) */
+int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const float *W_dec, int A,
+                             int k, int N, int d, float *g_acts, void *stream);
+
+/* g_W_dec[idx[a][j]][:] += acts[a][j] * grad_out[a][:]  accumulated into a dense, caller-zeroed
+ * [N][d] buffer (the layout autograd expects for Sae.W_dec.grad). */
+int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
+                             int k, int N, int d, float *g_W_dec, void *stream);
+
+/* ---- feature-cache sparsify ------------------------------------------------------------------
+ * From the per-token top-k (vals/idx[B*S][k], any order) produce the reference cache's COO
+ * records in its order (row, pos, feature ascending):
+ *     keep (|v| > thresh) and (filter_bitmap == NULL or filter_bitmap[feature] != 0)
+ *     locations[n] = (row_base + b, s, feature) int64 ; activations[n] = v
+ * Two calls: _count fills counts[B*S+1] (exclusive prefix sum, counts[B*S] = nnz) on the device;
+ * the caller reads nnz, allocates, then _write emits the records. */
+int msae_sparsify_count(const float *vals, const int32_t *idx, int B, int S, int k, float thresh,
+                        const uint8_t *filter_bitmap, int N, int64_t *counts, void *stream);
+int msae_sparsify_write(const float *vals, const int32_t *idx, int B, int S, int k, float thresh,
+                        const uint8_t *filter_bitmap, int N, int64_t row_base,
+                        const int64_t *counts, int64_t *locations, float *activations,
+                        void *stream);
+
+/* ---- stage timing of msae_encode_topk's fused path (measurement aid for bench.py) --------------
+ * Between _begin and _end every fused msae_encode_topk call records HIP events, on the stream it
+ * launches on, at the boundaries of its 6 stages:
+ *   0 prep (zero + x->bf16)   1 sample GEMM   2 threshold TopK   3 main bf16 MFMA GEMM
+ *   4 select + exact re-score 5 exact fallback of flagged tokens
+ * _end synchronises on the recorded events and returns stage_ms[n_steps][6] (HOST pointers). */
+int msae_profile_begin(int max_steps);
+int msae_profile_end(float *stage_ms, int *n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSAE_H_ */

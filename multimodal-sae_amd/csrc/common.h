@@ -1,0 +1,112 @@
+// common.h -- shared device/host helpers for the gfx950 SAE kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msae.h"
+
+#define MSAE_WAVE 64
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+#define MSAE_HIP_TRY(expr)                  \
+  do {                                      \
+    hipError_t e__ = (expr);                \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+
+static inline int msae_launch_status() { return (int)hipGetLastError(); }
+
+static inline bool msae_aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+__host__ __device__ static inline size_t msae_align_up(size_t v, size_t a) {
+  return (v + a - 1) / a * a;
+}
+
+// ---- element conversion ---------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned)b) << 16);
+}
+// round-to-nearest-even f32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) {
+  return (float)__builtin_bit_cast(_Float16, b);
+}
+
+// Load 4 consecutive activations x[i..i+3] of element type DT as f32 (exact up-cast, sae.py:174).
+template <int DT>
+__device__ __forceinline__ f32x4 load_x4(const void *x, size_t i) {
+  if constexpr (DT == MSAE_F32) {
+    return *reinterpret_cast<const f32x4 *>(static_cast<const float *>(x) + i);
+  } else {
+    u16x4 r = *reinterpret_cast<const u16x4 *>(static_cast<const unsigned short *>(x) + i);
+    f32x4 o;
+    if constexpr (DT == MSAE_BF16) {
+      o[0] = bf16_bits_to_f32(r[0]); o[1] = bf16_bits_to_f32(r[1]);
+      o[2] = bf16_bits_to_f32(r[2]); o[3] = bf16_bits_to_f32(r[3]);
+    } else {
+      o[0] = f16_bits_to_f32(r[0]); o[1] = f16_bits_to_f32(r[1]);
+      o[2] = f16_bits_to_f32(r[2]); o[3] = f16_bits_to_f32(r[3]);
+    }
+    return o;
+  }
+}
+template <int DT>
+__device__ __forceinline__ float load_x1(const void *x, size_t i) {
+  if constexpr (DT == MSAE_F32) return static_cast<const float *>(x)[i];
+  else if constexpr (DT == MSAE_BF16) return bf16_bits_to_f32(static_cast<const unsigned short *>(x)[i]);
+  else return f16_bits_to_f32(static_cast<const unsigned short *>(x)[i]);
+}
+
+// ---- canonical ordering key: larger key == ranks earlier ------------------------------------
+// order-preserving map of an f32 to u32 (-0 folded onto +0 so it ties with +0 like `==` does)
+__device__ __forceinline__ unsigned f32_order_key(float f) {
+  unsigned b = __float_as_uint(f);
+  if (b == 0x80000000u) b = 0u;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(unsigned k) {
+  unsigned b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+// 64-bit rank key of (value, index): value desc, then index asc  <=>  key desc
+__device__ __forceinline__ unsigned long long rank_key(float v, int idx) {
+  return ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - idx);
+}
+__device__ __forceinline__ int rank_key_index(unsigned long long k) {
+  return 0x7FFFFFFF - (int)(unsigned)(k & 0xFFFFFFFFull);
+}
+
+// Bitonic sort of n (power of two) 64-bit keys in LDS, DESCENDING; all threads of the block call.
+__device__ __forceinline__ void bitonic_sort_desc_u64(unsigned long long *s, int n) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+        int lo = (i / stride) * (stride << 1) + (i % stride);
+        int hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        unsigned long long a = s[lo], b = s[hi];
+        if ((a < b) == desc) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__host__ __device__ static inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}

@@ -1,0 +1,245 @@
+// topk.hip -- canonical top-k of dense f32 rows (value descending, ties by ascending index).
+//
+// Replaces Tensor.topk as used by Sae.select_topk (reference sae/sae.py:179-181) and by the cache
+// loop (features/cache.py:210-212).  The fused encoder (encode_fused.hip) never materialises the
+// dense [T][N] latents; this kernel serves the dense legacy API, the exact fallback, and the
+// sample-threshold selection of the fused encoder.
+//
+// One 1024-thread workgroup per row.  Radix select on the order-preserving u32 key of each value
+// (12 + 12 + 8 bits, LDS histograms) finds the key of the k-th largest element and how many
+// elements equal to it are needed (r); an index-ordered collect pass (block prefix sums) gathers
+// the k winners -- every element above the pivot plus the r lowest-index elements equal to it --
+// and an LDS bitonic sort puts them in canonical order.  HBM-bound: the row is streamed once from
+// HBM and re-read from L2 by the later passes (N*4 B = 512 KiB at N = 131072).
+#include "common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_WAVES = TK_THREADS / 64;
+constexpr int TK_BINS = 4096;
+
+struct TkShared {
+  unsigned hist[TK_BINS];
+  unsigned wave_tot[TK_WAVES];
+  unsigned bin;
+  unsigned remaining;
+  unsigned base_gt;
+  unsigned base_eq;
+};
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned n = __shfl_up(v, off, 64);
+    if (lane >= off) v += n;
+  }
+  return v;
+}
+
+// Block-wide exclusive prefix sum of `v` in thread order; returns the exclusive prefix and
+// writes the block total to *total.  Uses sh.wave_tot; contains two barriers.
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, TkShared &sh, unsigned *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = wave_incl_scan(v, lane);
+  __syncthreads();  // previous users of wave_tot are done
+  if (lane == 63) sh.wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < TK_WAVES; ++w) {
+    unsigned t = sh.wave_tot[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load4(const float *row, int i, int N, float (&v)[4]) {
+  if constexpr (VEC) {
+    f32x4 t = *reinterpret_cast<const f32x4 *>(row + i);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (i + e < N) ? row[i + e] : 0.f;
+  }
+}
+
+// One radix pass: histogram of ((key >> shift) & (nbins-1)) over elements whose key matches
+// `prefix` under `mask`; then locate the bin holding the `remaining`-th largest such element.
+template <bool VEC>
+__device__ __forceinline__ void radix_pass(const float *row, int N, unsigned prefix, unsigned mask,
+                                           int shift, int nbins, TkShared &sh) {
+  const unsigned need = sh.remaining;  // read before any barrier: the winner rewrites it below
+  for (int b = threadIdx.x; b < nbins; b += TK_THREADS) sh.hist[b] = 0;
+  __syncthreads();
+  const int n4 = (N + 3) & ~3;
+  for (int i = threadIdx.x * 4; i < n4; i += TK_THREADS * 4) {
+    float v[4];
+    load4<VEC>(row, i, N, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (VEC || i + e < N) {
+        unsigned key = f32_order_key(v[e]);
+        if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & (unsigned)(nbins - 1)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // suffix search from the top bin: thread t owns bins [t*per, t*per+per)
+  const int per = (nbins + TK_THREADS - 1) / TK_THREADS;  // 4 for 4096 bins, 1 for <= 1024
+  // reversed thread order so an exclusive PREFIX scan over rt is a SUFFIX sum over bins
+  const int rt = TK_THREADS - 1 - threadIdx.x;  // rt == 0 owns the highest bins
+  unsigned local = 0;
+  for (int e = 0; e < per; ++e) {
+    int b = nbins - 1 - (rt * per + e);
+    if (b >= 0) local += sh.hist[b];
+  }
+  // scan in rt order: emulate by scanning in thread order of a mirrored value
+  // (thread x holds value for rt = 1023 - x; we need prefix over rt, i.e. suffix over x)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned n = __shfl_down(incl, off, 64);
+    if (lane + off < 64) incl += n;
+  }
+  __syncthreads();
+  if (lane == 0) sh.wave_tot[wave] = incl;  // total of this wave
+  __syncthreads();
+  unsigned above = 0;
+  for (int w = wave + 1; w < TK_WAVES; ++w) above += sh.wave_tot[w];
+  above += incl - local;  // elements in bins strictly above this thread's bins
+  if (above < need && need <= above + local) {
+    unsigned cum = above;
+    for (int e = 0; e < per; ++e) {
+      int b = nbins - 1 - (rt * per + e);
+      if (b < 0) break;
+      unsigned c = sh.hist[b];
+      if (cum + c >= need) {
+        sh.bin = (unsigned)b;
+        sh.remaining = need - cum;  // safe: exactly one thread satisfies the outer condition
+        break;
+      }
+      cum += c;
+    }
+  }
+  __syncthreads();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ latents,
+                                                               int N, int k, int ld,
+                                                               const int *__restrict__ n_rows,
+                                                               float *__restrict__ vals,
+                                                               int32_t *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (n_rows && (int)blockIdx.x >= *n_rows) return;  // device-side row count (exact fallback)
+  TkShared &sh = *reinterpret_cast<TkShared *>(smem_raw);
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem_raw + sizeof(TkShared));
+  const float *row = latents + (size_t)blockIdx.x * ld;
+  const int kp = next_pow2(k);
+
+  if (threadIdx.x == 0) {
+    sh.remaining = (unsigned)k;
+    sh.base_gt = 0;
+    sh.base_eq = 0;
+  }
+  for (int i = threadIdx.x; i < kp; i += TK_THREADS) keys[i] = 0ull;
+  __syncthreads();
+
+  // ---- radix select of the pivot key -------------------------------------------------------
+  unsigned prefix = 0, mask = 0;
+  radix_pass<VEC>(row, N, prefix, mask, 20, 4096, sh);
+  prefix |= sh.bin << 20; mask |= 0xFFFu << 20;
+  radix_pass<VEC>(row, N, prefix, mask, 8, 4096, sh);
+  prefix |= sh.bin << 8; mask |= 0xFFFu << 8;
+  radix_pass<VEC>(row, N, prefix, mask, 0, 256, sh);
+  prefix |= sh.bin;
+  const unsigned pivot = prefix;           // key of the k-th largest element
+  const unsigned r = sh.remaining;         // how many elements == pivot to take (lowest index)
+  const unsigned n_gt = (unsigned)k - r;   // elements strictly above the pivot
+  __syncthreads();
+
+  // ---- index-ordered collect ---------------------------------------------------------------
+  const int n4 = (N + 3) & ~3;
+  for (int base = 0; base < n4; base += TK_THREADS * 4) {
+    const int i = base + threadIdx.x * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned key[4];
+    unsigned c_gt = 0, c_eq = 0;
+    if (i < n4) load4<VEC>(row, i, N, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool in = (i + e < N);
+      key[e] = in ? f32_order_key(v[e]) : 0u;
+      c_gt += (in && key[e] > pivot);
+      c_eq += (in && key[e] == pivot);
+    }
+    const unsigned packed = c_gt | (c_eq << 16);
+    if (__syncthreads_or((int)packed) == 0) continue;
+    unsigned total;
+    const unsigned ex = block_excl_scan(packed, sh, &total);
+    unsigned p_gt = sh.base_gt + (ex & 0xFFFFu);
+    unsigned p_eq = sh.base_eq + (ex >> 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i + e < N) {
+        if (key[e] > pivot) {
+          keys[p_gt++] = rank_key(v[e], i + e);
+        } else if (key[e] == pivot) {
+          if (p_eq < r) keys[n_gt + p_eq] = rank_key(v[e], i + e);
+          ++p_eq;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      sh.base_gt += total & 0xFFFFu;
+      sh.base_eq += total >> 16;
+    }
+    __syncthreads();
+    if (sh.base_gt >= n_gt && sh.base_eq >= r) break;  // uniform: all k winners found
+  }
+  __syncthreads();
+
+  // ---- canonical order ---------------------------------------------------------------------
+  bitonic_sort_desc_u64(keys, kp);
+  for (int j = threadIdx.x; j < k; j += TK_THREADS) {
+    const unsigned long long kk = keys[j];
+    const int ix = rank_key_index(kk);
+    idx[(size_t)blockIdx.x * k + j] = ix;
+    vals[(size_t)blockIdx.x * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
+  }
+}
+
+}  // namespace
+
+extern "C" size_t msae_topk_ws_bytes(int T, int N, int k) {
+  (void)T; (void)N; (void)k;
+  return 0;
+}
+
+// ld = row pitch in elements (>= N); exposed to the other translation units of the library.
+int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
+                     float *vals, int32_t *idx, hipStream_t s) {
+  if (T < 0 || N <= 0 || k <= 0 || k > N || k > 4096 || ld < N) return MSAE_EINVAL;
+  if (T == 0) return 0;
+  const size_t smem = sizeof(TkShared) + (size_t)next_pow2(k) * sizeof(unsigned long long);
+  const bool vec = (N % 4 == 0) && (ld % 4 == 0) && msae_aligned(latents, 16);
+  if (vec)
+    hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(T), dim3(TK_THREADS), smem, s, latents, N, k, ld,
+                       n_rows, vals, idx);
+  else
+    hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(T), dim3(TK_THREADS), smem, s, latents, N, k,
+                       ld, n_rows, vals, idx);
+  return msae_launch_status();
+}
+
+extern "C" int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_t *idx,
+                             void *ws, size_t ws_bytes, void *stream) {
+  (void)ws; (void)ws_bytes;
+  return msae_topk_launch(latents, T, N, k, N, nullptr, vals, idx, (hipStream_t)stream);
+}

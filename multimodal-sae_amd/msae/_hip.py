@@ -1,0 +1,109 @@
+"""ctypes binding of libmsae_hip.so (C ABI declared in include/msae.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers and the
+current HIP stream.  There is NO CPU fallback: if the shared library is missing, or a tensor is not
+on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_DIR = Path(__file__).resolve().parent / "_lib"
+LIB_PATH = _LIB_DIR / "libmsae_hip.so"
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_size_t, ctypes.c_int64)
+
+# name -> (restype, argtypes); mirrors include/msae.h one to one
+PROTOTYPES = {
+    "msae_abi_version": (c_int, []),
+    "msae_error_string": (ctypes.c_char_p, [c_int]),
+    "msae_target_arch": (ctypes.c_char_p, []),
+    "msae_pre_acts_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p]),
+    "msae_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "msae_topk_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                              c_void_p]),
+    "msae_encoder_prepared_bytes": (c_size_t, [c_int, c_int]),
+    "msae_encoder_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "msae_encode_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "msae_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p]),
+    "msae_decode_bwd_acts_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p]),
+    "msae_decode_bwd_wdec_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p]),
+    "msae_sparsify_count": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                    c_void_p, c_void_p]),
+    "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "msae_profile_begin": (c_int, [c_int]),
+    "msae_profile_end": (c_int, [c_void_p, c_void_p]),
+}
+
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+_lib = None
+
+
+class MsaeLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libmsae_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MSAE_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise MsaeLibraryMissing(
+            f"{path} not found: build it with `python __graft_entry__.py` "
+            "(multimodal-sae_amd/csrc/build.sh). There is no CPU fallback for the SAE kernels.")
+    lib = ctypes.CDLL(str(path))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.msae_abi_version() != 1:
+        raise RuntimeError("libmsae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().msae_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_device(*tensors: torch.Tensor | None) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "msae kernels run on MI355X only: got a tensor on "
+                f"{t.device}. Move the Sae and its inputs to a HIP device (there is no CPU path).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

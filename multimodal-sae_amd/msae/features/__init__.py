@@ -1,0 +1,5 @@
+from .cache import Cache, FeatureCache, FeatureImageCache, generate_split_indices
+from .hooks import attribution_sae_hook, clamp_features_max, sae_reconstruct
+
+__all__ = ["Cache", "FeatureCache", "FeatureImageCache", "generate_split_indices",
+           "clamp_features_max", "attribution_sae_hook", "sae_reconstruct"]

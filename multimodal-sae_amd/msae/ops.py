@@ -1,0 +1,244 @@
+"""PyTorch-ROCm custom ops (``torch.ops.msae.*``) over the C ABI of libmsae_hip.so.
+
+These are the operators the drop-in ``Sae`` module (msae/sae/sae.py) and the feature cache
+(msae/features/cache.py) are built from.  Reference call sites they replace:
+
+    msae::pre_acts      nn.Linear + relu                     sae_auto_interp/sae/sae.py:172-177
+    msae::topk          Tensor.topk                          sae/sae.py:179-181, features/cache.py:210
+    msae::encode_topk   Sae.encode, fused (+ hook edits)     sae/sae.py:183-185, steering.py:113-114
+    msae::decode        decoder_impl / TritonDecoder.apply   sae/utils.py:107-129, kernels.py:403-429
+    msae::sparsify      scatter_ + Cache.get_nonzeros/add    features/cache.py:214-217,42-92
+
+All ops run on the tensor's device on the current stream, never synchronise (``sparsify`` reads one
+int64 back, as ``torch.nonzero`` does), and raise on CPU tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+
+_WS: dict = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> Tensor:
+    """Grow-only per-device scratch buffer (uint8, 256-B aligned by the caching allocator)."""
+    ws = _WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            del _WS[dev]
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _WS[dev] = ws
+    return ws
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _act(x: Tensor) -> Tensor:
+    x = x.detach()
+    if x.dtype not in _hip.DTYPE_CODE:
+        x = x.to(torch.float32)
+    return x.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op("msae::pre_acts", mutates_args=())
+def pre_acts(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor]) -> Tensor:
+    """relu((x - b_dec) @ W_enc.T + b_enc) -> dense [..., N] f32 (exact f32 MFMA path)."""
+    dev = _hip.require_device(x, W_enc, b_enc, b_dec)
+    lib = _hip.load()
+    xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
+    N, d = W.shape
+    assert xa.shape[-1] == d, f"x last dim {xa.shape[-1]} != d_in {d}"
+    T = xa.numel() // d
+    out = torch.empty(*xa.shape[:-1], N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_pre_acts_f32(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
+                                         _hip.ptr(be), _hip.ptr(bd), T, d, N, 1, _hip.ptr(out),
+                                         _hip.stream_of(xa)), "msae_pre_acts_f32")
+    return out
+
+
+@pre_acts.register_fake
+def _(x, W_enc, b_enc, b_dec):
+    return x.new_empty(*x.shape[:-1], W_enc.shape[0], dtype=torch.float32)
+
+
+@torch.library.custom_op("msae::topk", mutates_args=())
+def topk(latents: Tensor, k: int) -> Tuple[Tensor, Tensor]:
+    """Canonical top-k along the last dim: values descending, ties by ascending index; int64 idx."""
+    dev = _hip.require_device(latents)
+    lib = _hip.load()
+    lat = _f32c(latents)
+    N = lat.shape[-1]
+    T = lat.numel() // N
+    vals = torch.empty(*lat.shape[:-1], k, dtype=torch.float32, device=dev)
+    idx = torch.empty(*lat.shape[:-1], k, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_topk_f32(_hip.ptr(lat), T, N, k, _hip.ptr(vals), _hip.ptr(idx), None, 0,
+                                     _hip.stream_of(lat)), "msae_topk_f32")
+    return vals, idx.to(torch.int64)
+
+
+@topk.register_fake
+def _(latents, k):
+    return (latents.new_empty(*latents.shape[:-1], k, dtype=torch.float32),
+            latents.new_empty(*latents.shape[:-1], k, dtype=torch.int64))
+
+
+def prepare_encoder(W_enc: Tensor) -> Tensor:
+    """One-time bf16 copy (+ sampled rows) of the encoder weights for the fused path."""
+    dev = _hip.require_device(W_enc)
+    lib = _hip.load()
+    W = _f32c(W_enc)
+    N, d = W.shape
+    nbytes = lib.msae_encoder_prepared_bytes(N, d)
+    prepared = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_encoder_prepare(_hip.ptr(W), N, d, _hip.ptr(prepared), _hip.stream_of(W)),
+                   "msae_encoder_prepare")
+    return prepared
+
+
+@torch.library.custom_op("msae::encode_topk", mutates_args=())
+def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
+                prepared: Optional[Tensor], k: int, set_feature: int = -1, set_value: float = 0.0,
+                zero_feature: int = -1) -> Tuple[Tensor, Tensor, Tensor]:
+    """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...])."""
+    dev = _hip.require_device(x, W_enc, b_enc, b_dec, prepared)
+    lib = _hip.load()
+    xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
+    N, d = W.shape
+    assert xa.shape[-1] == d, f"x last dim {xa.shape[-1]} != d_in {d}"
+    T = xa.numel() // d
+    vals = torch.empty(*xa.shape[:-1], k, dtype=torch.float32, device=dev)
+    idx = torch.empty(*xa.shape[:-1], k, dtype=torch.int32, device=dev)
+    status = torch.zeros(xa.shape[:-1], dtype=torch.int32, device=dev)
+    if T == 0:
+        return vals, idx.to(torch.int64), status
+    nws = lib.msae_encode_topk_ws_bytes(T, d, N, k)
+    ws = _workspace(dev, nws)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_encode_topk(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
+                                        _hip.ptr(be), _hip.ptr(bd), _hip.ptr(prepared), T, d, N, k,
+                                        set_feature, set_value, zero_feature, _hip.ptr(vals),
+                                        _hip.ptr(idx), _hip.ptr(status), _hip.ptr(ws), ws.numel(),
+                                        _hip.stream_of(xa)), "msae_encode_topk")
+    return vals, idx.to(torch.int64), status
+
+
+@encode_topk.register_fake
+def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1):
+    return (x.new_empty(*x.shape[:-1], k, dtype=torch.float32),
+            x.new_empty(*x.shape[:-1], k, dtype=torch.int64),
+            x.new_empty(x.shape[:-1], dtype=torch.int32))
+
+
+# ---- decoder (differentiable, mirrors TritonDecoder: kernels.py:403-429) ---------------------------
+def _idx32(top_indices: Tensor) -> Tensor:
+    return top_indices.detach().to(torch.int32).contiguous()
+
+
+@torch.library.custom_op("msae::decode", mutates_args=())
+def decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, b_dec: Optional[Tensor]) -> Tensor:
+    """sum_j top_acts[:, j] * W_dec[top_indices[:, j]] (+ b_dec);  W_dec is [N, d] row-major."""
+    dev = _hip.require_device(top_indices, top_acts, W_dec, b_dec)
+    lib = _hip.load()
+    assert top_indices.shape == top_acts.shape, "indices / acts shape mismatch"  # kernels.py:193
+    idx, acts, W, bd = _idx32(top_indices), _f32c(top_acts), _f32c(W_dec), _f32c(b_dec)
+    N, d = W.shape
+    k = idx.shape[-1]
+    A = idx.numel() // k
+    out = torch.empty(*idx.shape[:-1], d, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_decode_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(W), _hip.ptr(bd), A, k, N,
+                                       d, _hip.ptr(out), None, _hip.stream_of(acts)), "msae_decode_f32")
+    return out
+
+
+@decode.register_fake
+def _(top_indices, top_acts, W_dec, b_dec):
+    return top_acts.new_empty(*top_acts.shape[:-1], W_dec.shape[1], dtype=torch.float32)
+
+
+@torch.library.custom_op("msae::decode_bwd", mutates_args=())
+def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: Tensor,
+               need_acts: bool, need_w: bool) -> Tuple[Tensor, Tensor]:
+    dev = _hip.require_device(top_indices, top_acts, W_dec, grad_out)
+    lib = _hip.load()
+    idx, acts, W, g = _idx32(top_indices), _f32c(top_acts), _f32c(W_dec), _f32c(grad_out)
+    N, d = W.shape
+    k = idx.shape[-1]
+    A = idx.numel() // k
+    g_acts = torch.empty_like(acts) if need_acts else acts.new_empty(0)
+    g_w = torch.zeros_like(W) if need_w else W.new_empty(0)
+    with torch.cuda.device(dev):
+        st = _hip.stream_of(g)
+        if need_acts:
+            _hip.check(lib.msae_decode_bwd_acts_f32(_hip.ptr(idx), _hip.ptr(g), _hip.ptr(W), A, k, N, d,
+                                                    _hip.ptr(g_acts), st), "msae_decode_bwd_acts_f32")
+        if need_w:
+            _hip.check(lib.msae_decode_bwd_wdec_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(g), A, k, N,
+                                                    d, _hip.ptr(g_w), st), "msae_decode_bwd_wdec_f32")
+    return g_acts, g_w
+
+
+@decode_bwd.register_fake
+def _(top_indices, top_acts, W_dec, grad_out, need_acts, need_w):
+    return (torch.empty_like(top_acts, dtype=torch.float32) if need_acts else top_acts.new_empty(0),
+            torch.empty_like(W_dec, dtype=torch.float32) if need_w else W_dec.new_empty(0))
+
+
+def _decode_setup(ctx, inputs, output):
+    top_indices, top_acts, W_dec, b_dec = inputs
+    ctx.save_for_backward(top_indices, top_acts, W_dec)
+    ctx.has_bdec = b_dec is not None
+
+
+def _decode_backward(ctx, grad_out):
+    top_indices, top_acts, W_dec = ctx.saved_tensors
+    need_acts, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    g_acts = g_w = g_b = None
+    if need_acts or need_w:
+        ga, gw = decode_bwd(top_indices, top_acts, W_dec, grad_out.contiguous(), need_acts, need_w)
+        g_acts = ga.to(top_acts.dtype) if need_acts else None
+        g_w = gw.to(W_dec.dtype) if need_w else None
+    if ctx.has_bdec and ctx.needs_input_grad[3]:
+        g_b = grad_out.reshape(-1, grad_out.shape[-1]).sum(0)
+    return None, g_acts, g_w, g_b
+
+
+decode.register_autograd(_decode_backward, setup_context=_decode_setup)
+
+
+# ---- cache sparsify ---------------------------------------------------------------------------------
+def sparsify(top_acts: Tensor, top_indices: Tensor, num_latents: int, row_base: int = 0,
+             thresh: float = 1e-5, filter_bitmap: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """[B, S, k] top-k -> (locations [nnz, 3] int64, activations [nnz] f32) in the reference cache's
+    record order (row, pos, feature ascending); |v| > thresh and optional feature bitmap applied."""
+    dev = _hip.require_device(top_acts, top_indices, filter_bitmap)
+    lib = _hip.load()
+    assert top_acts.dim() == 3 and top_acts.shape == top_indices.shape
+    B, S, k = top_acts.shape
+    vals, idx = _f32c(top_acts), _idx32(top_indices)
+    counts = torch.empty(B * S + 1, dtype=torch.int64, device=dev)
+    fb = None if filter_bitmap is None else filter_bitmap.to(torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        st = _hip.stream_of(vals)
+        _hip.check(lib.msae_sparsify_count(_hip.ptr(vals), _hip.ptr(idx), B, S, k, thresh, _hip.ptr(fb),
+                                           num_latents, _hip.ptr(counts), st), "msae_sparsify_count")
+        nnz = int(counts[-1].item())  # the one host read (torch.nonzero does the same)
+        loc = torch.empty(nnz, 3, dtype=torch.int64, device=dev)
+        act = torch.empty(nnz, dtype=torch.float32, device=dev)
+        if nnz:
+            _hip.check(lib.msae_sparsify_write(_hip.ptr(vals), _hip.ptr(idx), B, S, k, thresh,
+                                               _hip.ptr(fb), num_latents, row_base, _hip.ptr(counts),
+                                               _hip.ptr(loc), _hip.ptr(act), st), "msae_sparsify_write")
+    return loc, act

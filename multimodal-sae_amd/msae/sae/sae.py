@@ -1,0 +1,211 @@
+"""Drop-in `Sae` module backed by the gfx950 HIP kernels.
+
+Same constructor, attributes, state-dict keys (`encoder.weight [N,d]`, `encoder.bias [N]`,
+`W_dec [N,d]`, `b_dec [d]`), checkpoint layout (`<dir>/cfg.json` + `<dir>/sae.safetensors`) and
+methods as the reference module (sae_auto_interp/sae/sae.py:44-271), so the hooks in
+features/cache.py, features/steering.py, features/patching/utils.py and tools/*.py keep working
+unchanged.  What differs is underneath:
+
+* `pre_acts`      -> torch.ops.msae.pre_acts   (exact f32 MFMA GEMM, dense output for legacy callers)
+* `select_topk`   -> torch.ops.msae.topk       (canonical order: value desc, index asc)
+* `encode`        -> torch.ops.msae.encode_topk (fused: the dense [T, N] latents never reach HBM)
+* `decode`        -> torch.ops.msae.decode     (coalesced gather-matmul over W_dec rows, autograd)
+
+SAE math is f32 whatever dtype the LLM hands over, as in the reference (sae.py:140,174).
+There is no CPU implementation: calling a compute method with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import json
+import re
+from fnmatch import fnmatch
+from pathlib import Path
+from typing import NamedTuple, Optional, Union
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from .config import SaeConfig
+
+
+class EncoderOutput(NamedTuple):
+    top_acts: Tensor
+    """Activations of the top-k latents."""
+    top_indices: Tensor
+    """Indices of the top-k features."""
+
+
+class ForwardOutput(NamedTuple):
+    sae_out: Tensor
+    latent_acts: Tensor
+    latent_indices: Tensor
+    fvu: Tensor
+    auxk_loss: Tensor
+    multi_topk_fvu: Tensor
+
+
+def _natural_key(s: str):
+    return [int(p) if p.isdigit() else p for p in re.split(r"(\d+)", s)]
+
+
+class Sae(nn.Module):
+    def __init__(self, d_in: int, cfg: SaeConfig, device: Union[str, torch.device] = "cpu",
+                 dtype: Union[torch.dtype, None] = None, *, decoder: bool = True):
+        super().__init__()
+        self.cfg = cfg
+        self.d_in = d_in
+        self.num_latents = cfg.num_latents or d_in * cfg.expansion_factor
+
+        self.encoder = nn.Linear(d_in, self.num_latents, device=device, dtype=dtype)
+        self.encoder.bias.data.zero_()
+        self.W_dec = nn.Parameter(self.encoder.weight.data.clone()) if decoder else None
+        if decoder and self.cfg.normalize_decoder:
+            self.set_decoder_norm_to_unit_norm()
+        self.b_dec = nn.Parameter(torch.zeros(d_in, dtype=dtype, device=device))
+        self._prepared: Optional[Tensor] = None
+        self._prepared_key = None
+
+    # ---- checkpoint I/O (sae.py:69-162) -----------------------------------------------------------
+    @staticmethod
+    def load_many(name: str, local: bool = False, layers: Union[list, None] = None,
+                  device: Union[str, torch.device] = "cpu", *, decoder: bool = True,
+                  pattern: Union[str, None] = None) -> dict:
+        pattern = pattern + "/*" if pattern is not None else None
+        if local:
+            repo_path = Path(name)
+        else:
+            from huggingface_hub import snapshot_download
+
+            repo_path = Path(snapshot_download(name, allow_patterns=pattern))
+        if layers is not None:
+            return {layer: Sae.load_from_disk(repo_path / layer, device=device, decoder=decoder)
+                    for layer in sorted(layers, key=_natural_key)}
+        dirs = [f for f in repo_path.iterdir()
+                if f.is_dir() and (pattern is None or fnmatch(f.name, pattern))]
+        return {f.name: Sae.load_from_disk(f, device=device, decoder=decoder)
+                for f in sorted(dirs, key=lambda f: _natural_key(f.name))}
+
+    @staticmethod
+    def load_from_hub(name: str, hookpoint: Union[str, None] = None,
+                      device: Union[str, torch.device] = "cpu", *, decoder: bool = True) -> "Sae":
+        from huggingface_hub import snapshot_download
+
+        repo_path = Path(snapshot_download(
+            name, allow_patterns=f"{hookpoint}/*" if hookpoint is not None else None))
+        if hookpoint is not None:
+            repo_path = repo_path / hookpoint
+        elif not repo_path.joinpath("cfg.json").exists():
+            raise FileNotFoundError("No config file found; try specifying a layer.")
+        return Sae.load_from_disk(repo_path, device=device, decoder=decoder)
+
+    @staticmethod
+    def load_from_disk(path: Union[Path, str], device: Union[str, torch.device] = "cpu", *,
+                       decoder: bool = True) -> "Sae":
+        from safetensors.torch import load_model
+
+        path = Path(path)
+        with open(path / "cfg.json", "r") as f:
+            cfg_dict = json.load(f)
+        d_in = cfg_dict.pop("d_in")
+        cfg = SaeConfig.from_dict(cfg_dict)
+        sae = Sae(d_in, cfg, device=device, decoder=decoder)
+        load_model(model=sae, filename=str(path / "sae.safetensors"), device=str(device),
+                   strict=decoder)
+        return sae
+
+    def save_to_disk(self, path: Union[Path, str]):
+        from safetensors.torch import save_model
+
+        path = Path(path)
+        path.mkdir(parents=True, exist_ok=True)
+        save_model(self, str(path / "sae.safetensors"))
+        with open(path / "cfg.json", "w") as f:
+            json.dump({**self.cfg.to_dict(), "d_in": self.d_in}, f)
+
+    @property
+    def device(self):
+        return self.encoder.weight.device
+
+    @property
+    def dtype(self):
+        return self.encoder.weight.dtype
+
+    # ---- hot path -----------------------------------------------------------------------------------
+    def pre_acts(self, x: Tensor) -> Tensor:
+        """relu((x - b_dec) W_enc^T + b_enc) as a dense [..., N] f32 tensor (sae.py:172-177).
+        Kept for callers that edit or reduce the dense latents (steering.py:111-114,
+        tools/probe_activations.py:116); the caching / encode paths use the fused op instead."""
+        return ops.pre_acts(x, self.encoder.weight, self.encoder.bias, self.b_dec)
+
+    def select_topk(self, latents: Tensor) -> EncoderOutput:
+        """Top-k latents (sae.py:179-181).  Order is canonical (value desc, index asc), a valid
+        instance of the reference's `sorted=False`."""
+        return EncoderOutput(*ops.topk(latents, self.cfg.k))
+
+    def _prepared_weights(self) -> Optional[Tensor]:
+        w = self.encoder.weight
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        if self._prepared is None or self._prepared_key != key:
+            self._prepared = ops.prepare_encoder(w)
+            self._prepared_key = key
+        return self._prepared
+
+    def encode(self, x: Tensor, *, set_feature: int = -1, set_value: float = 0.0,
+               zero_feature: int = -1, return_status: bool = False):
+        """Fused encode + TopK (sae.py:183-185).  `set_feature/set_value` and `zero_feature` apply
+        the steering / attribution hooks' edits of the dense latents (steering.py:113-114,
+        patching/utils.py:43-48) inside the kernel, before TopK."""
+        acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
+                                            self._prepared_weights(), self.cfg.k, set_feature,
+                                            float(set_value), zero_feature)
+        out = EncoderOutput(acts, idx)
+        return (out, status) if return_status else out
+
+    def decode(self, top_acts: Tensor, top_indices: Tensor) -> Tensor:
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        return ops.decode(top_indices, top_acts.to(self.dtype), self.W_dec, self.b_dec)
+
+    def forward(self, x: Tensor, dead_mask: Union[Tensor, None] = None) -> ForwardOutput:
+        """Training forward (sae.py:193-247): reconstruction, FVU, AuxK and Multi-TopK terms.
+        Gradients flow through `decode` (W_dec, b_dec, activations); the encoder's backward is the
+        trainer row of DESIGN.md section 8(f)."""
+        pre_acts = self.pre_acts(x)
+        top_acts, top_indices = self.select_topk(pre_acts)
+        sae_out = self.decode(top_acts, top_indices)
+        e = sae_out - x
+        total_variance = (x - x.mean(0)).pow(2).sum()
+
+        if dead_mask is not None and (num_dead := int(dead_mask.sum())) > 0:
+            k_aux = x.shape[-1] // 2
+            scale = min(num_dead / k_aux, 1.0)
+            k_aux = min(k_aux, num_dead)
+            auxk_latents = torch.where(dead_mask[None], pre_acts, -torch.inf)
+            auxk_acts, auxk_indices = ops.topk(auxk_latents, k_aux)
+            e_hat = self.decode(auxk_acts, auxk_indices)
+            auxk_loss = scale * (e_hat - e).pow(2).sum() / total_variance
+        else:
+            auxk_loss = sae_out.new_tensor(0.0)
+
+        fvu = e.pow(2).sum() / total_variance
+        if self.cfg.multi_topk:
+            top_acts, top_indices = ops.topk(pre_acts, 4 * self.cfg.k)
+            sae_out = self.decode(top_acts, top_indices)
+            multi_topk_fvu = (sae_out - x).pow(2).sum() / total_variance
+        else:
+            multi_topk_fvu = sae_out.new_tensor(0.0)
+        return ForwardOutput(sae_out, top_acts, top_indices, fvu, auxk_loss, multi_topk_fvu)
+
+    # ---- decoder-norm utilities (sae.py:249-271) ------------------------------------------------------
+    @torch.no_grad()
+    def set_decoder_norm_to_unit_norm(self):
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        eps = torch.finfo(self.W_dec.dtype).eps
+        self.W_dec.data /= torch.norm(self.W_dec.data, dim=1, keepdim=True) + eps
+
+    @torch.no_grad()
+    def remove_gradient_parallel_to_decoder_directions(self):
+        assert self.W_dec is not None, "Decoder weight was not initialized."
+        assert self.W_dec.grad is not None
+        along = (self.W_dec.grad * self.W_dec.data).sum(dim=1, keepdim=True)
+        self.W_dec.grad -= along * self.W_dec.data

@@ -1,0 +1,161 @@
+"""CPU: the C-ABI library loads and exports every symbol include/msae.h declares (no compute),
+and the host-side logic that needs no GPU (config, checkpoint I/O, split naming, error paths)."""
+import json
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = (REPO / "include" / "msae.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msae_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from msae import _hip
+
+    lib = _hip.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"libmsae_hip.so does not export {name}"
+    assert set(declared) == set(_hip.PROTOTYPES), set(declared) ^ set(_hip.PROTOTYPES)
+    assert lib.msae_abi_version() == 1
+    assert lib.msae_target_arch() == b"gfx950"
+    assert b"workspace" in lib.msae_error_string(-3)
+    # pure host-side size queries (no GPU needed)
+    assert lib.msae_encoder_prepared_bytes(131072, 4096) >= 131072 * 4096 * 2
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32) > 0
+    assert lib.msae_encode_topk_ws_bytes(16, 768, 4096, 32) >= 16 * 4096 * 4
+
+
+def test_compute_on_cpu_tensors_raises_instead_of_falling_back():
+    from msae import Sae, SaeConfig, ops
+
+    sae = Sae(16, SaeConfig(num_latents=64, k=4))
+    x = torch.randn(3, 16)
+    for fn in (lambda: sae.pre_acts(x), lambda: sae.encode(x),
+               lambda: sae.decode(torch.rand(3, 4), torch.zeros(3, 4, dtype=torch.long)),
+               lambda: ops.topk(torch.randn(3, 64), 4)):
+        with pytest.raises(RuntimeError, match="MI355X|HIP"):
+            fn()
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from msae import _hip
+
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setenv("MSAE_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_hip.MsaeLibraryMissing):
+        _hip.load()
+
+
+def test_sae_checkpoint_roundtrip_and_cfg_json(tmp_path):
+    """cfg.json keys and state-dict keys are the reference's (sae.py:126-162)."""
+    from safetensors.torch import load_file
+
+    from msae import Sae, SaeConfig
+
+    sae = Sae(16, SaeConfig(num_latents=64, k=4))
+    assert sae.num_latents == 64 and sae.W_dec.shape == (64, 16)
+    assert torch.allclose(sae.W_dec.norm(dim=1), torch.ones(64), atol=1e-5)  # normalize_decoder
+    assert torch.count_nonzero(sae.encoder.bias) == 0 and torch.count_nonzero(sae.b_dec) == 0
+    sae.save_to_disk(tmp_path / "model.layers.24")
+    cfg = json.loads((tmp_path / "model.layers.24" / "cfg.json").read_text())
+    assert cfg == {"expansion_factor": 32, "normalize_decoder": True, "num_latents": 64, "k": 4,
+                   "multi_topk": False, "signed": False, "d_in": 16}
+    assert sorted(load_file(tmp_path / "model.layers.24" / "sae.safetensors")) == \
+        ["W_dec", "b_dec", "encoder.bias", "encoder.weight"]
+    back = Sae.load_from_disk(tmp_path / "model.layers.24")
+    assert torch.equal(back.W_dec, sae.W_dec) and back.cfg == sae.cfg and back.d_in == 16
+    many = Sae.load_many(str(tmp_path), local=True)
+    assert list(many) == ["model.layers.24"]
+    enc_only = Sae.load_from_disk(tmp_path / "model.layers.24", decoder=False)
+    assert enc_only.W_dec is None
+    with pytest.raises(AssertionError):
+        enc_only.decode(torch.rand(1, 4), torch.zeros(1, 4, dtype=torch.long))
+    assert Sae(8, SaeConfig(expansion_factor=4)).num_latents == 32
+
+
+def test_split_indices_match_reference(golden_dir):
+    from msae.features import generate_split_indices
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    for key in g.files:
+        if key.startswith("splits_"):
+            _, width, n = key.split("_")
+            assert generate_split_indices(int(width), int(n)) == [tuple(r) for r in g[key].tolist()]
+    si = generate_split_indices(131072, 128)
+    assert si[:2] == [(0, 1023), (1024, 2047)]
+
+
+def test_save_splits_and_concat_file_layout(golden_dir, tmp_path):
+    """Writer reproduces the reference's per-rank and concatenated files (cache.py:249-309),
+    including the dropped last feature of each split; two ranks concatenate in rank order."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from msae.features import cache as C
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    module = "model.layers.24"
+    loc = torch.from_numpy(g["nofilter_locations"])
+    act = torch.from_numpy(g["nofilter_activations"])
+    fc = C.FeatureCache.__new__(C.FeatureCache)
+    fc.width = int(g["N"])
+    fc.cache = C.Cache(shard_size=0)
+    fc.cache.feature_locations[module], fc.cache.feature_activations[module] = loc, act
+    fc.save_splits(4, str(tmp_path), rank=0)
+    assert sorted(os.listdir(tmp_path / module)) == list(g["split_rank_files"])
+    # a second rank with shifted rows
+    loc1 = loc.clone(); loc1[:, 0] += 1000
+    fc.cache.feature_locations[module] = loc1
+    fc.save_splits(4, str(tmp_path), rank=1)
+    fc.concate_safetensors(4, str(tmp_path))
+    names = sorted(os.listdir(tmp_path / module))
+    assert names == list(g["split_concat_files"])
+    total = 0
+    for nm in names:
+        dat = load_file(str(tmp_path / module / nm))
+        ref_l, ref_a = g[f"split_{nm}_locations"], g[f"split_{nm}_activations"]
+        n = len(ref_l)
+        assert np.array_equal(dat["locations"][:n].numpy(), ref_l)
+        assert np.array_equal(dat["locations"][n:, 0].numpy(), ref_l[:, 0] + 1000)
+        assert np.array_equal(dat["activations"][:n].numpy(), ref_a)
+        total += n
+        start, end = (int(v) for v in nm.split(".")[0].split("_"))
+        f = dat["locations"][:, 2]
+        assert bool(((f >= start) & (f < end)).all())     # feature == end is dropped (quirk)
+    dropped = int((np.isin(g["nofilter_locations"][:, 2], [15, 31, 47, 63])).sum())
+    assert total == len(loc) - dropped
+    # the fixed variant keeps them
+    fc.cache.feature_locations[module] = loc
+    fc.save_splits(4, str(tmp_path / "fixed"), rank=0, include_split_end=True)
+    kept = sum(len(load_file(str(tmp_path / "fixed" / module / f))["activations"])
+               for f in os.listdir(tmp_path / "fixed" / module))
+    assert kept == len(loc)
+
+
+def test_legacy_dense_cache_add_matches_reference(golden_dir):
+    """Cache.add on DENSE latents (cache.py:42-92) -- pure torch, runs anywhere."""
+    import synth
+    from oracle import oracle
+    from msae.features import Cache
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    d, N, k = int(g["d"]), int(g["N"]), int(g["k"])
+    W_enc, b_enc, _, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    pre = oracle.pre_acts(g["x"].reshape(-1, d), W_enc, b_enc, b_dec)
+    v, i = oracle.topk(pre, k)
+    dense = torch.zeros(6, N).scatter_(-1, torch.from_numpy(i).long(), torch.from_numpy(v)).view(2, 3, N)
+    for tag, filt in (("nofilter", None), ("filter", {"m": torch.from_numpy(g["filter_features"])})):
+        c = Cache(shard_size=100, filters=filt, batch_size=2)
+        c.add(dense, 5, "m")
+        c.save()
+        assert np.array_equal(c.feature_locations["m"].numpy(), g[f"{tag}_locations"])

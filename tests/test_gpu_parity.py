@@ -1,0 +1,430 @@
+"""GPU parity: the HIP path (through the C ABI / torch.ops.msae) against the CPU oracle and the
+golden fixtures generated from the reference.  Run on a real MI355X: `pytest -m gpu`.
+
+Bars:
+  * HIP vs oracle (same arithmetic definition): BIT-EXACT values and indices.
+  * HIP vs reference fixtures: tolerance of the fp32 summation-order difference (RTOL 1e-4);
+    indices identical wherever the reference's (k, k+1) gap exceeds EPS_GAP.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+EPS_GAP = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from msae import _hip
+
+    _hip.load()  # fail loudly if the native library is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.kind == "f":
+        # -0.0 == +0.0 is accepted (the oracle skips zero activations, the kernel selects)
+        bad = (_bits(a) != _bits(b)) & ~((a == 0) & (b == 0))
+    else:
+        bad = a != b
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.size} elements differ; first at {np.argwhere(bad)[0]}"
+
+
+# ---- decode -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("A,k,N,d", [(2, 10, 100, 50), (7, 32, 4096, 768), (64, 32, 16384, 4096),
+                                     (3, 256, 16384, 4096), (1, 1, 8, 4)])
+def test_decode_bit_exact_vs_oracle(dev, A, k, N, d):
+    from msae import ops
+
+    rng = np.random.default_rng(A * 1000 + k)
+    W_dec = synth.normalish(11, N * d).reshape(N, d)
+    b_dec = synth.normalish(12, d)
+    idx = np.stack([rng.permutation(N)[:k] for _ in range(A)]).astype(np.int32)
+    acts = np.abs(synth.normalish(13, A * k).reshape(A, k)).astype(np.float32)
+    acts[0, 0] = 0.0  # a zero activation must be skipped (kernels.py:277)
+    ref = oracle.decode(idx, acts, W_dec, b_dec)
+    out = ops.decode(_t(idx, dev).long(), _t(acts, dev), _t(W_dec, dev), _t(b_dec, dev)).cpu().numpy()
+    assert_bit_equal(out, ref, "decode")
+
+
+def test_decode_reference_seam_test(dev, golden_dir):
+    """train/sae/tests/test_decode.py:6-20 through the reference's own seam signature."""
+    from msae.sae.utils import decoder_impl
+
+    g = np.load(golden_dir / "g3_decode_seam.npz")
+    W_dec = _t(g["W_dec"], dev)
+    out = decoder_impl(_t(g["top_idx"], dev).long(), _t(g["top_vals"], dev), W_dec.mT)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(g["eager"]), rtol=1.3e-6, atol=1e-5)
+
+
+def test_decode_backward_matches_reference_autograd(dev, golden_dir):
+    from msae import ops
+
+    g = np.load(golden_dir / "g7_train.npz")
+    d, N = int(g["d"]), int(g["N"])
+    _, _, W_dec, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    W = _t(W_dec, dev).requires_grad_()
+    b = _t(b_dec, dev).requires_grad_()
+    acts = _t(g["dec_acts"], dev).requires_grad_()
+    y = ops.decode(_t(g["dec_idx"], dev).long(), acts, W, b)
+    y.backward(_t(g["dec_gout"], dev))
+    np.testing.assert_allclose(acts.grad.cpu().numpy(), g["dec_grad_acts"], rtol=1e-4, atol=1e-5)
+    rows = g["dec_idx"].reshape(-1)
+    np.testing.assert_allclose(W.grad[rows].cpu().numpy(), g["dec_grad_Wdec_rows"], rtol=1e-4, atol=1e-5)
+    assert int((W.grad.abs().sum(1) > 0).sum()) == int(g["dec_grad_Wdec_nnzrows"])
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g["dec_grad_bdec"], rtol=1e-4, atol=1e-5)
+    ga = oracle.decode_bwd_acts(g["dec_idx"], g["dec_gout"], W_dec)
+    np.testing.assert_allclose(acts.grad.cpu().numpy(), ga, rtol=1e-4, atol=1e-5)
+
+
+# ---- top-k ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,N,k", [(4, 131072, 32), (3, 131072, 256), (5, 4096, 32), (3, 1000, 7),
+                                   (2, 37, 37), (2, 8192, 16), (2, 16384, 2048), (1, 5, 1)])
+def test_topk_bit_exact_vs_oracle(dev, T, N, k):
+    from msae import ops
+
+    lat = synth.normalish(50 + k, T * N).reshape(T, N)
+    lat[0] = np.maximum(lat[0], 0)          # post-ReLU row: about half exact zeros
+    if T > 1:
+        lat[1] = np.round(lat[1] * 4) / 4   # heavy ties
+    if T > 2:
+        lat[2] = 0.0
+        lat[2, : min(N, 5)] = 1.0            # fewer than k positives: zeros fill by ascending index
+    ref_v, ref_i = oracle.topk(lat, k)
+    v, i = ops.topk(_t(lat, dev), k)
+    assert i.dtype == torch.int64
+    assert_bit_equal(i.cpu().numpy().astype(np.int32), ref_i, "topk idx")
+    assert_bit_equal(v.cpu().numpy(), ref_v, "topk vals")
+
+
+# ---- exact encoder ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,d,N,dtype", [(64, 768, 4096, torch.bfloat16), (5, 50, 100, torch.float32),
+                                         (130, 64, 1024, torch.float16), (16, 4096, 16384, torch.bfloat16),
+                                         (1, 16, 64, torch.float32), (200, 768, 4100, torch.float32)])
+def test_pre_acts_bit_exact_vs_oracle(dev, T, d, N, dtype):
+    from msae import ops
+
+    W_enc, b_enc, _, b_dec = synth.sae_weights(d, N, seed=3)
+    x = synth.activations(T, d, seed=T, bf16=(dtype != torch.float32), n_outlier=1)
+    xt = _t(x, dev, dtype)
+    x_up = xt.float().cpu().numpy()          # exactly what the kernel up-casts
+    ref = oracle.pre_acts(x_up, W_enc, b_enc, b_dec)
+    out = ops.pre_acts(xt, _t(W_enc, dev), _t(b_enc, dev), _t(b_dec, dev)).cpu().numpy()
+    assert_bit_equal(out, ref, "pre_acts")
+
+
+def _canon_np(v, i):
+    order = np.lexsort((i, -v.astype(np.float64)), axis=-1)
+    return np.take_along_axis(v, order, -1), np.take_along_axis(i, order, -1)
+
+
+@pytest.mark.parametrize("name", ["g1_c1_d768_n4096", "g2_d4096_n16384"])
+def test_sae_module_matches_reference_fixture(dev, golden_dir, name):
+    """Drop-in Sae (pre_acts / select_topk / encode / decode) vs outputs of the reference itself."""
+    from msae import Sae, SaeConfig
+
+    g = np.load(golden_dir / f"{name}.npz")
+    d, N, T = int(g["d"]), int(g["N"]), int(g["T"])
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    x = _t(synth.activations(T, d, int(g["xseed"])), dev, torch.bfloat16)
+    for k in g["ks"]:
+        k = int(k)
+        sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)
+        with torch.no_grad():
+            sae.encoder.weight.copy_(_t(W_enc, dev)); sae.encoder.bias.copy_(_t(b_enc, dev))
+            sae.W_dec.copy_(_t(W_dec, dev)); sae.b_dec.copy_(_t(b_dec, dev))
+            pre = sae.pre_acts(x)
+            top = sae.select_topk(pre)
+            enc = sae.encode(x)
+            recon = sae.decode(top.top_acts, top.top_indices)
+        assert torch.equal(enc.top_indices, top.top_indices) and torch.equal(enc.top_acts, top.top_acts)
+        np.testing.assert_allclose(pre[:8, :256].cpu().numpy(), g["pre_slice"], rtol=RTOL, atol=RTOL)
+        v, i = top.top_acts.cpu().numpy(), top.top_indices.cpu().numpy()
+        ref_v, ref_i, gap = g[f"k{k}_acts"], g[f"k{k}_idx"], g[f"k{k}_gap"]
+        np.testing.assert_allclose(v, ref_v, rtol=RTOL, atol=RTOL)
+        safe = gap > EPS_GAP
+        sep = np.all(np.abs(np.diff(ref_v, axis=1)) > EPS_GAP, axis=1) & safe
+        assert sep.mean() > 0.5
+        assert np.array_equal(i[sep], ref_i[sep])
+        for t in np.nonzero(safe)[0]:
+            assert set(i[t][v[t] > 0]) == set(ref_i[t][ref_v[t] > 0])
+        ref_r = g[f"k{k}_recon"]
+        assert np.abs(recon.cpu().numpy()[safe] - ref_r[safe]).max() <= RTOL * np.abs(ref_r).max()
+
+
+# ---- fused encoder ---------------------------------------------------------------------------------------
+def _rand_sae(dev, d, N, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    W_enc = torch.randn(N, d, generator=g, device=dev) / d ** 0.5
+    b_enc = torch.randn(N, generator=g, device=dev) * 0.05
+    b_dec = torch.randn(d, generator=g, device=dev) * 0.1
+    return W_enc, b_enc, b_dec
+
+
+def _rand_x(dev, T, d, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(T, d, generator=g, device=dev)
+    x[:, 13] *= 20.0
+    x[:, 990 % d] *= 20.0
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("T,d,N,k", [(384, 4096, 16384, 32), (300, 1024, 8192, 64)])
+def test_fused_encode_bit_exact_vs_oracle(dev, T, d, N, k):
+    from msae import ops
+
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 5)
+    x = _rand_x(dev, T, d, 6)
+    prepared = ops.prepare_encoder(W_enc)
+    v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)
+    ref_v, ref_i = oracle.encode_topk(x.float().cpu().numpy(), W_enc.cpu().numpy(), b_enc.cpu().numpy(),
+                                      b_dec.cpu().numpy(), k)
+    st = status.cpu().numpy()
+    assert (st != 2).all(), "unresolved tokens"
+    assert (st == 0).mean() > 0.9, f"fast path verified only {(st == 0).mean():.2%} of tokens"
+    assert_bit_equal(i.cpu().numpy().astype(np.int32), ref_i, "fused idx")
+    assert_bit_equal(v.cpu().numpy(), ref_v, "fused vals")
+
+
+def test_fused_encode_full_width_matches_exact_path(dev):
+    """BASELINE config 2 shape: d=4096, N=131072, k=32 (and k=256).  Fused path == exact HIP path
+    bit for bit on every token; exact HIP path == oracle on a subset of tokens."""
+    from msae import ops
+
+    d, N, T = 4096, 131072, 320
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 7)
+    x = _rand_x(dev, T, d, 8)
+    prepared = ops.prepare_encoder(W_enc)
+    pre = ops.pre_acts(x, W_enc, b_enc, b_dec)
+    for k in (32, 256):
+        ev, ei = ops.topk(pre, k)
+        v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)
+        st = status.cpu().numpy()
+        assert (st != 2).all()
+        assert (st == 0).mean() > 0.9, f"k={k}: fast path verified only {(st == 0).mean():.2%}"
+        assert torch.equal(i, ei), f"k={k}: indices differ on {(i != ei).any(-1).sum().item()} tokens"
+        assert torch.equal(v, ev)
+    ref_v, ref_i = oracle.encode_topk(x[:8].float().cpu().numpy(), W_enc.cpu().numpy(),
+                                      b_enc.cpu().numpy(), b_dec.cpu().numpy(), 32)
+    ev, ei = ops.topk(pre[:8], 32)
+    assert_bit_equal(ei.cpu().numpy().astype(np.int32), ref_i, "exact idx vs oracle")
+    assert_bit_equal(ev.cpu().numpy(), ref_v, "exact vals vs oracle")
+
+
+def test_fused_encode_hook_edits(dev):
+    """set_feature (steering.py:113-114) / zero_feature (patching/utils.py:43-48) inside the fused
+    kernel == the same edits applied to the dense latents."""
+    from msae import ops
+
+    d, N, T, k = 1024, 8192, 300, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 9)
+    x = _rand_x(dev, T, d, 10)
+    prepared = ops.prepare_encoder(W_enc)
+    pre = ops.pre_acts(x, W_enc, b_enc, b_dec)
+    hot = int(pre[0].argmax())
+    for kw in (dict(set_feature=77, set_value=10.0), dict(zero_feature=hot),
+               dict(set_feature=5, set_value=0.25, zero_feature=hot)):
+        lat = pre.clone()
+        if kw.get("set_feature", -1) >= 0:
+            lat[:, kw["set_feature"]] = kw["set_value"]
+        if kw.get("zero_feature", -1) >= 0:
+            lat[:, kw["zero_feature"]] = 0.0
+        ev, ei = ops.topk(lat, k)
+        v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k, **kw)
+        assert (status != 2).all()
+        assert torch.equal(i, ei) and torch.equal(v, ev), kw
+    # small-T (exact dispatch) with edits, the steering decode-step shape
+    v, i, _ = ops.encode_topk(x[:1], W_enc, b_enc, b_dec, prepared, k, set_feature=77, set_value=10.0)
+    lat = pre[:1].clone(); lat[:, 77] = 10.0
+    ev, ei = ops.topk(lat, k)
+    assert torch.equal(i, ei) and torch.equal(v, ev)
+
+
+def test_fused_encode_degenerate_tokens_take_exact_path(dev):
+    """Tokens with (almost) no positive pre-activation cannot pass the guard band: they must come
+    back from the in-call exact fallback (status 1) with the canonical zero-filled top-k."""
+    from msae import ops
+
+    d, N, T, k = 1024, 8192, 300, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 11)
+    b_enc = b_enc - 100.0                      # every pre-activation negative -> all latents zero
+    x = _rand_x(dev, T, d, 12)
+    x[5:] = (x[5:].float() * 0).to(x.dtype)    # keep it cheap: only 5 distinct rows
+    prepared = ops.prepare_encoder(W_enc)
+    v, i, status = ops.encode_topk(x[:300], W_enc, b_enc, b_dec, prepared, k)
+    st = status.cpu().numpy()
+    assert (st >= 1).all()
+    ok = st == 1
+    assert ok.sum() >= 100                     # FB_MAX = 128 tokens are resolved inside the call
+    assert (v[torch.from_numpy(ok).to(dev)] == 0).all()
+    exp = torch.arange(k, device=dev).expand(int(ok.sum()), k)
+    assert torch.equal(i[torch.from_numpy(ok).to(dev)], exp)
+
+
+# ---- cache sparsify + files ----------------------------------------------------------------------------------
+def test_sparsify_matches_reference_cache(dev, golden_dir):
+    from msae import ops
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    d, N, k = int(g["d"]), int(g["N"]), int(g["k"])
+    W_enc, b_enc, _, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    x = _t(g["x"], dev)
+    v, i, _ = ops.encode_topk(x, _t(W_enc, dev), _t(b_enc, dev), _t(b_dec, dev), None, k)
+    loc, act = ops.sparsify(v, i, N, row_base=5 * 2 + 100)
+    assert np.array_equal(loc.cpu().numpy(), g["nofilter_locations"])
+    np.testing.assert_allclose(act.cpu().numpy(), g["nofilter_activations"], rtol=1e-5)
+    bm = torch.zeros(N, dtype=torch.uint8, device=dev)
+    bm[_t(g["filter_features"], dev).long()] = 1
+    loc, act = ops.sparsify(v, i, N, row_base=110, filter_bitmap=bm)
+    assert np.array_equal(loc.cpu().numpy(), g["filter_locations"])
+    np.testing.assert_allclose(act.cpu().numpy(), g["filter_activations"], rtol=1e-5)
+
+
+def test_sparsify_bit_exact_vs_oracle_large(dev):
+    from msae import ops
+
+    B, S, k, N = 3, 50, 32, 131072
+    rng = np.random.default_rng(0)
+    idx = np.stack([rng.permutation(N)[:k] for _ in range(B * S)]).astype(np.int32).reshape(B, S, k)
+    vals = np.maximum(synth.normalish(5, B * S * k).reshape(B, S, k), 0).astype(np.float32)
+    vals[0, 0, :3] = [1e-5, 1.0000001e-5, 9e-6]   # threshold edge: > 1e-5 strictly
+    bitmap = (rng.random(N) < 0.5).astype(np.uint8)
+    for fb in (None, bitmap):
+        ref_loc, ref_act = oracle.sparsify(vals, idx, B, S, row_base=1234567, filter_bitmap=fb)
+        loc, act = ops.sparsify(_t(vals, dev), _t(idx, dev).long(), N, row_base=1234567,
+                                filter_bitmap=None if fb is None else _t(fb, dev))
+        assert np.array_equal(loc.cpu().numpy(), ref_loc)
+        assert_bit_equal(act.cpu().numpy(), ref_act, "sparsify act")
+
+
+class _TinyLM(torch.nn.Module):
+    """Stand-in for the HF decoder stack: embeds ids, one hooked layer `model.layers.24`."""
+
+    def __init__(self, table: torch.Tensor):
+        super().__init__()
+        self.embed = torch.nn.Embedding.from_pretrained(table)
+        self.model = torch.nn.Module()
+        self.model.layers = torch.nn.ModuleDict({"24": torch.nn.Identity()})
+
+    def forward(self, input_ids):
+        return (self.model.layers["24"](self.embed(input_ids)),)
+
+
+def test_feature_cache_end_to_end_files(dev, golden_dir, tmp_path):
+    """FeatureCache.run -> save_splits -> concate_safetensors reproduces the files the reference
+    wrote for the same activations (fixture g4: names, locations, activations)."""
+    from safetensors.torch import load_file
+
+    from msae import Sae, SaeConfig
+    from msae.features import FeatureCache
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    d, N, k = int(g["d"]), int(g["N"]), int(g["k"])
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)
+    with torch.no_grad():
+        sae.encoder.weight.copy_(_t(W_enc, dev)); sae.encoder.bias.copy_(_t(b_enc, dev))
+        sae.W_dec.copy_(_t(W_dec, dev)); sae.b_dec.copy_(_t(b_dec, dev))
+    x = g["x"]  # [2, 3, d]: token id b*3+s -> row of the embedding table
+    lm = _TinyLM(_t(x.reshape(6, d), dev)).to(dev)
+    module = "model.layers.24"
+    fc = FeatureCache(lm, None, {module: sae}, batch_size=2, shard_size=100)
+    # 6 batches of 2 sequences; batch 5 is the fixture's batch (row offset 5*2+100)
+    ids = torch.arange(6).reshape(2, 3)
+    dataset = [{"input_ids": ids[b % 2]} for b in range(12)]
+    dataset[10]["input_ids"], dataset[11]["input_ids"] = ids[0], ids[1]
+    fc.run(3, dataset)
+    loc = fc.cache.feature_locations[module]
+    sel = loc[:, 0] >= 110
+    assert np.array_equal(loc[sel].numpy(), g["nofilter_locations"])
+    np.testing.assert_allclose(fc.cache.feature_activations[module][sel].numpy(),
+                               g["nofilter_activations"], rtol=1e-5)
+    # file layout, restricted to the fixture's rows
+    fc.cache.feature_locations[module] = loc[sel]
+    fc.cache.feature_activations[module] = fc.cache.feature_activations[module][sel]
+    fc.cache.shard_size = 0
+    fc.save_splits(4, str(tmp_path), rank=0)
+    import os
+    assert sorted(os.listdir(tmp_path / module)) == list(g["split_rank_files"])
+    fc.concate_safetensors(4, str(tmp_path))
+    names = sorted(os.listdir(tmp_path / module))
+    assert names == list(g["split_concat_files"])
+    for nm in names:
+        dat = load_file(str(tmp_path / module / nm))
+        assert np.array_equal(dat["locations"].numpy(), g[f"split_{nm}_locations"])
+        np.testing.assert_allclose(dat["activations"].numpy(), g[f"split_{nm}_activations"], rtol=1e-5)
+
+
+# ---- hooks + training forward ------------------------------------------------------------------------------
+def _golden_sae(dev, g):
+    from msae import Sae, SaeConfig
+
+    d, N, k = int(g["d"]), int(g["N"]), int(g["k"])
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, int(g["wseed"]))
+    sae = Sae(d, SaeConfig(num_latents=N, k=k, multi_topk=True), device=dev)
+    with torch.no_grad():
+        sae.encoder.weight.copy_(_t(W_enc, dev)); sae.encoder.bias.copy_(_t(b_enc, dev))
+        sae.W_dec.copy_(_t(W_dec, dev)); sae.b_dec.copy_(_t(b_dec, dev))
+    return sae
+
+
+def test_steering_and_attribution_hooks_match_reference(dev, golden_dir):
+    from msae.features import attribution_sae_hook, clamp_features_max
+
+    g = np.load(golden_dir / "g5_hooks.npz")
+    sae = _golden_sae(dev, g)
+    layer = torch.nn.Identity()
+    for S in (5, 1):
+        x = _t(g[f"steer_S{S}_x"], dev)
+        handles = clamp_features_max(sae, int(g[f"steer_S{S}_feature"]), layer, k=float(g[f"steer_S{S}_clamp"]))
+        with torch.no_grad():
+            out = layer(x)
+        for h in handles:
+            h.remove()
+        ref = g[f"steer_S{S}_out"]
+        assert out.dtype == torch.float16 and out.shape == x.shape
+        assert np.abs(out.float().cpu().numpy() - ref.astype(np.float32)).max() <= 2e-3 * np.abs(ref).max()
+    x = _t(g["attr_x"], dev)
+    for tag, off in (("none", None), ("off", int(g["attr_off_feature"]))):
+        cache = {}
+        h = layer.register_forward_hook(attribution_sae_hook({"L": sae}, {layer: "L"}, cache, off))
+        with torch.no_grad():
+            out = layer(x)
+        h.remove()
+        ref = g[f"attr_{tag}_out"]
+        assert np.abs(out.float().cpu().numpy() - ref.astype(np.float32)).max() <= 2e-3 * np.abs(ref).max()
+        assert cache["L"] is out
+
+
+def test_training_forward_matches_reference(dev, golden_dir):
+    g = np.load(golden_dir / "g7_train.npz")
+    sae = _golden_sae(dev, g)
+    out = sae(_t(g["x"], dev), _t(g["dead_mask"], dev))
+    assert abs(out.fvu.item() - float(g["fvu"])) <= 1e-4 * abs(float(g["fvu"]))
+    assert abs(out.auxk_loss.item() - float(g["auxk_loss"])) <= 1e-4 * abs(float(g["auxk_loss"]))
+    assert abs(out.multi_topk_fvu.item() - float(g["multi_topk_fvu"])) <= 1e-4 * abs(float(g["multi_topk_fvu"]))
+
+
+def test_cpu_tensors_raise(dev):
+    from msae import ops
+
+    with pytest.raises(RuntimeError):
+        ops.topk(torch.zeros(2, 8), 2)
