@@ -24,6 +24,7 @@
 // Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the guard
 // band holds, and ARE that path's outputs when it does not.
 #include "common.h"
+#include "gemm_bf16.h"
 
 int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                          const float *b_dec, const int *rows, const int *n_rows, int T, int d, int N,
@@ -46,7 +47,7 @@ struct Prepared {
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 
 __host__ __device__ inline bool fast_shape_ok(int N, int d) {
-  return N % (SAMPLE_STRIDE * 128) == 0 && d % 64 == 0 && N >= SAMPLE_STRIDE * 128;
+  return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/16 must tile by BN = 256
 }
 
 inline Prepared make_prepared(int N, int d) {
@@ -81,11 +82,13 @@ __global__ __launch_bounds__(256) void prepare_weights_kernel(const float *__res
   }
 }
 
-// xb[t][c] = bf16((float)x[t][c] - b_dec[c]) for t < T, zero rows up to Tp.
+// a32[t][c] = (float)x[t][c] - b_dec[c] (the exact f32 SAE input, sae.py:174) and
+// xb[t][c] = bf16(a32[t][c]) for t < T; xb rows up to Tp are zero.
 template <int DT>
 __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
                                                      const float *__restrict__ b_dec, int T, int Tp,
-                                                     int d, unsigned short *__restrict__ xb) {
+                                                     int d, unsigned short *__restrict__ xb,
+                                                     float *__restrict__ a32) {
   const size_t groups = (size_t)Tp * d / 4;
   for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (size_t)gridDim.x * 256) {
     const size_t e = g * 4;
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
     if ((int)t < T) {
       f32x4 v = load_x4<DT>(x, e);
       if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+      *reinterpret_cast<f32x4 *>(a32 + e) = v;
       o[0] = f32_to_bf16_bits(v[0]); o[1] = f32_to_bf16_bits(v[1]);
       o[2] = f32_to_bf16_bits(v[2]); o[3] = f32_to_bf16_bits(v[3]);
     }
@@ -101,246 +105,124 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
   }
 }
 
-// ---- bf16 MFMA GEMM ----------------------------------------------------------------------------
-constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_THREADS = 256;
-constexpr int G_TILE_BYTES = G_BM * G_BK * 2;           // 16 KiB per operand tile
-constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;         // A + B
-constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;          // double buffered: 64 KiB
-
-// LDS image of a [128 rows][64 bf16] tile: row r at byte r*128, its eight 16-B chunks permuted
-// by chunk' = chunk ^ ((r >> 1) & 7).  global_load_lds writes lane-linear (dest = base + lane*16),
-// so the permutation is applied to the per-lane SOURCE address and again on the fragment read.
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
-
-__device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ g, int row0,
-                                           int row_max, int ld, int k0, unsigned char *lds_tile,
-                                           int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;            // 1 KiB = 8 rows of the tile
-    const int r = piece * 8 + (lane >> 3);     // tile row this lane fills
-    const int c = (lane & 7) ^ swz(r);         // global chunk that lands in LDS slot (r, lane&7)
-    int grow = row0 + r;
-    grow = grow < row_max ? grow : row_max - 1;  // clamp: rows past the end are never used
-    const unsigned short *src = g + (size_t)grow * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)src,
-        (__attribute__((address_space(3))) void *)(lds_tile + piece * 1024), 16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ bf16x8 read_frag(const unsigned char *lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8 *>(lds_tile + row * 128 + ((chunk ^ swz(row)) << 4));
-}
-
-// tile id -> (tm, tn).  Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends
-// on it).  Each XCD walks super-tiles of 8 (M) x 4 (N) tiles so the 32 concurrently resident
-// workgroups of an XCD share 8 A-tiles and 4 B-tiles in that XCD's L2.
-__device__ __forceinline__ void map_tile(int b, int nM, int nN, int &tm, int &tn) {
-  constexpr int GM = 8, GN = 4;
-  if (nM % GM == 0 && nN % GN == 0 && ((nM / GM) * (nN / GN)) % 8 == 0) {
-    const int xcd = b & 7, slot = b >> 3;
-    const int grp = slot / (GM * GN), w = slot % (GM * GN);
-    const int st = grp * 8 + xcd;
-    const int nSM = nM / GM;
-    tm = (st % nSM) * GM + (w % GM);
-    tn = (st / nSM) * GN + (w / GM);
-  } else {
-    tm = b % nM;
-    tn = b / nM;
-  }
-}
-
-struct GemmEpilogue {
-  const float *bias;     // b_enc
-  int bias_stride, bias_off;   // feature of column n is n*bias_stride + bias_off
-  float *dense; int ld_dense;  // DENSE: out[t][n] = acc + bias
-  const float *tau_vals; int tau_ld, tau_col;  // THRESH: tau[t] = tau_vals[t*tau_ld + tau_col]
-  int *cnt; unsigned long long *cand; int cap;  // candidate lists
-  int skip_a, skip_b;  // features never emitted (hook edits replace their latents)
-};
-
-template <bool DENSE>
-__global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_kernel(
-    const unsigned short *__restrict__ A, const unsigned short *__restrict__ B, int T, int Tp, int d,
-    int N, int nM, int nN, GemmEpilogue ep) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  int tm, tn;
-  map_tile(blockIdx.x, nM, nN, tm, tn);
-  const int m0 = tm * G_BM, n0 = tn * G_BN;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = d / G_BK;
-  stage_tile(A, m0, Tp, d, 0, smem, wave, lane);
-  stage_tile(B, n0, N, d, 0, smem + G_TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int l31 = lane & 31, kh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    unsigned char *cur = smem + (kt & 1) * G_STAGE_BYTES;
-    unsigned char *nxt = smem + ((kt + 1) & 1) * G_STAGE_BYTES;
-    if (kt + 1 < nk) {
-      stage_tile(A, m0, Tp, d, (kt + 1) * G_BK, nxt, wave, lane);
-      stage_tile(B, n0, N, d, (kt + 1) * G_BK, nxt + G_TILE_BYTES, wave, lane);
-    }
-    const unsigned char *sA = cur, *sB = cur + G_TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < G_BK / 16; ++ks) {
-      const int chunk = ks * 2 + kh;
-      const bf16x8 a0 = read_frag(sA, wr * 64 + l31, chunk);
-      const bf16x8 a1 = read_frag(sA, wr * 64 + 32 + l31, chunk);
-      const bf16x8 b0 = read_frag(sB, wc * 64 + l31, chunk);
-      const bf16x8 b1 = read_frag(sB, wc * 64 + 32 + l31, chunk);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // epilogue.  C[i][n]: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  if constexpr (DENSE) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + l31;
-      const float bn = ep.bias ? ep.bias[n * ep.bias_stride + ep.bias_off] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int t = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n] = acc[i][j][e] + bn;
-        }
-    }
-  } else {
-    // all 32 per-lane thresholds first (independent loads), then the rare-survivor compares
-    float tau[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int t = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
-        tau[i][e] = (v > 0.f) ? v : __builtin_inff();  // degenerate / padded token: emit nothing
-      }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int feat = n0 + wc * 64 + j * 32 + l31;
-      const float bn = ep.bias ? ep.bias[feat] : 0.f;
-      const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][j][e] + bn;
-          if (v > tau[i][e] && live) {
-            const int t = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const int slot = atomicAdd(ep.cnt + t, 1);
-            if (slot < ep.cap)
-              ep.cand[(size_t)t * ep.cap + slot] =
-                  ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
-          }
-        }
-    }
-  }
-}
+// ---- bf16 MFMA GEMM: gemm_bf16.h.  Tile choice from tools/gemm_sweep on MI355X (T=8192, d=4096,
+// N=131072): 256x256x64, 2-slot ring, 8 waves as 2x4 -> ~1.2 PFLOP/s; 128x128x64 -> ~1.0 PFLOP/s.
+using GemmMain = GemmCfg<256, 256, 64, 2, 2, 4>;
+constexpr int G_BM = GemmMain::BM, G_BN = GemmMain::BN;
 
 // ---- candidate select + exact re-score ----------------------------------------------------------
 struct RescoreArgs {
-  const void *x; const float *W_enc, *b_enc, *b_dec;
+  const float *a32; const float *W_enc, *b_enc;
   const float *tau_vals; int tau_ld, tau_col;
   const int *cnt; const unsigned long long *cand; int cap;
-  int T, d, N, k, n_rescore;
+  int T, d, N, k, n_rescore, step, r_max;
   int set_feature; float set_value; int zero_feature;
   float *vals; int32_t *idx; int32_t *status;
   int *flagged; int *n_flagged;
 };
 
-// dynamic LDS: keys[cap] u64 | a[d] f32 | res[nrp] u64 | errs[n_rescore] f32 | maxerr f32
-template <int DT>
-__global__ __launch_bounds__(256) void select_rescore_kernel(RescoreArgs p) {
+// Wave-wide bitonic sort (descending) of n = power-of-two u64 keys in LDS by ONE 64-lane wave.
+__device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n, int lane) {
+  for (int size = 2; size <= n; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = lane; i < (n >> 1); i += 64) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = s[lo], y = s[hi];
+        if ((x < y) == desc) { s[lo] = y; s[hi] = x; }
+      }
+    }
+  __syncthreads();
+}
+
+// ONE WAVE per token (64-thread workgroup).  dynamic LDS: keys[cap] u64 | res[nrp] u64.
+//
+// The candidate list is ordered by coarse value; lane c re-scores candidate c with the exact
+// ascending-k f32 chain: it walks row f of W_enc with 8 x 16-B loads in flight (one 128-B line
+// per batch) while the token's f32 activation vector a32[t][:] arrives through wave-uniform
+// scalar loads.  No LDS staging of operands, so ~32 tokens per CU keep ~160 KB of row reads in
+// flight (HBM-bound: (k + step) * d * 4 B per token).
+//
+// Rounds: the best `n_rescore` candidates are re-scored; if the guard band
+//     v_k(exact) > max(best not-yet-rescored coarse, tau) + eps,   eps = 4 * max|coarse - exact|
+// does not hold and candidates remain, the next `step` are re-scored too, up to `r_max`.  Tokens
+// that still fail (or overflowed their list / have tau <= 0) go to the exact path.
+__global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
+                                                            const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
-  float *a = reinterpret_cast<float *>(smem + (size_t)p.cap * 8);
-  const int nrp = next_pow2(p.n_rescore + 1);
-  unsigned long long *res = reinterpret_cast<unsigned long long *>(smem + (size_t)p.cap * 8 + (size_t)p.d * 4);
-  float *errs = reinterpret_cast<float *>(res + nrp);
-  float &s_maxerr = errs[p.n_rescore];  // all LDS lives in the one dynamic array (16-B aligned base)
-
+  const int nrp = next_pow2(p.r_max + 1);
+  unsigned long long *res = keys + p.cap;
+  const int lane = threadIdx.x;
   const int t = blockIdx.x;
   const int cnt = p.cnt[t];
   const int n = cnt < p.cap ? cnt : p.cap;
   const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+  const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
 
-  for (int i = threadIdx.x; i < p.cap; i += 256) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
-  for (int c = threadIdx.x * 4; c < p.d; c += 1024) {
-    f32x4 v = load_x4<DT>(p.x, (size_t)t * p.d + c);
-    if (p.b_dec) v = v - *reinterpret_cast<const f32x4 *>(p.b_dec + c);
-    *reinterpret_cast<f32x4 *>(a + c) = v;
-  }
-  for (int i = threadIdx.x; i < nrp; i += 256) res[i] = 0ull;
-  if (threadIdx.x == 0) s_maxerr = 0.f;
-  bitonic_sort_desc_u64(keys, p.cap);   // coarse value desc (index asc on ties); barriers inside
+  const int np = next_pow2(n > 2 ? n : 2);
+  for (int i = lane; i < np; i += 64) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  for (int i = lane; i < nrp; i += 64) res[i] = 0ull;
+  wave_sort_desc_u64(keys, np, lane);   // coarse value desc (index asc on ties)
+  const int has_set = p.set_feature >= 0 ? 1 : 0;
+  if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
 
-  // exact ascending-k chain for the best n_rescore coarse candidates: one lane per candidate
-  const int C = n < p.n_rescore ? n : p.n_rescore;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const unsigned long long key = keys[c];
-    const int f = rank_key_index(key);
-    const float coarse = f32_from_order_key((unsigned)(key >> 32));
-    const float *w = p.W_enc + (size_t)f * p.d;
-    float acc = 0.f;
-    for (int kk = 0; kk < p.d; kk += 4) {
-      const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + kk);
-      const f32x4 av = *reinterpret_cast<const f32x4 *>(a + kk);
-      acc = __builtin_fmaf(av[0], wv[0], acc);
-      acc = __builtin_fmaf(av[1], wv[1], acc);
-      acc = __builtin_fmaf(av[2], wv[2], acc);
-      acc = __builtin_fmaf(av[3], wv[3], acc);
-    }
-    const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
-    const float lat = pre > 0.f ? pre : 0.f;
-    res[c] = rank_key(lat, f);
-    errs[c] = fabsf(pre - coarse);
-  }
-  if (threadIdx.x == 0 && p.set_feature >= 0) res[p.n_rescore] = rank_key(p.set_value, p.set_feature);
-  __syncthreads();
-  // max |coarse - exact| over the re-scored candidates (wave 0)
-  if (threadIdx.x < 64) {
-    float m = 0.f;
-    for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, errs[c]);
+  float my_err = 0.f;
+  int done = 0;                                  // candidates re-scored so far (wave-uniform)
+  int target = n < p.n_rescore ? n : p.n_rescore;
+  bool ok = false;
+  for (;;) {
+    for (int c0 = done; c0 < target; c0 += 64) {
+      const int c = c0 + lane;
+      const bool active = c < target;
+      const unsigned long long key = active ? keys[c] : keys[c0];
+      const int f = rank_key_index(key);
+      const float coarse = f32_from_order_key((unsigned)(key >> 32));
+      const float *__restrict__ w = W_enc + (size_t)f * p.d;
+      float acc = 0.f;
+      for (int kk = 0; kk < p.d; kk += 32) {     // d % 64 == 0 on this path
+        f32x4 wv[8];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-    if (threadIdx.x == 0) s_maxerr = m;
+        for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc = __builtin_fmaf(a[kk + 4 * u + 0], wv[u][0], acc);   // a[] is wave-uniform: SGPRs
+          acc = __builtin_fmaf(a[kk + 4 * u + 1], wv[u][1], acc);
+          acc = __builtin_fmaf(a[kk + 4 * u + 2], wv[u][2], acc);
+          acc = __builtin_fmaf(a[kk + 4 * u + 3], wv[u][3], acc);
+        }
+      }
+      const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
+      if (active) {
+        res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
+        my_err = fmaxf(my_err, fabsf(pre - coarse));
+      }
+    }
+    done = target;
+    float maxerr = my_err;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxerr = fmaxf(maxerr, __shfl_xor(maxerr, off, 64));
+    wave_sort_desc_u64(res, nrp, lane);
+    const float eps = 4.f * maxerr + 1e-30f;
+    const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
+    float bound = tau;
+    if (n > done) bound = fmaxf(bound, f32_from_order_key((unsigned)(keys[done] >> 32)));
+    const bool have_k = done + has_set >= p.k;
+    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && (v_k > bound + eps);
+    if (ok || done >= n || done >= p.r_max || !(tau > 0.f) || cnt > p.cap) break;
+    target = done + p.step;                       // extend the re-scored set
+    if (target > n) target = n;
+    if (target > p.r_max) target = p.r_max;
+    __syncthreads();
   }
-  bitonic_sort_desc_u64(res, nrp);
 
-  // verify the guard band and write
-  const float eps = 4.f * s_maxerr + 1e-30f;
-  const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
-  float bound = tau;
-  if (n > C) bound = fmaxf(bound, f32_from_order_key((unsigned)(keys[C] >> 32)));
-  const bool have_k = (C + (p.set_feature >= 0 ? 1 : 0)) >= p.k;
-  const bool ok = (cnt <= p.cap) && (tau > 0.f) && have_k && (v_k > bound + eps);
-  for (int j = threadIdx.x; j < p.k; j += 256) {
+  for (int j = lane; j < p.k; j += 64) {
     const unsigned long long key = res[j];
     p.idx[(size_t)t * p.k + j] = key ? rank_key_index(key) : 0;
     p.vals[(size_t)t * p.k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
   }
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     if (p.status) p.status[t] = ok ? 0 : 2;
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
@@ -394,8 +276,8 @@ inline void prof_mark(int i, hipStream_t s) {
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
   bool fast;
-  int Tp, S, r, cap, n_rescore;
-  size_t off_xb, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
+  int Tp, S, r, cap, n_rescore, step, r_max;
+  size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
       off_fbi, off_dense, bytes;
 };
 
@@ -409,8 +291,12 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.S = N / SAMPLE_STRIDE;
     p.r = k / 4 > 16 ? k / 4 : 16;
     p.cap = next_pow2(64 * p.r);
-    p.n_rescore = k + (k / 2 > 16 ? k / 2 : 16);
+    p.step = k / 8 > 8 ? k / 8 : 8;
+    p.n_rescore = k + p.step;              // first round: k + 8 rows of W_enc per token at k = 32
+    p.r_max = k + 12 * p.step;             // rounds extend the re-scored set up to here
+    if (p.r_max > p.cap) p.r_max = p.cap;
     p.off_xb = take((size_t)p.Tp * d * 2);
+    p.off_a32 = take((size_t)T * d * 4);
     p.off_sample = take((size_t)T * p.S * 4);
     p.off_tauv = take((size_t)T * p.r * 4);
     p.off_taui = take((size_t)T * p.r * 4);
@@ -433,6 +319,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
              int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
              int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
   unsigned short *xb = reinterpret_cast<unsigned short *>(ws + pl.off_xb);
+  float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
   float *sample = reinterpret_cast<float *>(ws + pl.off_sample);
   float *tauv = reinterpret_cast<float *>(ws + pl.off_tauv);
   int32_t *taui = reinterpret_cast<int32_t *>(ws + pl.off_taui);
@@ -449,21 +336,15 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   prof_mark(0, s);
   hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T);
   hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, s, flagged, (size_t)(FB_MAX + 64));
-  hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb);
+  hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
-  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)gemm_bf16_kernel<true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)gemm_bf16_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-  const int nM = pl.Tp / G_BM;
   prof_mark(1, s);
   {  // sample pass -> dense [T][S]
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
     ep.dense = sample; ep.ld_dense = pl.S;
-    const int nN = pl.S / G_BN;
-    hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(nM * nN), dim3(G_THREADS), G_LDS_BYTES, s, xb,
-                       wsamp, T, pl.Tp, d, pl.S, nM, nN, ep);
+    const int grc = gemm_bf16_launch<GemmMain, true>(xb, wsamp, T, pl.Tp, d, pl.S, ep, s);
+    if (grc) return grc;
   }
   prof_mark(2, s);
   int rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);
@@ -476,24 +357,24 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.cnt = cnt; ep.cand = cand; ep.cap = pl.cap;
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
-    const int nN = N / G_BN;
-    hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(nM * nN), dim3(G_THREADS), G_LDS_BYTES, s, xb,
-                       wb, T, pl.Tp, d, N, nM, nN, ep);
+    const int grc = gemm_bf16_launch<GemmMain, false>(xb, wb, T, pl.Tp, d, N, ep, s);
+    if (grc) return grc;
   }
   prof_mark(4, s);
   {
     RescoreArgs ra{};
-    ra.x = x; ra.W_enc = W_enc; ra.b_enc = b_enc; ra.b_dec = b_dec;
+    ra.a32 = a32; ra.W_enc = W_enc; ra.b_enc = b_enc;
     ra.tau_vals = tauv; ra.tau_ld = pl.r; ra.tau_col = pl.r - 1;
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.n_rescore = pl.n_rescore;
+    ra.step = pl.step; ra.r_max = pl.r_max;
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
-    const int nrp = next_pow2(pl.n_rescore + 1);
-    const size_t smem = (size_t)pl.cap * 8 + (size_t)d * 4 + (size_t)nrp * 8 + (size_t)(pl.n_rescore + 4) * 4;
-    auto kern = select_rescore_kernel<DT>;
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(T), dim3(256), smem, s, ra);
+    const int nrp = next_pow2(pl.r_max + 1);
+    const size_t smem = ((size_t)pl.cap + nrp) * 8;
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(select_rescore_kernel, dim3(T), dim3(64), smem, s, ra, (const float *)a32, W_enc);
   }
   prof_mark(5, s);
   // exact recompute of flagged tokens (device-side count; empty grids exit immediately)

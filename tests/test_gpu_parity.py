@@ -161,9 +161,16 @@ def test_sae_module_matches_reference_fixture(dev, golden_dir, name):
         ref_v, ref_i, gap = g[f"k{k}_acts"], g[f"k{k}_idx"], g[f"k{k}_gap"]
         np.testing.assert_allclose(v, ref_v, rtol=RTOL, atol=RTOL)
         safe = gap > EPS_GAP
+        assert safe.mean() > 0.9
+        # exact order equality where every neighbouring pair of reference values is separated
+        # (rare at k = 256: 255 gaps must all exceed EPS_GAP); position-wise otherwise
         sep = np.all(np.abs(np.diff(ref_v, axis=1)) > EPS_GAP, axis=1) & safe
-        assert sep.mean() > 0.5
         assert np.array_equal(i[sep], ref_i[sep])
+        pos_ok = np.ones_like(ref_i, dtype=bool)
+        pos_ok[:, 1:] &= np.abs(np.diff(ref_v, axis=1)) > EPS_GAP
+        pos_ok[:, :-1] &= np.abs(np.diff(ref_v, axis=1)) > EPS_GAP
+        pos_ok &= safe[:, None]
+        assert np.array_equal(i[pos_ok], ref_i[pos_ok])
         for t in np.nonzero(safe)[0]:
             assert set(i[t][v[t] > 0]) == set(ref_i[t][ref_v[t] > 0])
         ref_r = g[f"k{k}_recon"]

@@ -1,0 +1,87 @@
+// gemm_sweep.hip -- standalone tuning harness for csrc/gemm_bf16.h (not part of the product).
+// Times every tile/pipeline configuration of the candidate-pass GEMM on the BASELINE shape
+// (T=8192, d=4096, N=131072, threshold epilogue with nothing emitted) and cross-checks the dense
+// epilogue of each configuration against a naive f32 reference on a small problem.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../multimodal-sae_amd/csrc/gemm_bf16.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_bf16(unsigned short *p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    float f = ((float)(z & 0xFFFFFF) / 8388608.0f) - 1.0f;   // uniform [-1, 1)
+    p[i] = f32_to_bf16_bits(f);
+  }
+}
+__global__ void ref_dense(const unsigned short *A, const unsigned short *B, int T, int d, int N, float *out) {
+  int n = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = 0; k < d; ++k) acc += bf16_bits_to_f32(A[(size_t)t * d + k]) * bf16_bits_to_f32(B[(size_t)n * d + k]);
+  out[(size_t)t * N + n] = acc;
+}
+__global__ void max_diff(const float *a, const float *b, size_t n, float *res) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(a[i] - b[i]));
+  atomicMax((int *)res, __float_as_int(m));
+}
+
+struct Ctx { unsigned short *A, *B; float *tau, *dense, *ref, *res; int *cnt; unsigned long long *cand; int T, d, N, Ns; };
+
+template <class C>
+void run(const char *name, Ctx &c, int reps) {
+  GemmEpilogue ep{};
+  // correctness on the small problem (first Ns features)
+  ep.dense = c.dense; ep.ld_dense = c.Ns; ep.bias_stride = 1;
+  CK(hipMemset(c.dense, 0, (size_t)c.T * c.Ns * 4));
+  int rc = gemm_bf16_launch<C, true>(c.A, c.B, c.T, c.T, c.d, c.Ns, ep, 0);
+  if (rc) { printf("%-28s launch failed rc=%d\n", name, rc); return; }
+  CK(hipMemset(c.res, 0, 4));
+  max_diff<<<1024, 256>>>(c.dense, c.ref, (size_t)512 * c.Ns, c.res);   // ref covers the first 512 tokens
+  float md; CK(hipMemcpy(&md, c.res, 4, hipMemcpyDeviceToHost));
+  // timing on the full problem
+  GemmEpilogue et{};
+  et.bias_stride = 1; et.tau_vals = c.tau; et.tau_ld = 1; et.tau_col = 0; et.cnt = c.cnt; et.cand = c.cand; et.cap = 16; et.skip_a = et.skip_b = -1;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) gemm_bf16_launch<C, false>(c.A, c.B, c.T, c.T, c.d, c.N, et, 0);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int i = 0; i < reps; ++i) {
+    CK(hipEventRecord(e0, 0));
+    gemm_bf16_launch<C, false>(c.A, c.B, c.T, c.T, c.d, c.N, et, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = fminf(best, ms); sum += ms;
+  }
+  double fl = 2.0 * c.T * c.d * (double)c.N;
+  printf("%-28s lds=%3dKB thr=%3d  maxdiff=%.3e  mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", name, C::LDS_BYTES / 1024, C::NT, md,
+         sum / reps, fl / (sum / reps * 1e-3) / 1e12, best, fl / (best * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+  Ctx c{}; c.T = 8192; c.d = 4096; c.N = 131072; c.Ns = 4096;
+  int reps = argc > 1 ? atoi(argv[1]) : 5;
+  CK(hipMalloc(&c.A, (size_t)c.T * c.d * 2)); CK(hipMalloc(&c.B, (size_t)c.N * c.d * 2));
+  CK(hipMalloc(&c.tau, c.T * 4)); CK(hipMemset(c.tau, 0, c.T * 4));           // tau <= 0 -> nothing emitted
+  CK(hipMalloc(&c.cnt, c.T * 4)); CK(hipMemset(c.cnt, 0, c.T * 4)); CK(hipMalloc(&c.cand, (size_t)c.T * 16 * 8));
+  CK(hipMalloc(&c.dense, (size_t)c.T * c.Ns * 4)); CK(hipMalloc(&c.ref, (size_t)512 * c.Ns * 4)); CK(hipMalloc(&c.res, 4));
+  fill_bf16<<<4096, 256>>>(c.A, (size_t)c.T * c.d, 1); fill_bf16<<<4096, 256>>>(c.B, (size_t)c.N * c.d, 2);
+  ref_dense<<<dim3(c.Ns / 256, 512), 256>>>(c.A, c.B, 512, c.d, c.Ns, c.ref);
+  CK(hipDeviceSynchronize());
+#define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
+  RUN(256, 256, 64, 2, 2, 4);
+  RUN(256, 256, 64, 2, 2, 4, 1);
+  RUN(256, 256, 64, 2, 2, 4, 2);
+  RUN(256, 256, 64, 2, 2, 4, 3);
+  RUN(256, 256, 32, 3, 2, 4, 1);
+  RUN(256, 256, 32, 3, 2, 4, 3);
+  RUN(256, 256, 32, 4, 2, 4, 3);
+  RUN(256, 256, 64, 2, 4, 2, 3);
+  RUN(256, 256, 64, 2, 4, 2, 0);
+  RUN(128, 128, 64, 2, 2, 2, 3);
+  return 0;
+}

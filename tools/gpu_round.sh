@@ -17,7 +17,7 @@ echo "== bench =="
 timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
 echo "== rocprof =="
 rm -rf $OUT/prof
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
 find $OUT/prof -name "*stats*" | head; 
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f; done
 # drop the bulky per-dispatch trace, keep the stats
