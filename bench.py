@@ -92,7 +92,7 @@ def load_traffic(kernel: str):
     f = REPO / "profiles" / "pmc_traffic.json"
     if f.exists():
         try:
-            return json.loads(f.read_text()).get(kernel)
+            return json.loads(f.read_text()).get(kernel, {}).get("bytes_per_launch")
         except Exception:
             return None
     return None

@@ -87,7 +87,9 @@ int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void 
  * the reference hooks' edits of the dense latents applied before TopK:
  *   set_feature >= 0 : latents[:, set_feature] = set_value       (steering.py:113-114)
  *   zero_feature >= 0: latents[:, zero_feature] = 0               (patching/utils.py:43-48)
- * status (optional, int32[T]): 0 = fast path verified; 1 = token recomputed by the exact path. */
+ * status (optional, int32[T]): 0 = fast path verified; 1 = token recomputed by the exact path
+ * inside the call; 2 = flagged but not recomputed (more than 128 flagged tokens in one call: the
+ * caller re-runs those through msae_pre_acts_f32 + msae_topk_f32). */
 size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,

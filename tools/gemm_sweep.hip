@@ -74,14 +74,11 @@ int main(int argc, char **argv) {
   CK(hipDeviceSynchronize());
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
   RUN(256, 256, 64, 2, 2, 4);
-  RUN(256, 256, 64, 2, 2, 4, 1);
-  RUN(256, 256, 64, 2, 2, 4, 2);
-  RUN(256, 256, 64, 2, 2, 4, 3);
-  RUN(256, 256, 32, 3, 2, 4, 1);
-  RUN(256, 256, 32, 3, 2, 4, 3);
-  RUN(256, 256, 32, 4, 2, 4, 3);
-  RUN(256, 256, 64, 2, 4, 2, 3);
-  RUN(256, 256, 64, 2, 4, 2, 0);
-  RUN(128, 128, 64, 2, 2, 2, 3);
+  RUN(256, 256, 64, 2, 2, 2);
+  RUN(256, 256, 32, 3, 2, 2);
+  RUN(256, 256, 32, 4, 2, 2);
+  RUN(256, 256, 64, 2, 2, 2, 1);
+  RUN(256, 128, 64, 2, 2, 1);
+  RUN(128, 256, 64, 2, 1, 2);
   return 0;
 }
