@@ -5,8 +5,8 @@
 //
 // Pipeline per call (all on one stream, no host synchronisation):
 //   1. prep_x        xb[T][d] = bf16(x - b_dec)                           (HBM, tiny)
-//   2. gemm<DENSE>   coarse pre-acts of a 1/16 strided SAMPLE of the features -> [T][S] f32
-//   3. topk (r-th)   tau[t] = r-th largest sample value: expected ~16*r features of the full
+//   2. gemm<DENSE>   coarse pre-acts of a 1/32 strided SAMPLE of the features -> [T][S] f32
+//   3. topk (r-th)   tau[t] = r-th largest sample value: expected ~32*r features of the full
 //                    width exceed tau[t]
 //   4. gemm<THRESH>  THE DOMINANT KERNEL.  [T][d] x [d][N] on v_mfma_f32_32x32x16_bf16, LDS tiles
 //                    filled by global_load_lds (16 B/lane), XOR-swizzled, double-buffered;
@@ -34,7 +34,7 @@ int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const in
 
 namespace {
 
-constexpr int SAMPLE_STRIDE = 16, SAMPLE_OFF = 7;
+constexpr int SAMPLE_STRIDE = 32, SAMPLE_OFF = 13;
 constexpr int FB_MAX = 128;         // tokens the in-call exact fallback can absorb
 constexpr int EXACT_T_MAX = 255;    // below this many tokens the exact path is used directly
 
@@ -47,7 +47,7 @@ struct Prepared {
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 
 __host__ __device__ inline bool fast_shape_ok(int N, int d) {
-  return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/16 must tile by BN = 256
+  return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/32 must tile by BN = 256
 }
 
 inline Prepared make_prepared(int N, int d) {
@@ -61,7 +61,7 @@ inline Prepared make_prepared(int N, int d) {
   return p;
 }
 
-// W_bf16[n][c] = bf16(W[n][c]); sample row j = row j*16+7.  grid-stride over 8-element groups.
+// W_bf16[n][c] = bf16(W[n][c]); sample row j = row j*SAMPLE_STRIDE + SAMPLE_OFF.  grid-stride over 8-element groups.
 __global__ __launch_bounds__(256) void prepare_weights_kernel(const float *__restrict__ W, int N,
                                                               int d, unsigned short *__restrict__ wb,
                                                               unsigned short *__restrict__ ws) {
@@ -289,8 +289,8 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
   if (p.fast) {
     p.Tp = (T + G_BM - 1) / G_BM * G_BM;
     p.S = N / SAMPLE_STRIDE;
-    p.r = k / 4 > 16 ? k / 4 : 16;
-    p.cap = next_pow2(64 * p.r);
+    p.r = k / 4 > 8 ? k / 4 : 8;           // tau = r-th largest of the 1/32 sample: ~32*r survivors
+    p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.step = k / 8 > 8 ? k / 8 : 8;
     p.n_rescore = k + p.step;              // first round: k + 8 rows of W_enc per token at k = 32
     p.r_max = k + 12 * p.step;             // rounds extend the re-scored set up to here

@@ -35,6 +35,8 @@ struct GemmEpilogue {
 
 // FLAGS: bit 0 = raise wave priority around each MFMA cluster (s_setprio); bit 1 = spread the next
 // stage's LDS-DMA issue over the k-steps of the current one instead of issuing it up front.
+// (An L2-prefetch variant -- one sparse dword load per wave per k-tile, 2-6 tiles ahead -- measured
+// 954 vs 1180 TFLOP/s and was dropped: L2 miss latency is not what the loop waits for.)
 template <int BM_, int BN_, int BK_, int STAGES_, int WM_, int WN_, int FLAGS_ = 0>
 struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, STAGES = STAGES_, WM = WM_, WN = WN_;
@@ -110,6 +112,56 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <class C, bool DENSE>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
+                                              int m0, int n0, int wr, int wc, int lane) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  // epilogue.  C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if constexpr (DENSE) {
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      const int n = n0 + wc * C::TN + j * 32 + l31;
+      const float bn = ep.bias ? ep.bias[n * ep.bias_stride + ep.bias_off] : 0.f;
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n] = acc[i][j][e] + bn;
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+      // the 16 per-lane thresholds of this row block first (independent loads), then the compares
+      float tau[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
+        tau[e] = (v > 0.f) ? v : __builtin_inff();  // degenerate / padded token: emit nothing
+      }
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) {
+        const int feat = n0 + wc * C::TN + j * 32 + l31;
+        const float bn = ep.bias ? ep.bias[feat] : 0.f;
+        const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e] + bn;
+          if (v > tau[e] && live) {
+            const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            const int slot = atomicAdd(ep.cnt + t, 1);
+            if (slot < ep.cap)
+              ep.cand[(size_t)t * ep.cap + slot] =
+                  ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class C, bool DENSE>
 __global__ __launch_bounds__(C::NT) void gemm_bf16_kernel(const unsigned short *__restrict__ A,
                                                           const unsigned short *__restrict__ B, int T,
                                                           int Tp, int d, int N, int nM, int nN,
@@ -176,61 +228,115 @@ __global__ __launch_bounds__(C::NT) void gemm_bf16_kernel(const unsigned short *
     }
   }
 
-  // epilogue.  C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  if constexpr (DENSE) {
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane);
+}
+
+// ---- ping-pong schedule -------------------------------------------------------------------------
+// Same tiles, LDS image and epilogues; different time structure.  The 8 waves form two groups of 4
+// (one wave of each group per SIMD).  A k-tile is BK/16 steps; every step is a LOAD phase (6
+// fragment ds_reads + this wave's share of the LDS-DMA for the tile STAGES-1 ahead) followed by a
+// COMPUTE phase (MI*NI MFMAs under s_setprio 1), phases separated by s_barrier.  Group B runs one
+// phase behind group A, so on every SIMD one wave is always in its MFMA phase while its partner
+// reads LDS / issues DMA: the matrix pipe no longer drains at the per-tile barrier.  LDS-DMA for
+// a tile is issued >= 2 tiles before its first read and retired by a counted vmcnt one phase
+// (one barrier) before that read; the ring needs STAGES >= 4 slots.
+template <class C, bool DENSE>
+__global__ __launch_bounds__(C::NT) void gemm_bf16_pp_kernel(const unsigned short *__restrict__ A,
+                                                             const unsigned short *__restrict__ B,
+                                                             int T, int Tp, int d, int N, int nM,
+                                                             int nN, GemmEpilogue ep) {
+  static_assert(C::STAGES >= 4 && C::NWAVES == 8, "ping-pong needs a 4-slot ring and 8 waves");
+  constexpr int KS = C::BK / 16;                       // steps per k-tile
+  constexpr int PER = (C::PPW + KS - 1) / KS;          // LDS-DMA pieces issued per LOAD phase
+  static_assert(PER * KS == C::PPW, "pieces must split evenly over the steps");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2;                            // 0: group A, 1: group B (one phase behind)
+  const int wr = wave / C::WN, wc = wave % C::WN;
+  int tm, tn;
+  gemm_map_tile(blockIdx.x, nM, nN, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+  f32x16 acc[C::MI][C::NI];
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-      const int n = n0 + wc * C::TN + j * 32 + l31;
-      const float bn = ep.bias ? ep.bias[n * ep.bias_stride + ep.bias_off] : 0.f;
+  for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = d / C::BK;
+#pragma unroll
+  for (int s = 0; s < C::STAGES - 1; ++s)
+    gemm_stage<C>(A, B, m0, n0, Tp, N, d, s < nk ? s : nk - 1, smem, s, wave, lane);
+  wait_vmcnt<C::PPW *(C::STAGES - 2)>();               // tile 0 landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();           // group B starts one phase later
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char *sA = smem + (kt % C::STAGES) * C::STAGE_BYTES;
+    const unsigned char *sB = sA + C::A_BYTES;
+    int nkt = kt + C::STAGES - 1;                       // tile whose DMA is issued during this tile
+    const int nslot = nkt % C::STAGES;
+    nkt = nkt < nk ? nkt : nk - 1;                      // past the end: harmless re-load keeps vmcnt uniform
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // ---------------- LOAD phase
+      const int chunk = ks * 2 + kh;
+      bf16x8 a[C::MI], b[C::NI];
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) a[i] = gemm_frag<C>(sA, wr * C::TM + i * 32 + l31, chunk);
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) b[j] = gemm_frag<C>(sB, wc * C::TN + j * 32 + l31, chunk);
+      if (ks == 0) gemm_stage<C, 0, PER>(A, B, m0, n0, Tp, N, d, nkt, smem, nslot, wave, lane);
+      if (ks == 1) gemm_stage<C, PER, (2 * PER < C::PPW ? 2 * PER : C::PPW)>(A, B, m0, n0, Tp, N, d, nkt, smem, nslot, wave, lane);
+      if (ks == 2) gemm_stage<C, (2 * PER < C::PPW ? 2 * PER : C::PPW), (3 * PER < C::PPW ? 3 * PER : C::PPW)>(A, B, m0, n0, Tp, N, d, nkt, smem, nslot, wave, lane);
+      if (ks == 3) gemm_stage<C, (3 * PER < C::PPW ? 3 * PER : C::PPW), C::PPW>(A, B, m0, n0, Tp, N, d, nkt, smem, nslot, wave, lane);
+      // group B's last LOAD phase of the tile is the phase before group A first reads tile kt+1:
+      // retire this wave's pieces of tile kt+1 (leave tiles kt+2 .. kt+STAGES-1 in flight)
+      if (ks == KS - 1 && grp == 1) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own ds_reads done before the slot can be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- COMPUTE phase
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n] = acc[i][j][e] + bn;
-        }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) {
-      // the 16 per-lane thresholds of this row block first (independent loads), then the compares
-      float tau[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
-        tau[e] = (v > 0.f) ? v : __builtin_inff();  // degenerate / padded token: emit nothing
-      }
-#pragma unroll
-      for (int j = 0; j < C::NI; ++j) {
-        const int feat = n0 + wc * C::TN + j * 32 + l31;
-        const float bn = ep.bias ? ep.bias[feat] : 0.f;
-        const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][j][e] + bn;
-          if (v > tau[e] && live) {
-            const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const int slot = atomicAdd(ep.cnt + t, 1);
-            if (slot < ep.cap)
-              ep.cand[(size_t)t * ep.cap + slot] =
-                  ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
-          }
-        }
-      }
+        for (int j = 0; j < C::NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (ks == KS - 1 && grp == 0) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();           // pair group B's extra initial barrier
+  wait_vmcnt<0>();
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane);
 }
 
 // Host launcher.  Requires Tp % BM == 0, N % BN == 0, d % BK == 0 (checked by the caller's plan).
-template <class C, bool DENSE>
+template <class C, bool DENSE, bool PINGPONG = false>
 inline int gemm_bf16_launch(const unsigned short *A, const unsigned short *B, int T, int Tp, int d,
                             int N, const GemmEpilogue &ep, hipStream_t s) {
   if (Tp % C::BM || N % C::BN || d % C::BK) return MSAE_EINVAL;
-  auto kern = gemm_bf16_kernel<C, DENSE>;
-  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   C::LDS_BYTES));
   const int nM = Tp / C::BM, nN = N / C::BN;
-  hipLaunchKernelGGL(kern, dim3(nM * nN), dim3(C::NT), C::LDS_BYTES, s, A, B, T, Tp, d, N, nM, nN, ep);
+  if constexpr (PINGPONG) {
+    auto kern = gemm_bf16_pp_kernel<C, DENSE>;
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(nM * nN), dim3(C::NT), C::LDS_BYTES, s, A, B, T, Tp, d, N, nM, nN, ep);
+  } else {
+    auto kern = gemm_bf16_kernel<C, DENSE>;
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     C::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(nM * nN), dim3(C::NT), C::LDS_BYTES, s, A, B, T, Tp, d, N, nM, nN, ep);
+  }
   return (int)hipGetLastError();
 }
