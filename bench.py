@@ -115,8 +115,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    ddp = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
     from msae import _hip, ops
@@ -133,7 +135,8 @@ def main():
         W_dec = W_dec_shard
     del W_dec_shard
     engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world,
-                        group=dist.group.WORLD if world > 1 else None)
+                        group=dist.group.WORLD if ddp else None,
+                        force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
 
     def step():
         return engine.forward(x)
@@ -147,14 +150,14 @@ def main():
     dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(args.steps)]
     engine.decode_events = dec_ev
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     stage_ms = (ctypes.c_float * (args.steps * 6))()
@@ -165,7 +168,7 @@ def main():
         if engine.decode_event_i else float("nan")
     engine.decode_events = None
 
-    if world > 1:
+    if ddp:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -204,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
         print(json.dumps(res))
-    if world > 1:
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,10 +54,14 @@ class ShardedSae:
 
     def __init__(self, W_enc_shard: Tensor, b_enc_shard: Tensor, W_dec: Tensor, b_dec: Tensor, k: int,
                  rank: int = 0, world: int = 1, group=None,
-                 encode_fn: Optional[Callable] = None, decode_fn: Optional[Callable] = None):
+                 encode_fn: Optional[Callable] = None, decode_fn: Optional[Callable] = None,
+                 force_collectives: bool = False):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
+        # collectives run whenever there is more than one rank; `force_collectives` also runs them on
+        # a 1-rank group so the RCCL code path can be exercised on a single-GPU box
+        self.collective = world > 1 or (force_collectives and dist.is_initialized())
         self.decode_events = None
         self.decode_event_i = 0
         if encode_fn is None:
@@ -71,7 +75,7 @@ class ShardedSae:
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
         vals, idx, status = self._encode(x)
-        if self.world == 1:
+        if not self.collective:
             return vals, idx, status
         T = vals.shape[0]
         packed = torch.stack((vals.view(torch.int32), (idx + self.rank * self.n_loc).to(torch.int32)), 0)
@@ -89,7 +93,7 @@ class ShardedSae:
             ev = self.decode_events[self.decode_event_i]
             self.decode_event_i += 1
             ev[0].record()
-        if self.world == 1:
+        if not self.collective:
             out = self._decode(idx, vals)
         else:
             T = vals.shape[0]

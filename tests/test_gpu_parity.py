@@ -435,3 +435,29 @@ def test_cpu_tensors_raise(dev):
 
     with pytest.raises(RuntimeError):
         ops.topk(torch.zeros(2, 8), 2)
+
+
+def test_bench_under_torchrun_with_rccl_collectives(dev):
+    """bench.py launched exactly as the driver launches it (torch.distributed.run, backend nccl ==
+    RCCL), on one rank with the collectives forced on: exercises init, both all-gathers, the merge
+    and the token-sharded decode on real RCCL; the result must agree with the plain run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MSAE_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(REPO / "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--tokens", "1024", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
