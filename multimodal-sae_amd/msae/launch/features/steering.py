@@ -1,0 +1,57 @@
+"""python -m msae.launch.features.steering -m <model> -t <text> [-i <image>] --sae-path ...
+--filters ... -k <clamp> -s <save dir>   (reference launch/features/steering.py:18-113)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+
+import torch
+import torch.distributed as dist
+
+from ...features.steering import SteeringController
+from ...utils import ddp_setup, load_filter, load_saes, maybe_load_llava_model
+
+
+def parse_argument(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", "-m", type=str, default="llava-hf/llama3-llava-next-8b-hf",
+                   help="The model name of your trained model")
+    p.add_argument("--image-path", "-i", type=str, default=None, help="The path to your image")
+    p.add_argument("--text", "-t", type=str, help="The text you want to ask the model")
+    p.add_argument("--sae-path", type=str, help="The path to your sae, can be hub or local")
+    p.add_argument("--filters", type=str, help="The filters path")
+    p.add_argument("--clamp-value", "-k", type=float, default=50, help="The clamping value")
+    p.add_argument("--save-dir", "-s", default="./results/steering",
+                   help="The path to save your steering result")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_argument(argv)
+    ddp, rank, world = ddp_setup()
+    model, processor = maybe_load_llava_model(args.model, rank=rank, dtype=torch.float16, hf_token=None)
+    filters = load_filter(args.filters, device="cpu")
+    sae_dict = load_saes(args.sae_path, filters, device=f"cuda:{rank}")
+    for module_name, sae in sae_dict.items():
+        feats = filters[module_name]
+        feature_idx = (feats.tensor_split(world)[rank] if ddp else feats).cpu().tolist()
+        result = SteeringController(sae=sae, module_name=module_name, feature_idx=feature_idx,
+                                    prompt=args.text, model=model, processor=processor,
+                                    image_path=args.image_path, k=args.clamp_value).run()
+        if ddp:
+            gathered = [None] * world
+            dist.gather_object(result, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                for r in gathered:
+                    result.update(r)
+        if rank == 0:
+            os.makedirs(args.save_dir, exist_ok=True)
+            with open(os.path.join(args.save_dir, f"{module_name}.json"), "w", encoding="utf-8") as f:
+                json.dump(result, f, indent=4, ensure_ascii=False)
+        if ddp:
+            dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

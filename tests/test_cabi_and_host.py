@@ -159,3 +159,39 @@ def test_legacy_dense_cache_add_matches_reference(golden_dir):
         c.add(dense, 5, "m")
         c.save()
         assert np.array_equal(c.feature_locations["m"].numpy(), g[f"{tag}_locations"])
+
+
+def test_cli_flags_match_reference_readme_commands(tmp_path):
+    """The README's cache / steering command lines (README.md:46-56,106-110) parse unchanged."""
+    from msae.config import parse_cache_config
+    from msae.launch.features.steering import parse_argument
+
+    cfg = parse_cache_config(["llava-hf/llama3-llava-next-8b-hf", "lmms-lab/sae-sample-cache-dataset",
+                              "--sae_path", "lmms-lab/llama3-llava-next-8b-hf-sae-131k", "--split", "train",
+                              "--batch_size", "1", "--ctx_len", "64", "--n_splits", "128",
+                              "--save_dir", "./sae_cache", "--filters_path", "filters.json"])
+    assert (cfg.model, cfg.dataset) == ("llava-hf/llama3-llava-next-8b-hf", "lmms-lab/sae-sample-cache-dataset")
+    assert (cfg.batch_size, cfg.ctx_len, cfg.n_splits, cfg.split) == (1, 64, 128, "train")
+    assert cfg.filters_path == "filters.json" and cfg.load_in_8bit is False
+    d = parse_cache_config([])
+    assert (d.batch_size, d.n_splits, d.ctx_len, d.save_dir) == (32, 2, 2048, "./features_cache")
+    a = parse_argument(["-t", "Tell me a story", "-k", "30", "--sae-path", "p", "--filters", "f.json",
+                        "-i", "img.png", "-s", "out"])
+    assert (a.text, a.clamp_value, a.sae_path, a.filters, a.image_path, a.save_dir) == \
+        ("Tell me a story", 30.0, "p", "f.json", "img.png", "out")
+    assert parse_argument(["-t", "x"]).model == "llava-hf/llama3-llava-next-8b-hf"
+
+
+def test_load_filter_and_load_saes_local(tmp_path):
+    from msae import Sae, SaeConfig
+    from msae.utils import load_filter, load_saes, load_single_sae
+
+    for name in ("model.layers.2", "model.layers.10"):
+        Sae(8, SaeConfig(num_latents=32, k=4)).save_to_disk(tmp_path / name)
+    (tmp_path / "filters.json").write_text(json.dumps({"model.layers.10": [3, 1, 30]}))
+    filt = load_filter(str(tmp_path / "filters.json"), device="cpu")
+    assert filt["model.layers.10"].tolist() == [3, 1, 30]
+    assert list(load_saes(str(tmp_path), device="cpu")) == ["model.layers.2", "model.layers.10"]  # natural order
+    only = load_saes(str(tmp_path), filters=filt, device="cpu")
+    assert list(only) == ["model.layers.10"] and only["model.layers.10"].num_latents == 32
+    assert load_single_sae(str(tmp_path), "model.layers.2", device="cpu").d_in == 8
