@@ -6,12 +6,17 @@ No reference counterpart: the reference only data-parallelises by sharding the d
 Rank g of G owns rows [g*N/G, (g+1)*N/G) of W_enc / b_enc.  Every rank sees the same tokens x
 (each rank runs the same LLM forward, or x is broadcast).  Per call:
 
-  1. local fused encode + TopK over the shard           -> (vals f32, idx i32 + g*N/G)  [T, k]
-  2. ONE all-gather of the packed pairs (8 B * k per token per rank = 256 B at k = 32) over
-     RCCL/xGMI -- latency-bound, the only exchange step of the path
-  3. every rank merges the G*k candidates per token with the canonical key (value desc, global
-     index asc); global top-k is a subset of the union of per-shard top-k, so the result is
-     bit-identical to the single-GPU result
+  1. local fused encode + exact TopK over the shard, but only the shard's best
+     k_loc = min(k, 2*ceil(k/G) + 8) latents                -> (vals f32, idx i32 + g*N/G)  [T, k_loc]
+     (the global top-k puts ~k/G members in each shard, so re-scoring a full local top-k on every
+     rank would multiply the HBM-bound re-score work by G)
+  2. ONE all-gather of the packed pairs (8 B * k_loc per token per rank) over RCCL/xGMI --
+     latency-bound, the only exchange step of the encode
+  3. every rank merges the G*k_loc candidates per token with the canonical key (value desc, global
+     index asc) and VERIFIES the truncation: if a shard's last gathered latent made it into the
+     merged top-k that shard may hold more members, and the token is redone with k_loc = k (every
+     rank derives the same flagged set from the same gathered data; normally it is empty).  The
+     result is bit-identical to the single-GPU result
   4. decode is token-sharded against a replicated W_dec (2 GiB of 288 GB): rank g reconstructs
      tokens [g*T/G, (g+1)*T/G) and an all-gather returns the full [T, d] to every rank (the hook
      that replaces the layer output needs it everywhere; the caching path skips it).
@@ -55,7 +60,7 @@ class ShardedSae:
     def __init__(self, W_enc_shard: Tensor, b_enc_shard: Tensor, W_dec: Tensor, b_dec: Tensor, k: int,
                  rank: int = 0, world: int = 1, group=None,
                  encode_fn: Optional[Callable] = None, decode_fn: Optional[Callable] = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, k_loc: Optional[int] = None):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
@@ -64,28 +69,53 @@ class ShardedSae:
         self.collective = world > 1 or (force_collectives and dist.is_initialized())
         self.decode_events = None
         self.decode_event_i = 0
+        self.second_round_tokens = 0
+        if k_loc is None:
+            k_loc = min(k, 2 * -(-k // world) + 8) if self.collective else k
+        k_loc = max(k_loc, -(-k // world))      # the union must hold at least k candidates
+        self.k_loc = min(k_loc, k, self.n_loc)
         if encode_fn is None:
             from . import ops
 
             prepared = ops.prepare_encoder(W_enc_shard)
-            encode_fn = lambda x: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, k)
+            encode_fn = lambda x, kk: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk)
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
         self._encode, self._decode = encode_fn, decode_fn
 
+    def _gather_pairs(self, vals: Tensor, idx: Tensor):
+        """all-gather of [T, kk] (f32, global i32) pairs -> ([T, G, kk] f32, [T, G, kk] int64)."""
+        T, kk = vals.shape
+        packed = torch.stack((vals.contiguous().view(torch.int32),
+                              (idx + self.rank * self.n_loc).to(torch.int32)), 0).contiguous()
+        flat = torch.empty((self.world * 2, T, kk), dtype=torch.int32, device=packed.device)
+        dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
+        g = flat.view(self.world, 2, T, kk)
+        return g[:, 0].view(torch.float32).permute(1, 0, 2), g[:, 1].permute(1, 0, 2).to(torch.int64)
+
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
-        vals, idx, status = self._encode(x)
         if not self.collective:
-            return vals, idx, status
+            return self._encode(x, self.k)
+        vals, idx, status = self._encode(x, self.k_loc)
         T = vals.shape[0]
-        packed = torch.stack((vals.view(torch.int32), (idx + self.rank * self.n_loc).to(torch.int32)), 0)
-        flat = torch.empty((self.world * 2, T, self.k), dtype=torch.int32, device=packed.device)
-        dist.all_gather_into_tensor(flat, packed.contiguous(), group=self.group)  # concat along dim 0
-        gathered = flat.view(self.world, 2, T, self.k)
-        all_vals = gathered[:, 0].view(torch.float32).permute(1, 0, 2).reshape(T, self.world * self.k)
-        all_idx = gathered[:, 1].permute(1, 0, 2).reshape(T, self.world * self.k).to(torch.int64)
-        vals, idx = merge_topk(all_vals, all_idx, self.k)
-        return vals, idx, status
+        all_vals, all_idx = self._gather_pairs(vals, idx)                    # [T, G, k_loc]
+        mv, mi = merge_topk(all_vals.reshape(T, -1), all_idx.reshape(T, -1), self.k)
+        if self.k_loc < self.k:
+            # truncation check: a shard whose LAST gathered latent ranks inside the merged top-k may
+            # own further members that were never gathered
+            kth = canonical_key(mv[:, -1], mi[:, -1])                        # [T]
+            last = canonical_key(all_vals[:, :, -1], all_idx[:, :, -1])      # [T, G]
+            flagged = (last >= kth[:, None]).any(dim=1)
+            redo = torch.nonzero(flagged).flatten()                          # same on every rank
+            if redo.numel():
+                self.second_round_tokens += int(redo.numel())
+                v2, i2, s2 = self._encode(x[redo].contiguous(), self.k)
+                av2, ai2 = self._gather_pairs(v2, i2)
+                mv2, mi2 = merge_topk(av2.reshape(len(redo), -1), ai2.reshape(len(redo), -1), self.k)
+                mv[redo], mi[redo] = mv2, mi2
+                status = status.clone()
+                status[redo] = torch.maximum(status[redo], s2)
+        return mv, mi, status
 
     def decode(self, vals: Tensor, idx: Tensor, gather: bool = True) -> Tensor:
         ev = None

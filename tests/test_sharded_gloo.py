@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, T, d, N, k, out_dir):
+def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False):
     for p in (REPO, REPO / "tests", REPO / "multimodal-sae_amd"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -32,12 +32,15 @@ def _worker(rank, world, port, T, d, N, k, out_dir):
     from msae.parallel import ShardedSae
 
     W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0   # most of the global top-k lives in shard 0
     x = synth.activations(T, d, seed=32)
     n_loc = N // world
     lo, hi = rank * n_loc, (rank + 1) * n_loc
 
-    def encode_fn(xt):
-        v, i = oracle.encode_topk(xt.numpy(), W_enc[lo:hi], b_enc[lo:hi], b_dec, k)
+    def encode_fn(xt, kk):
+        v, i = oracle.encode_topk(xt.numpy(), W_enc[lo:hi], b_enc[lo:hi], b_dec, kk)
         return torch.from_numpy(v), torch.from_numpy(i).long(), torch.zeros(len(v), dtype=torch.int32)
 
     def decode_fn(idx, vals):
@@ -45,23 +48,30 @@ def _worker(rank, world, port, T, d, N, k, out_dir):
 
     eng = ShardedSae(torch.from_numpy(W_enc[lo:hi]), torch.from_numpy(b_enc[lo:hi]),
                      torch.from_numpy(W_dec), torch.from_numpy(b_dec), k, rank=rank, world=world,
-                     group=dist.group.WORLD, encode_fn=encode_fn, decode_fn=decode_fn)
+                     group=dist.group.WORLD, encode_fn=encode_fn, decode_fn=decode_fn, k_loc=k_loc)
     out = eng.forward(torch.from_numpy(x))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(),
-             i=out["top_indices"].numpy(), r=out["sae_out"].numpy())
+             i=out["top_indices"].numpy(), r=out["sae_out"].numpy(), redo=eng.second_round_tokens,
+             k_loc=eng.k_loc)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T", [13, 8])
-def test_feature_sharded_equals_single_shard(tmp_path, T):
+@pytest.mark.parametrize("T,k,k_loc,cluster", [(13, 8, None, False), (8, 8, None, False),
+                                               (13, 16, 10, False), (13, 16, 9, True)])
+def test_feature_sharded_equals_single_shard(tmp_path, T, k, k_loc, cluster):
+    """k_loc < k: per-shard truncation verified after the merge; `cluster` concentrates the global
+    top-k in one shard so the second round (full local top-k for the flagged tokens) must run."""
     import synth
     from oracle import oracle
 
-    d, N, k, world = 64, 1024, 8, 2
+    d, N, world = 64, 1024, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, T, d, N, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, T, d, N, k, str(tmp_path), k_loc, cluster), nprocs=world, join=True)
     W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0
     x = synth.activations(T, d, seed=32)
     ref_v, ref_i = oracle.encode_topk(x, W_enc, b_enc, b_dec, k)
     ref_r = oracle.decode(ref_i, ref_v, W_dec, b_dec)
@@ -70,6 +80,8 @@ def test_feature_sharded_equals_single_shard(tmp_path, T):
         assert np.array_equal(g["i"], ref_i), f"rank {rank}: merged indices differ"
         assert np.array_equal(g["v"], ref_v)
         assert np.array_equal(g["r"], ref_r)
+        if cluster:
+            assert int(g["redo"]) > 0 and int(g["k_loc"]) == k_loc   # the second round really ran
 
 
 def test_merge_topk_is_canonical_with_ties():
