@@ -127,6 +127,14 @@ int msae_sparsify_write(const float *vals, const int32_t *idx, int B, int S, int
                         const int64_t *counts, int64_t *locations, float *activations,
                         void *stream);
 
+/* ---- merge of per-shard results (feature-sharded encode; no reference counterpart) ----
+ * gathered: int32 [G][2][T][kl], the all-gather of each rank's packed block [2][T][kl]
+ * (plane 0 = f32 activation bits, plane 1 = GLOBAL feature index).  Writes the canonical top-k of
+ * the G*kl candidates per token; flagged[t] (optional) = 1 when kl < k and some shard's last
+ * candidate ranks inside the merged top-k (that shard may hold more members than it sent). */
+int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, int k, float *vals, int32_t *idx,
+                    int32_t *flagged, void *stream);
+
 /* ---- stage timing of msae_encode_topk's fused path (measurement aid for bench.py) --------------
  * Between _begin and _end every fused msae_encode_topk call records HIP events, on the stream it
  * launches on, at the boundaries of its 6 stages:

@@ -31,6 +31,8 @@ int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const f
                          int relu, float *out, int ld_out, hipStream_t s);
 int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
                      float *vals, int32_t *idx, hipStream_t s);
+bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float *out, int out_ld,
+                           int out_col, hipStream_t s);
 
 namespace {
 
@@ -347,8 +349,11 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     if (grc) return grc;
   }
   prof_mark(2, s);
-  int rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);
-  if (rc) return rc;
+  int rc = 0;
+  if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s)) {
+    rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);  // generic shapes
+    if (rc) return rc;
+  }
   prof_mark(3, s);
   {  // full pass with the threshold epilogue
     GemmEpilogue ep{};

@@ -215,6 +215,89 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
   }
 }
 
+// ---- r-th largest value of each row (threshold select of the fused encoder) ---------------------
+// One wave per row; the row lives in registers (VPL values per lane) and the r-th largest order
+// key is found by a 32-step bisection on the key space (count(key >= mid) by lane + wave reduce).
+// HBM-bound: the row is read once.
+template <int VPL>
+__global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict__ rows, int T, int S,
+                                                        int ld, int r, float *__restrict__ out,
+                                                        int out_ld, int out_col) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float *row = rows + (size_t)t * ld;
+  unsigned key[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL / 4; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + (i * 64 + lane) * 4);
+    key[4 * i + 0] = f32_order_key(v[0]); key[4 * i + 1] = f32_order_key(v[1]);
+    key[4 * i + 2] = f32_order_key(v[2]); key[4 * i + 3] = f32_order_key(v[3]);
+  }
+  unsigned lo = 0u;               // invariant: count(key >= lo) >= r
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned mid = lo | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) c += (key[i] >= mid) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (c >= r) lo = mid;
+  }
+  if (lane == 0) out[(size_t)t * out_ld + out_col] = f32_from_order_key(lo);
+}
+
+// ---- merge of per-shard top-k_loc lists (feature-sharded encode, msae/parallel.py) ---------------
+// gathered: int32 [G][2][T][kl] exactly as all_gather_into_tensor lays out each rank's packed
+// [2][T][kl] block (plane 0 = f32 activation bits, plane 1 = GLOBAL feature index).
+// One wave per token: G*kl rank keys into LDS, bitonic sort, canonical top-k out.  flagged[t] = 1
+// when some shard's LAST gathered latent ranks inside the merged top-k (that shard may own more
+// members than it sent; the host redoes those tokens with k_loc = k).
+__global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t *__restrict__ gathered, int T,
+                                                        int G, int kl, int k,
+                                                        float *__restrict__ vals,
+                                                        int32_t *__restrict__ idx,
+                                                        int32_t *__restrict__ flagged) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];
+  const int lane = threadIdx.x, t = blockIdx.x;
+  const int M = G * kl, np = next_pow2(M);
+  unsigned long long worst_last = 0ull;  // best (largest) key among the shards' last entries
+  for (int i = lane; i < np; i += 64) {
+    unsigned long long key = 0ull;
+    if (i < M) {
+      const int g = i / kl, j = i % kl;
+      const float v = __int_as_float(gathered[(((size_t)g * 2 + 0) * T + t) * kl + j]);
+      const int f = gathered[(((size_t)g * 2 + 1) * T + t) * kl + j];
+      key = rank_key(v, f);
+      if (j == kl - 1) worst_last = key > worst_last ? key : worst_last;
+    }
+    mkeys[i] = key;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(worst_last, off, 64);
+    worst_last = o > worst_last ? o : worst_last;
+  }
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = lane; i < (np >> 1); i += 64) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = mkeys[lo], y = mkeys[hi];
+        if ((x < y) == desc) { mkeys[lo] = y; mkeys[hi] = x; }
+      }
+    }
+  __syncthreads();
+  for (int j = lane; j < k; j += 64) {
+    const unsigned long long key = mkeys[j];
+    idx[(size_t)t * k + j] = rank_key_index(key);
+    vals[(size_t)t * k + j] = f32_from_order_key((unsigned)(key >> 32));
+  }
+  if (lane == 0 && flagged) flagged[t] = (kl < k && worst_last >= mkeys[k - 1]) ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" size_t msae_topk_ws_bytes(int T, int N, int k) {
@@ -238,8 +321,33 @@ int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const in
   return msae_launch_status();
 }
 
+// out[t*out_ld + out_col] = r-th largest of rows[t][0..S); false when the shape has no fast kernel.
+bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float *out, int out_ld,
+                           int out_col, hipStream_t s) {
+  if (S % 256 || ld % 4 || !msae_aligned(rows, 16) || r < 1 || r > S) return false;
+  const dim3 grid((T + 3) / 4), block(256);
+  switch (S / 64) {
+#define KTH_CASE(V) case V: hipLaunchKernelGGL(kth_value_kernel<V>, grid, block, 0, s, rows, T, S, ld, r, out, out_ld, out_col); return true;
+    KTH_CASE(4) KTH_CASE(8) KTH_CASE(16) KTH_CASE(32) KTH_CASE(64) KTH_CASE(128)
+#undef KTH_CASE
+    default: return false;
+  }
+}
+
 extern "C" int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_t *idx,
                              void *ws, size_t ws_bytes, void *stream) {
   (void)ws; (void)ws_bytes;
   return msae_topk_launch(latents, T, N, k, N, nullptr, vals, idx, (hipStream_t)stream);
+}
+
+extern "C" int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, int k, float *vals,
+                               int32_t *idx, int32_t *flagged, void *stream) {
+  if (T < 0 || G <= 0 || kl <= 0 || k <= 0 || (long)G * kl < k || (long)G * kl > 8192) return MSAE_EINVAL;
+  if (T == 0) return 0;
+  const size_t smem = (size_t)next_pow2(G * kl) * sizeof(unsigned long long);
+  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)merge_topk_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(T), dim3(64), smem, (hipStream_t)stream, gathered, T, G,
+                     kl, k, vals, idx, flagged);
+  return msae_launch_status();
 }

@@ -242,3 +242,18 @@ def sparsify(top_acts: Tensor, top_indices: Tensor, num_latents: int, row_base: 
                                                _hip.ptr(fb), num_latents, row_base, _hip.ptr(counts),
                                                _hip.ptr(loc), _hip.ptr(act), st), "msae_sparsify_write")
     return loc, act
+
+
+def merge_topk_gathered(gathered: Tensor, T: int, G: int, kl: int, k: int):
+    """Canonical top-k of the all-gathered per-shard pairs (int32 [G*2, T, kl]) on the device.
+    -> (vals f32 [T,k], idx int64 [T,k], flagged bool [T])."""
+    dev = _hip.require_device(gathered)
+    lib = _hip.load()
+    assert gathered.dtype == torch.int32 and gathered.is_contiguous() and gathered.numel() == G * 2 * T * kl
+    vals = torch.empty(T, k, dtype=torch.float32, device=dev)
+    idx = torch.empty(T, k, dtype=torch.int32, device=dev)
+    flagged = torch.empty(T, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_merge_topk(_hip.ptr(gathered), T, G, kl, k, _hip.ptr(vals), _hip.ptr(idx),
+                                       _hip.ptr(flagged), _hip.stream_of(gathered)), "msae_merge_topk")
+    return vals, idx.to(torch.int64), flagged.bool()

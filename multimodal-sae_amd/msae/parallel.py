@@ -82,36 +82,41 @@ class ShardedSae:
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
         self._encode, self._decode = encode_fn, decode_fn
 
-    def _gather_pairs(self, vals: Tensor, idx: Tensor):
-        """all-gather of [T, kk] (f32, global i32) pairs -> ([T, G, kk] f32, [T, G, kk] int64)."""
+    def _gather_merge(self, vals: Tensor, idx: Tensor):
+        """all-gather the [T, kk] (f32, global i32) pairs of every rank, merge to the canonical
+        top-k.  -> (vals [T,k], idx [T,k] int64, flagged [T] bool)."""
         T, kk = vals.shape
         packed = torch.stack((vals.contiguous().view(torch.int32),
                               (idx + self.rank * self.n_loc).to(torch.int32)), 0).contiguous()
         flat = torch.empty((self.world * 2, T, kk), dtype=torch.int32, device=packed.device)
         dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
-        g = flat.view(self.world, 2, T, kk)
-        return g[:, 0].view(torch.float32).permute(1, 0, 2), g[:, 1].permute(1, 0, 2).to(torch.int64)
+        if flat.is_cuda:
+            from . import ops
+
+            return ops.merge_topk_gathered(flat, T, self.world, kk, self.k)   # HIP merge kernel
+        g = flat.view(self.world, 2, T, kk)                     # CPU/gloo: the same merge in torch
+        av, ai = g[:, 0].view(torch.float32).permute(1, 0, 2), g[:, 1].permute(1, 0, 2).to(torch.int64)
+        mv, mi = merge_topk(av.reshape(T, -1), ai.reshape(T, -1), self.k)
+        if kk < self.k:
+            # a shard whose LAST gathered latent ranks inside the merged top-k may own further members
+            kth = canonical_key(mv[:, -1], mi[:, -1])
+            flagged = (canonical_key(av[:, :, -1], ai[:, :, -1]) >= kth[:, None]).any(dim=1)
+        else:
+            flagged = torch.zeros(T, dtype=torch.bool, device=mv.device)
+        return mv, mi, flagged
 
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
         if not self.collective:
             return self._encode(x, self.k)
         vals, idx, status = self._encode(x, self.k_loc)
-        T = vals.shape[0]
-        all_vals, all_idx = self._gather_pairs(vals, idx)                    # [T, G, k_loc]
-        mv, mi = merge_topk(all_vals.reshape(T, -1), all_idx.reshape(T, -1), self.k)
+        mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
-            # truncation check: a shard whose LAST gathered latent ranks inside the merged top-k may
-            # own further members that were never gathered
-            kth = canonical_key(mv[:, -1], mi[:, -1])                        # [T]
-            last = canonical_key(all_vals[:, :, -1], all_idx[:, :, -1])      # [T, G]
-            flagged = (last >= kth[:, None]).any(dim=1)
-            redo = torch.nonzero(flagged).flatten()                          # same on every rank
+            redo = torch.nonzero(flagged).flatten()             # identical on every rank
             if redo.numel():
                 self.second_round_tokens += int(redo.numel())
                 v2, i2, s2 = self._encode(x[redo].contiguous(), self.k)
-                av2, ai2 = self._gather_pairs(v2, i2)
-                mv2, mi2 = merge_topk(av2.reshape(len(redo), -1), ai2.reshape(len(redo), -1), self.k)
+                mv2, mi2, _ = self._gather_merge(v2, i2)
                 mv[redo], mi[redo] = mv2, mi2
                 status = status.clone()
                 status[redo] = torch.maximum(status[redo], s2)

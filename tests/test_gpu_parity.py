@@ -461,3 +461,30 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
+
+
+@pytest.mark.parametrize("T,G,kl,k", [(100, 8, 16, 32), (33, 2, 32, 32), (17, 4, 24, 32), (5, 8, 64, 256)])
+def test_merge_kernel_matches_torch_merge(dev, T, G, kl, k):
+    """HIP merge of the all-gathered per-shard pairs == the torch merge used on CPU/gloo (itself
+    checked against the single-shard oracle result in test_sharded_gloo.py), incl. the truncation
+    flag and ties / zeros."""
+    from msae import ops
+    from msae.parallel import canonical_key, merge_topk
+
+    g = torch.Generator().manual_seed(T * 7 + G)
+    vals = torch.relu(torch.randn(G, T, kl, generator=g)).sort(dim=-1, descending=True).values
+    vals[:, :3] = torch.round(vals[:, :3] * 2) / 2                   # ties across shards
+    vals = vals.sort(dim=-1, descending=True).values
+    idx = torch.stack([torch.stack([torch.randperm(1000, generator=g)[:kl] + 1000 * s for _ in range(T)])
+                       for s in range(G)]).to(torch.int32)
+    gathered = torch.stack((vals.view(torch.int32), idx), 1).reshape(G * 2, T, kl).contiguous()
+    v, i, flagged = ops.merge_topk_gathered(gathered.to(dev), T, G, kl, k)
+    av, ai = vals.permute(1, 0, 2), idx.permute(1, 0, 2).long()
+    rv, ri = merge_topk(av.reshape(T, -1), ai.reshape(T, -1), k)
+    assert torch.equal(i.cpu(), ri) and torch.equal(v.cpu(), rv)
+    if kl < k:
+        kth = canonical_key(rv[:, -1], ri[:, -1])
+        rf = (canonical_key(av[:, :, -1], ai[:, :, -1]) >= kth[:, None]).any(dim=1)
+        assert torch.equal(flagged.cpu(), rf)
+    else:
+        assert not flagged.any()
