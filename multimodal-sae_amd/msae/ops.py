@@ -257,3 +257,64 @@ def merge_topk_gathered(gathered: Tensor, T: int, G: int, kl: int, k: int):
         _hip.check(lib.msae_merge_topk(_hip.ptr(gathered), T, G, kl, k, _hip.ptr(vals), _hip.ptr(idx),
                                        _hip.ptr(flagged), _hip.stream_of(gathered)), "msae_merge_topk")
     return vals, idx.to(torch.int64), flagged.bool()
+
+
+# ---- trainable encoder (training forward, sae.py:193-247) -------------------------------------------
+class _SparseEncode(torch.autograd.Function):
+    """pre_acts + the three TopK selections of Sae.forward as ONE autograd node with a SPARSE
+    backward.  The reference back-propagates a dense [T, N] gradient through topk -> relu ->
+    nn.Linear (a second full GEMM, dW = g^T a); only the selected (token, latent) pairs carry
+    gradient, so here
+        dW_enc[n] += g[t,j] * a[t]      -> msae_decode_bwd_wdec_f32 (sparse outer-product accumulate)
+        da[t]      = sum_j g[t,j] W_enc[n_tj]  -> msae_decode_f32 over W_enc (gather matmul)
+        db_enc[n] += g[t,j]  ;  dx = da ;  db_dec = -sum_t da[t]
+    with g masked by relu'(pre) = (value > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi):
+        pre = pre_acts(x, W_enc, b_enc, b_dec)
+        vals, idxs = [], []
+        v, i = topk(pre, k)
+        vals.append(v); idxs.append(i)
+        if k_aux > 0:
+            v, i = topk(torch.where(dead_mask[None], pre, -torch.inf), k_aux)  # sae.py:217-220
+            vals.append(v); idxs.append(i)
+        if k_multi > 0:
+            v, i = topk(pre, k_multi)                                           # sae.py:233
+            vals.append(v); idxs.append(i)
+        ctx.save_for_backward(x, W_enc, b_dec, torch.cat(idxs, -1), torch.cat(vals, -1))
+        ctx.splits = [t.shape[-1] for t in vals]
+        ctx.has_b_enc = b_enc is not None
+        out = []
+        for v, i in zip(vals, idxs):
+            out += [v, i]
+        for i in idxs:
+            ctx.mark_non_differentiable(i)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, W_enc, b_dec, idx_cat, val_cat = ctx.saved_tensors
+        g = [grads[2 * j] if grads[2 * j] is not None else
+             torch.zeros(val_cat.shape[0], n, device=val_cat.device) for j, n in enumerate(ctx.splits)]
+        g_cat = torch.cat(g, -1).float() * (val_cat > 0)           # relu'
+        a = x.float() - b_dec
+        need_x, need_W, need_be, need_bd = ctx.needs_input_grad[:4]
+        g_x = g_W = g_be = g_bd = None
+        if need_W:
+            _, g_W = decode_bwd(idx_cat, g_cat, W_enc, a.contiguous(), False, True)
+        if need_be and ctx.has_b_enc:
+            g_be = torch.zeros(W_enc.shape[0], device=g_cat.device).index_add_(
+                0, idx_cat.reshape(-1), g_cat.reshape(-1))
+        if need_x or need_bd:
+            da = decode(idx_cat, g_cat, W_enc, None)
+            g_x = da.to(x.dtype) if need_x else None
+            g_bd = -da.sum(0) if need_bd else None
+        return g_x, g_W, g_be, g_bd, None, None, None, None
+
+
+def sparse_encode(x: Tensor, W_enc: Tensor, b_enc: Tensor, b_dec: Tensor, k: int,
+                  dead_mask: Optional[Tensor] = None, k_aux: int = 0, k_multi: int = 0):
+    """-> [(acts, idx)] for the top-k, (optional) AuxK and (optional) Multi-TopK selections."""
+    out = _SparseEncode.apply(x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi)
+    return [(out[2 * j], out[2 * j + 1]) for j in range(len(out) // 2)]

@@ -167,29 +167,33 @@ class Sae(nn.Module):
         return ops.decode(top_indices, top_acts.to(self.dtype), self.W_dec, self.b_dec)
 
     def forward(self, x: Tensor, dead_mask: Union[Tensor, None] = None) -> ForwardOutput:
-        """Training forward (sae.py:193-247): reconstruction, FVU, AuxK and Multi-TopK terms.
-        Gradients flow through `decode` (W_dec, b_dec, activations); the encoder's backward is the
-        trainer row of DESIGN.md section 8(f)."""
-        pre_acts = self.pre_acts(x)
-        top_acts, top_indices = self.select_topk(pre_acts)
+        """Training forward (sae.py:193-247): reconstruction, FVU, AuxK and Multi-TopK terms, fully
+        differentiable.  The encoder is one autograd node with a sparse backward (ops._SparseEncode):
+        gradients reach encoder.weight / encoder.bias / b_dec / x only through the selected latents,
+        exactly as in the reference's dense graph, without its second [T,N]x[T,d] GEMM."""
+        k_aux, scale = 0, 0.0
+        if dead_mask is not None and (num_dead := int(dead_mask.sum())) > 0:
+            k_aux = x.shape[-1] // 2                      # heuristic from the paper (sae.py:209)
+            scale = min(num_dead / k_aux, 1.0)
+            k_aux = min(k_aux, num_dead)
+        k_multi = 4 * self.cfg.k if self.cfg.multi_topk else 0
+        sel = ops.sparse_encode(x, self.encoder.weight, self.encoder.bias, self.b_dec, self.cfg.k,
+                                dead_mask, k_aux, k_multi)
+        top_acts, top_indices = sel[0]
         sae_out = self.decode(top_acts, top_indices)
         e = sae_out - x
         total_variance = (x - x.mean(0)).pow(2).sum()
 
-        if dead_mask is not None and (num_dead := int(dead_mask.sum())) > 0:
-            k_aux = x.shape[-1] // 2
-            scale = min(num_dead / k_aux, 1.0)
-            k_aux = min(k_aux, num_dead)
-            auxk_latents = torch.where(dead_mask[None], pre_acts, -torch.inf)
-            auxk_acts, auxk_indices = ops.topk(auxk_latents, k_aux)
+        if k_aux > 0:
+            auxk_acts, auxk_indices = sel[1]
             e_hat = self.decode(auxk_acts, auxk_indices)
             auxk_loss = scale * (e_hat - e).pow(2).sum() / total_variance
         else:
             auxk_loss = sae_out.new_tensor(0.0)
 
         fvu = e.pow(2).sum() / total_variance
-        if self.cfg.multi_topk:
-            top_acts, top_indices = ops.topk(pre_acts, 4 * self.cfg.k)
+        if k_multi > 0:
+            top_acts, top_indices = sel[-1]
             sae_out = self.decode(top_acts, top_indices)
             multi_topk_fvu = (sae_out - x).pow(2).sum() / total_variance
         else:

@@ -251,6 +251,29 @@ def train_fixture(Sae, SaeConfig):
                dec_grad_acts=acts.grad.numpy(), dec_grad_Wdec_rows=sae.W_dec.grad[idx.flatten()].numpy(),
                dec_grad_Wdec_nnzrows=int((sae.W_dec.grad.abs().sum(1) > 0).sum()),
                dec_grad_bdec=sae.b_dec.grad.numpy())
+    # full training gradients of the trainer's loss (train/sae/sae/trainer.py:379-384):
+    # loss = fvu + auxk_alpha * auxk_loss + multi_topk_fvu / 8
+    sae.zero_grad()
+    xg = x.clone().requires_grad_()
+    fo = sae(xg, dead)
+    loss = fo.fvu + (1.0 / 32) * fo.auxk_loss + fo.multi_topk_fvu / 8
+    loss.backward()
+    out.update(loss=loss.item(), g_W_enc=sae.encoder.weight.grad.numpy(), g_b_enc=sae.encoder.bias.grad.numpy(),
+               g_W_dec=sae.W_dec.grad.numpy(), g_b_dec=sae.b_dec.grad.numpy(), g_x=xg.grad.numpy())
+    # one optimizer step in the trainer's order (train/sae/sae/trainer.py:347-401): renormalise the
+    # decoder, forward/backward, clip_grad_norm_(1.0), remove decoder-parallel grads, Adam step
+    sae2 = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=11, multi_topk=True)
+    opt = torch.optim.Adam(sae2.parameters(), lr=1e-3)
+    sae2.set_decoder_norm_to_unit_norm()
+    fo = sae2(x, dead)
+    (fo.fvu + (1.0 / 32) * fo.auxk_loss + fo.multi_topk_fvu / 8).backward()
+    torch.nn.utils.clip_grad_norm_(sae2.parameters(), 1.0)
+    sae2.remove_gradient_parallel_to_decoder_directions()
+    opt.step()
+    out.update(step_fvu=fo.fvu.item(), step_W_enc=sae2.encoder.weight.detach().numpy(),
+               step_b_enc=sae2.encoder.bias.detach().numpy(), step_W_dec=sae2.W_dec.detach().numpy(),
+               step_b_dec=sae2.b_dec.detach().numpy(),
+               step_fired=np.unique(fo.latent_indices.numpy()))
     np.savez_compressed(HERE / "g7_train.npz", **out)
     print("wrote g7_train", out["fvu"], out["auxk_loss"], out["multi_topk_fvu"])
 

@@ -488,3 +488,40 @@ def test_merge_kernel_matches_torch_merge(dev, T, G, kl, k):
         assert torch.equal(flagged.cpu(), rf)
     else:
         assert not flagged.any()
+
+
+def test_training_gradients_match_reference(dev, golden_dir):
+    """Full backward of the trainer's loss (fvu + auxk/32 + multi_topk_fvu/8,
+    train/sae/sae/trainer.py:379-384) through the sparse encoder backward and the decoder kernels
+    vs the reference's dense autograd graph."""
+    g = np.load(golden_dir / "g7_train.npz")
+    sae = _golden_sae(dev, g)
+    x = _t(g["x"], dev).requires_grad_()
+    out = sae(x, _t(g["dead_mask"], dev))
+    loss = out.fvu + (1.0 / 32) * out.auxk_loss + out.multi_topk_fvu / 8
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    for name, got in (("g_W_enc", sae.encoder.weight.grad), ("g_b_enc", sae.encoder.bias.grad),
+                      ("g_W_dec", sae.W_dec.grad), ("g_b_dec", sae.b_dec.grad), ("g_x", x.grad)):
+        ref = g[name]
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-7, (name, err, np.abs(ref).max())
+
+
+def test_train_step_matches_reference_adam_step(dev, golden_dir):
+    """SaeTrainStep.step == the reference trainer's step order executed on the reference Sae
+    (renorm, fwd/bwd, clip, parallel-grad removal, Adam lr=1e-3): parameters after one step."""
+    from msae.train import SaeTrainStep
+
+    g = np.load(golden_dir / "g7_train.npz")
+    sae = _golden_sae(dev, g)
+    ts = SaeTrainStep(sae, lr=1e-3, auxk_alpha=1.0 / 32, dead_feature_threshold=0)
+    ts.num_tokens_since_fired[torch.from_numpy(g["dead_mask"]).to(dev)] = 1   # same dead mask as the fixture
+    stats = ts.step(_t(g["x"], dev))
+    assert abs(stats["fvu"] - float(g["step_fvu"])) <= 1e-4 * abs(float(g["step_fvu"]))
+    for name, p in (("step_W_enc", sae.encoder.weight), ("step_b_enc", sae.encoder.bias),
+                    ("step_W_dec", sae.W_dec), ("step_b_dec", sae.b_dec)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[name], rtol=0, atol=2e-5, err_msg=name)
+    fired = torch.zeros(sae.num_latents, dtype=torch.bool)
+    fired[torch.from_numpy(g["step_fired"])] = True
+    assert torch.equal(ts.num_tokens_since_fired.cpu() == 0, fired)
