@@ -139,10 +139,12 @@ def main():
                         force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
 
     def step():
-        return engine.forward(x)
+        # streaming loop: the reconstruction all-gather of step i overlaps the encode of step i+1
+        return engine.forward(x, async_gather=ddp)
 
     for _ in range(args.warmup):
         step()
+    engine.synchronize()
     torch.cuda.synchronize()
 
     # stage events are recorded on the launch stream during the timed region
@@ -156,6 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    engine.synchronize()
     torch.cuda.synchronize()
     if ddp:
         dist.barrier()

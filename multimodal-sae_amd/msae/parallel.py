@@ -69,6 +69,7 @@ class ShardedSae:
         self.collective = world > 1 or (force_collectives and dist.is_initialized())
         self.decode_events = None
         self.decode_event_i = 0
+        self._pending = None
         self.second_round_tokens = 0
         if k_loc is None:
             k_loc = min(k, 2 * -(-k // world) + 8) if self.collective else k
@@ -122,12 +123,16 @@ class ShardedSae:
                 status[redo] = torch.maximum(status[redo], s2)
         return mv, mi, status
 
-    def decode(self, vals: Tensor, idx: Tensor, gather: bool = True) -> Tensor:
+    def decode(self, vals: Tensor, idx: Tensor, gather: bool = True, async_gather: bool = False) -> Tensor:
+        """Token-sharded decode.  With `async_gather` the all-gather of the reconstruction is issued
+        asynchronously (RCCL's own stream) and overlaps whatever the caller enqueues next -- the
+        next batch's encode GEMM in a streaming loop; `synchronize()` (or the next decode) joins it."""
         ev = None
         if self.decode_events is not None and self.decode_event_i < len(self.decode_events):
             ev = self.decode_events[self.decode_event_i]
             self.decode_event_i += 1
             ev[0].record()
+        self.synchronize()                                   # buffers of the previous gather are free
         if not self.collective:
             out = self._decode(idx, vals)
         else:
@@ -139,7 +144,9 @@ class ShardedSae:
                 pad = torch.zeros(per, d, dtype=local.dtype, device=local.device)
                 pad[: hi - lo] = local
                 full = torch.empty(self.world * per, d, dtype=local.dtype, device=local.device)
-                dist.all_gather_into_tensor(full, pad, group=self.group)
+                work = dist.all_gather_into_tensor(full, pad, group=self.group, async_op=async_gather)
+                if async_gather:
+                    self._pending = (work, pad, full)        # keep the buffers alive until joined
                 out = full[:T]
             else:
                 out = local
@@ -147,7 +154,14 @@ class ShardedSae:
             ev[1].record()
         return out
 
-    def forward(self, x: Tensor) -> dict:
+    def synchronize(self):
+        """Join an outstanding asynchronous reconstruction gather (stream-ordered wait)."""
+        pending = getattr(self, "_pending", None)
+        if pending is not None:
+            pending[0].wait()
+            self._pending = None
+
+    def forward(self, x: Tensor, async_gather: bool = False) -> dict:
         vals, idx, status = self.encode(x)
-        recon = self.decode(vals, idx)
+        recon = self.decode(vals, idx, async_gather=async_gather)
         return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
