@@ -83,6 +83,12 @@ int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_
 size_t msae_encoder_prepared_bytes(int N, int d);
 int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream);
 
+/* Operand type of the fused encoder's candidate pass: 1 = int8 MFMA (default: per-token / per-feature
+ * scales, massive-activation dims in a separately scaled k-tile), 0 = bf16 MFMA.  Either way the
+ * candidates are re-scored with the exact f32 chain, so outputs do not depend on the choice.  The
+ * environment variable MSAE_COARSE=bf16|int8 sets the initial value.  Changes the workspace size. */
+int msae_set_coarse_mode(int mode);
+
 /* Fused Sae.encode: vals/idx[T][k] = canonical top-k of relu((x - b_dec) W_enc^T + b_enc), with
  * the reference hooks' edits of the dense latents applied before TopK:
  *   set_feature >= 0 : latents[:, set_feature] = set_value       (steering.py:113-114)

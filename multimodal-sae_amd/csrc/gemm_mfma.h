@@ -1,0 +1,348 @@
+// gemm_mfma.h -- candidate-pass GEMM  C[T][N] = A[T][K] * B[N][K]^T  on the gfx950 matrix cores, with
+// the SAE epilogues.  Two operand types share one tile / pipeline structure:
+//   bf16 : v_mfma_f32_32x32x16_bf16, f32 accumulate          (2.5 PFLOP/s dense peak)
+//   int8 : v_mfma_i32_32x32x32_i8,  i32 accumulate, per-token x per-feature scales applied in the
+//          epilogue; a leading "outlier" k-tile carries the few massive activation dims at a
+//          coarser per-token scale (acc *= m[t] after it)   (~2x the bf16 rate, half the bytes)
+// This is the dominant kernel of the fused encoder (encode_fused.hip): 2*d*N FLOP per token.  Both
+// operands are K-contiguous, so A and B fragments are read the same way.
+//
+// Structure (template parameters BM, BN, STAGES, WM, WN; a k-tile is always 128 B per row):
+//   * a workgroup of WM x WN waves computes a BM x BN tile; each wave owns (BM/WM) x (BN/WN) as
+//     MI x NI blocks of 32x32 (16 accumulator VGPRs each);
+//   * operand tiles travel L2 -> LDS by global_load_lds (16 B per lane, 1 KiB per wave instruction,
+//     no VGPR round trip) into a ring of STAGES slots; counted s_waitcnt vmcnt + ONE raw s_barrier
+//     per k-tile, so loads stay in flight across barriers;
+//   * LDS image: row r of a tile at byte r*128 with its eight 16-B chunks XOR-permuted by
+//     swz(r) = (r >> 1) & 7: every ds_read_b128 fragment read is bank-conflict-free
+//     (SQ_LDS_BANK_CONFLICT = 0 measured).  global_load_lds writes lane-linear, so the permutation
+//     is applied to the per-lane SOURCE address and again on the read;
+//   * tile -> workgroup map is XCD-aware: the 32 workgroups resident on one XCD's 32 CUs form an
+//     8 (M) x 4 (N) super-tile sharing 8 A-tiles and 4 B-tiles in that XCD's private L2.
+//
+// Measured on MI355X (tools/gemm_sweep, T=8192 K=4096 N=131072, random data; profiles/):
+//   256x256 tile, 2-slot ring, 8 waves (2x4): bf16 1.20 PFLOP/s (1.39 on zero-filled operands: the
+//   kernel is partly DVFS-bound), int8 2x that; 128x128: 1.0.  Ablations: MFMA+barriers only
+//   5.4 ms, LDS-DMA staging only 5.4 ms (~12.7 TB/s L2->LDS, independent of ring depth and row
+//   pitch), both 7.3 ms.  Deeper rings (half-size k-tiles x 4 slots), a two-group ping-pong
+//   schedule, s_setprio and an L2 prefetch were all measured equal or worse and are not kept.
+//
+// Epilogues: DENSE  out[t][n] = value + bias[feature(n)]                      (sample pass)
+//            THRESH append (feature, value + bias) to token t's candidate list when > tau[t]
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+
+struct GemmEpilogue {
+  const float *bias;             // b_enc
+  int bias_stride, bias_off;     // feature of column n is n*bias_stride + bias_off
+  float *dense; int ld_dense;    // DENSE
+  const float *tau_vals; int tau_ld, tau_col;   // THRESH: tau[t] = tau_vals[t*tau_ld + tau_col]
+  int *cnt; unsigned long long *cand; int cap;  // candidate lists
+  int skip_a, skip_b;            // features never emitted (hook edits replace their latents)
+  // int8 only: value = float(acc) * sx[t] * sw[feature]
+  const float *sx, *sw;
+};
+
+// Operands of one launch.  A rows are tokens, B rows are features; ld* in BYTES.
+struct GemmOperands {
+  const unsigned char *A, *B;
+  size_t ldA, ldB;
+  int nk;                        // k-tiles of 128 B per row
+  // int8 only: optional leading outlier tile (one k-tile, rows 128 B apart) and its multiplier
+  const unsigned char *Ao, *Bo;
+  const int *mscale;             // acc *= mscale[t] after the outlier tile
+};
+
+// FLAGS (tuning only; results invalid when an ABL bit is set):
+//   bit 2 ABL_NOSTAGE  skip the LDS-DMA staging in the loop
+//   bit 3 ABL_NOREAD   read the fragments once and reuse them
+//   bit 4 ABL_NOMFMA   issue no MFMA
+template <int BM_, int BN_, int STAGES_, int WM_, int WN_, bool I8_ = false, int FLAGS_ = 0>
+struct GemmCfg {
+  static constexpr int BM = BM_, BN = BN_, STAGES = STAGES_, WM = WM_, WN = WN_;
+  static constexpr bool I8 = I8_;
+  static constexpr bool ABL_NOSTAGE = FLAGS_ & 4, ABL_NOREAD = FLAGS_ & 8, ABL_NOMFMA = FLAGS_ & 16;
+  static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
+  static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
+  static constexpr int KS = 4;                   // MFMA k-steps per tile (32 B per lane-half each)
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
+  static constexpr int A_PIECES = A_BYTES / 1024;
+  static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
+  static_assert(TM % 32 == 0 && TN % 32 == 0, "tile shape");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ int gemm_swz(int row) { return (row >> 1) & 7; }
+
+// Issue this wave's share of one k-tile (byte offset kbyte in each row) into ring slot `slot`.
+template <class C>
+__device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A, size_t ldA,
+                                           const unsigned char *__restrict__ B, size_t ldB, int m0,
+                                           int n0, int Tp, int N, size_t kbyte, unsigned char *lds,
+                                           int slot, int wave, int lane) {
+  unsigned char *base = lds + slot * C::STAGE_BYTES;
+  const int r_in = lane >> 3, c_in = lane & 7;
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) {
+    const int piece = wave * C::PPW + i;              // wave-uniform
+    const bool isA = piece < C::A_PIECES;
+    const int pl = isA ? piece : piece - C::A_PIECES;  // piece index inside its operand tile
+    const int r = pl * 8 + r_in;                      // tile row filled by this lane
+    const int c = c_in ^ gemm_swz(r);                 // global chunk landing in LDS slot (r, c_in)
+    int grow = (isA ? m0 : n0) + r;
+    const int gmax = isA ? Tp : N;
+    grow = grow < gmax ? grow : gmax - 1;             // rows past the end are loaded but never used
+    const unsigned char *src = (isA ? A + (size_t)grow * ldA : B + (size_t)grow * ldB) + kbyte + c * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(base + piece * 1024),
+                                     16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ i32x4 gemm_frag(const unsigned char *tile, int row, int chunk) {
+  return *reinterpret_cast<const i32x4 *>(tile + row * 128 + ((chunk ^ gemm_swz(row)) << 4));
+}
+
+// tile id -> (tm, tn); see header.  Falls back to M-fastest order when the grid does not factor.
+__device__ __forceinline__ void gemm_map_tile(int b, int nM, int nN, int &tm, int &tn) {
+  constexpr int GM = 8, GN = 4;
+  if (nM % GM == 0 && nN % GN == 0 && ((nM / GM) * (nN / GN)) % 8 == 0) {
+    const int xcd = b & 7, slot = b >> 3;
+    const int grp = slot / (GM * GN), w = slot % (GM * GN);
+    const int st = grp * 8 + xcd;
+    const int nSM = nM / GM;
+    tm = (st % nSM) * GM + (w % GM);
+    tn = (st / nSM) * GN + (w / GM);
+  } else {
+    tm = b % nM;
+    tn = b / nM;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one k-tile of MFMAs out of the LDS images sA / sB
+template <class C>
+__device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
+                                             const unsigned char *sB, int wr, int wc, int l31, int kh,
+                                             i32x4 (&abl_a)[C::MI], i32x4 (&abl_b)[C::NI]) {
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int chunk = ks * 2 + kh;
+    i32x4 a[C::MI], b[C::NI];
+    if constexpr (C::ABL_NOREAD) {
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) { a[i] = abl_a[i]; asm volatile("" : "+v"(a[i])); }
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) { b[j] = abl_b[j]; asm volatile("" : "+v"(b[j])); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) a[i] = gemm_frag(sA, wr * C::TM + i * 32 + l31, chunk);
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) b[j] = gemm_frag(sB, wc * C::TN + j * 32 + l31, chunk);
+    }
+    if constexpr (C::ABL_NOMFMA) {
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) asm volatile("" ::"v"(b[j]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NI; ++j) {
+          if constexpr (C::I8)   // the accumulator registers hold i32 on this path
+            acc[i][j] = __builtin_bit_cast(
+                f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+// Epilogue.  DENSE stores every value.  THRESH compares with the per-token threshold; survivors are
+// rare (~1 per 500 outputs) but each needs a slot in its token's candidate list, i.e. a RETURNING
+// global atomic (~2 us round trip).  Doing that inline serialises ~30 round trips per wave -- as
+// long as the whole k-loop.  So survivors are first queued in LDS (the operand ring is free by
+// now; an LDS atomic returns in ~100 cycles) and then flushed, one queue entry per lane: the
+// global atomics of the whole workgroup are in flight together.
+template <class C, bool DENSE>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
+                                              int m0, int n0, int wr, int wc, int lane,
+                                              unsigned char *smem) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  constexpr int QCAP = 8192;                           // 64 KiB of the (>= 128 KiB) ring
+  unsigned *q_count = reinterpret_cast<unsigned *>(smem);
+  unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + 16);
+  if constexpr (!DENSE) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave has finished reading the ring
+    if (threadIdx.x == 0) *q_count = 0u;
+    __syncthreads();
+  }
+  // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i) {
+    // per-lane row constants of this row block first (independent loads), then the compares
+    float tau[16], rs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      tau[e] = 0.f; rs[e] = 0.f;
+      if constexpr (!DENSE) {
+        const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
+        tau[e] = (v > 0.f) ? v : __builtin_inff();  // degenerate / padded token: emit nothing
+      }
+      if constexpr (C::I8) rs[e] = (t < T) ? ep.sx[t] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      const int col = wc * C::TN + j * 32 + l31;       // column inside the tile
+      const int n = n0 + col;
+      const int feat = n * ep.bias_stride + ep.bias_off;
+      const float bn = ep.bias ? ep.bias[feat] : 0.f;
+      float cs = 1.f;
+      if constexpr (C::I8) cs = ep.sw[feat];
+      const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v;
+        if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * cs) + bn;
+        else v = acc[i][j][e] + bn;
+        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
+        const int t = m0 + row;
+        if constexpr (DENSE) {
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n] = v;
+        } else {
+          if (v > tau[e] && live) {
+            const unsigned slot = atomicAdd(q_count, 1u);                       // LDS atomic
+            if (slot < QCAP) {
+              queue[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(row << 16 | col);
+            } else {                                                              // queue full: slow path
+              const int gslot = atomicAdd(ep.cnt + t, 1);
+              if (gslot < ep.cap)
+                ep.cand[(size_t)t * ep.cap + gslot] =
+                    ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (!DENSE) {
+    __syncthreads();
+    const unsigned nq = *q_count < QCAP ? *q_count : QCAP;
+    for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
+      const unsigned long long e = queue[q];
+      const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
+      const float v = __uint_as_float((unsigned)(e >> 32));
+      const int t = m0 + row;
+      const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+      const int gslot = atomicAdd(ep.cnt + t, 1);
+      if (gslot < ep.cap)
+        ep.cand[(size_t)t * ep.cap + gslot] =
+            ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
+    }
+  }
+}
+
+template <class C, bool DENSE>
+__global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int Tp, int N, int nM, int nN,
+                                                     GemmEpilogue ep) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave / C::WN, wc = wave % C::WN;
+  int tm, tn;
+  gemm_map_tile(blockIdx.x, nM, nN, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;   // all-zero bits: also i32 zero
+
+  i32x4 abl_a[C::MI], abl_b[C::NI];
+  if constexpr (C::ABL_NOREAD) {
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) abl_a[i] = *reinterpret_cast<const i32x4 *>(op.A + (size_t)(m0 + i * 32 + l31) * op.ldA + kh * 16);
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) abl_b[j] = *reinterpret_cast<const i32x4 *>(op.B + (size_t)(n0 + j * 32 + l31) * op.ldB + kh * 16);
+  }
+
+  if constexpr (C::I8) {
+    if (op.Ao) {
+      // leading outlier tile: its own staging round trip (1 of nk+1 tiles), then acc *= m[t]
+      gemm_stage<C>(op.Ao, 128, op.Bo, 128, m0, n0, Tp, N, 0, smem, 0, wave, lane);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      gemm_compute<C>(acc, smem, smem + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+        int ms[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          ms[e] = (t < T) ? op.mscale[t] : 1;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NI; ++j) {
+          i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] *= ms[e];
+          acc[i][j] = __builtin_bit_cast(f32x16, v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave is done reading slot 0 before it is refilled
+    }
+  }
+
+  const int nk = op.nk;
+#pragma unroll
+  for (int s = 0; s < C::STAGES - 1; ++s)
+    if (s < nk) gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)s * C::ROWB, smem, s, wave, lane);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // k-tile kt has landed once at most STAGES-2 younger groups of this wave are outstanding
+    if (kt + C::STAGES - 2 < nk) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // all waves' pieces of kt landed; slot of kt-1 is free again
+    const int nkt = kt + C::STAGES - 1;
+    if constexpr (!C::ABL_NOSTAGE) {
+      if (nkt < nk)
+        gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)nkt * C::ROWB, smem,
+                      nkt % C::STAGES, wave, lane);
+    }
+    const unsigned char *sA = smem + (kt % C::STAGES) * C::STAGE_BYTES;
+    gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+  }
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem);
+}
+
+// Host launcher.  Requires Tp % BM == 0 and N % BN == 0 (checked by the caller's plan).
+template <class C, bool DENSE>
+inline int gemm_launch(const GemmOperands &op, int T, int Tp, int N, const GemmEpilogue &ep, hipStream_t s) {
+  if (Tp % C::BM || N % C::BN || op.nk <= 0) return MSAE_EINVAL;
+  const int nM = Tp / C::BM, nN = N / C::BN;
+  auto kern = gemm_kernel<C, DENSE>;
+  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  hipLaunchKernelGGL(kern, dim3(nM * nN), dim3(C::NT), C::LDS_BYTES, s, op, T, Tp, N, nM, nN, ep);
+  return (int)hipGetLastError();
+}

@@ -44,6 +44,7 @@ PROTOTYPES = {
                                     c_void_p, c_void_p]),
     "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "msae_set_coarse_mode": (c_int, [c_int]),
     "msae_merge_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_profile_begin": (c_int, [c_int]),
     "msae_profile_end": (c_int, [c_void_p, c_void_p]),

@@ -93,6 +93,12 @@ def _(latents, k):
             latents.new_empty(*latents.shape[:-1], k, dtype=torch.int64))
 
 
+def set_coarse_mode(mode: str) -> None:
+    """Operand type of the fused encoder's candidate pass: "int8" (default) or "bf16".  Outputs do
+    not depend on it (candidates are re-scored exactly); speed does."""
+    _hip.check(_hip.load().msae_set_coarse_mode({"bf16": 0, "int8": 1}[mode]), "msae_set_coarse_mode")
+
+
 def prepare_encoder(W_enc: Tensor) -> Tensor:
     """One-time bf16 copy (+ sampled rows) of the encoder weights for the fused path."""
     dev = _hip.require_device(W_enc)

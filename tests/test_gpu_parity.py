@@ -194,8 +194,18 @@ def _rand_x(dev, T, d, seed):
     return x.to(torch.bfloat16)
 
 
+@pytest.fixture(params=["int8", "bf16"])
+def coarse(request, dev):
+    """Both operand types of the fused encoder's candidate pass; outputs must not depend on it."""
+    from msae import ops
+
+    ops.set_coarse_mode(request.param)
+    yield request.param
+    ops.set_coarse_mode("int8")
+
+
 @pytest.mark.parametrize("T,d,N,k", [(384, 4096, 16384, 32), (300, 1024, 8192, 64)])
-def test_fused_encode_bit_exact_vs_oracle(dev, T, d, N, k):
+def test_fused_encode_bit_exact_vs_oracle(dev, coarse, T, d, N, k):
     from msae import ops
 
     W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 5)
@@ -211,7 +221,7 @@ def test_fused_encode_bit_exact_vs_oracle(dev, T, d, N, k):
     assert_bit_equal(v.cpu().numpy(), ref_v, "fused vals")
 
 
-def test_fused_encode_full_width_matches_exact_path(dev):
+def test_fused_encode_full_width_matches_exact_path(dev, coarse):
     """BASELINE config 2 shape: d=4096, N=131072, k=32 (and k=256).  Fused path == exact HIP path
     bit for bit on every token; exact HIP path == oracle on a subset of tokens."""
     from msae import ops
@@ -236,7 +246,7 @@ def test_fused_encode_full_width_matches_exact_path(dev):
     assert_bit_equal(ev.cpu().numpy(), ref_v, "exact vals vs oracle")
 
 
-def test_fused_encode_hook_edits(dev):
+def test_fused_encode_hook_edits(dev, coarse):
     """set_feature (steering.py:113-114) / zero_feature (patching/utils.py:43-48) inside the fused
     kernel == the same edits applied to the dense latents."""
     from msae import ops
@@ -265,7 +275,7 @@ def test_fused_encode_hook_edits(dev):
     assert torch.equal(i, ei) and torch.equal(v, ev)
 
 
-def test_fused_encode_degenerate_tokens_take_exact_path(dev):
+def test_fused_encode_degenerate_tokens_take_exact_path(dev, coarse):
     """Tokens with (almost) no positive pre-activation cannot pass the guard band: they must come
     back from the in-call exact fallback (status 1) with the canonical zero-filled top-k."""
     from msae import ops

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../multimodal-sae_amd/csrc/gemm_bf16.h"
+#include "../multimodal-sae_amd/csrc/gemm_mfma.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -32,38 +32,44 @@ __global__ void max_diff(const float *a, const float *b, size_t n, float *res) {
 
 struct Ctx { unsigned short *A, *B; float *tau, *dense, *ref, *res; int *cnt; unsigned long long *cand; int T, d, N, Ns; };
 
-template <class C, bool PP = false>
+template <class C>
 void run(const char *name, Ctx &c, int reps) {
+  GemmOperands op{};
+  op.A = (const unsigned char *)c.A; op.B = (const unsigned char *)c.B;
+  op.ldA = op.ldB = (size_t)c.d * 2; op.nk = c.d * 2 / 128;   // int8 configs read the same bytes as 2*d int8
   GemmEpilogue ep{};
-  // correctness on the small problem (first Ns features)
-  ep.dense = c.dense; ep.ld_dense = c.Ns; ep.bias_stride = 1;
-  CK(hipMemset(c.dense, 0, (size_t)c.T * c.Ns * 4));
-  int rc = gemm_bf16_launch<C, true, PP>(c.A, c.B, c.T, c.T, c.d, c.Ns, ep, 0);
-  if (rc) { printf("%-28s launch failed rc=%d\n", name, rc); return; }
-  CK(hipMemset(c.res, 0, 4));
-  max_diff<<<1024, 256>>>(c.dense, c.ref, (size_t)512 * c.Ns, c.res);   // ref covers the first 512 tokens
-  float md; CK(hipMemcpy(&md, c.res, 4, hipMemcpyDeviceToHost));
-  // timing on the full problem
+  float md = -1.f;
+  if (!C::I8) {  // correctness on the small problem (first Ns features) against the naive reference
+    ep.dense = c.dense; ep.ld_dense = c.Ns; ep.bias_stride = 1;
+    CK(hipMemset(c.dense, 0, (size_t)c.T * c.Ns * 4));
+    int rc = gemm_launch<C, true>(op, c.T, c.T, c.Ns, ep, 0);
+    if (rc) { printf("%-28s launch failed rc=%d\n", name, rc); return; }
+    CK(hipMemset(c.res, 0, 4));
+    max_diff<<<1024, 256>>>(c.dense, c.ref, (size_t)512 * c.Ns, c.res);   // ref covers the first 512 tokens
+    CK(hipMemcpy(&md, c.res, 4, hipMemcpyDeviceToHost));
+  }
   GemmEpilogue et{};
   et.bias_stride = 1; et.tau_vals = c.tau; et.tau_ld = 1; et.tau_col = 0; et.cnt = c.cnt; et.cand = c.cand; et.cap = 16; et.skip_a = et.skip_b = -1;
+  et.sx = c.tau; et.sw = c.tau;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) gemm_bf16_launch<C, false, PP>(c.A, c.B, c.T, c.T, c.d, c.N, et, 0);
+  for (int i = 0; i < 2; ++i) gemm_launch<C, false>(op, c.T, c.T, c.N, et, 0);
   CK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0.f;
   for (int i = 0; i < reps; ++i) {
     CK(hipEventRecord(e0, 0));
-    gemm_bf16_launch<C, false, PP>(c.A, c.B, c.T, c.T, c.d, c.N, et, 0);
+    gemm_launch<C, false>(op, c.T, c.T, c.N, et, 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = fminf(best, ms); sum += ms;
   }
-  double fl = 2.0 * c.T * c.d * (double)c.N;
-  printf("%-28s lds=%3dKB thr=%3d  maxdiff=%.3e  mean %.3f ms (%.0f TF)  best %.3f ms (%.0f TF)\n", name, C::LDS_BYTES / 1024, C::NT, md,
-         sum / reps, fl / (sum / reps * 1e-3) / 1e12, best, fl / (best * 1e-3) / 1e12);
+  double fl = 2.0 * c.T * (C::I8 ? 2.0 * c.d : c.d) * (double)c.N;
+  printf("%-28s lds=%3dKB thr=%3d  maxdiff=%.3e  mean %.3f ms (%.0f T%s)  best %.3f ms (%.0f)\n", name, C::LDS_BYTES / 1024, C::NT, md,
+         sum / reps, fl / (sum / reps * 1e-3) / 1e12, C::I8 ? "OP/s" : "FLOP/s", best, fl / (best * 1e-3) / 1e12);
   fflush(stdout);
 }
 
 int main(int argc, char **argv) {
-  Ctx c{}; c.T = 8192; c.d = 4096; c.N = 131072; c.Ns = 4096;
+  Ctx c{}; c.T = 8192; c.d = getenv("SWEEP_D") ? atoi(getenv("SWEEP_D")) : 4096; c.N = 131072; c.Ns = 4096;
+  printf("d = %d\n", c.d);
   int reps = argc > 1 ? atoi(argv[1]) : 5;
   CK(hipMalloc(&c.A, (size_t)c.T * c.d * 2)); CK(hipMalloc(&c.B, (size_t)c.N * c.d * 2));
   CK(hipMalloc(&c.tau, c.T * 4)); CK(hipMemset(c.tau, 0, c.T * 4));           // tau <= 0 -> nothing emitted
@@ -74,9 +80,8 @@ int main(int argc, char **argv) {
   ref_dense<<<dim3(c.Ns / 256, 512), 256>>>(c.A, c.B, 512, c.d, c.Ns, c.ref);
   CK(hipDeviceSynchronize());
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
-  RUN(256, 256, 64, 2, 2, 4);
-  run<GemmCfg<256, 256, 32, 4, 2, 4>, true>("PP 256,256,32,4,2,4", c, reps);
-  run<GemmCfg<256, 256, 32, 5, 2, 4>, true>("PP 256,256,32,5,2,4", c, reps);
-  RUN(256, 256, 32, 4, 2, 4);
+  RUN(256, 256, 2, 2, 4, false);
+  RUN(256, 256, 2, 2, 4, true);
+  RUN(128, 128, 2, 2, 2, false);
   return 0;
 }
