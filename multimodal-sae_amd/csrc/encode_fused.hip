@@ -428,7 +428,9 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const
     const bool have_k = done + has_set >= p.k;
     ok = (cnt <= p.cap) && (tau > 0.f) && have_k && (v_k > bound + eps);
     if (ok || done >= n || done >= p.r_max || !(tau > 0.f) || cnt > p.cap) break;
-    target = done + step;                         // extend the re-scored set; steps double
+    // extend the re-scored set; steps double.  (Measured: constant steps of 8 after a k+8 first
+    // round cost 2.2 ms instead of 1.55 ms -- round latency with few active lanes is not free.)
+    target = done + step;
     step *= 2;
     if (target > n) target = n;
     if (target > p.r_max) target = p.r_max;

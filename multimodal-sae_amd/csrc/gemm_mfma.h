@@ -70,7 +70,9 @@ struct GemmCfg {
   static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
   static constexpr int KS = 4;                   // MFMA k-steps per tile (32 B per lane-half each)
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int LDS_RING_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + 2 * NT * 4;   // + side buffer of epilogue constants
+  static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
   static constexpr int A_PIECES = A_BYTES / 1024;
   static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
@@ -181,40 +183,37 @@ __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const 
 template <class C, bool DENSE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
-                                              unsigned char *smem) {
+                                              unsigned char *smem, const float *side) {
   const int l31 = lane & 31, kh = lane >> 5;
   constexpr int QCAP = 8192;                           // 64 KiB of the (>= 128 KiB) ring
   unsigned *q_count = reinterpret_cast<unsigned *>(smem);
   unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // ring reads done everywhere; side[] written
   if constexpr (!DENSE) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // every wave has finished reading the ring
     if (threadIdx.x == 0) *q_count = 0u;
     __syncthreads();
   }
+  // side[tid]: tau of row tid | bias of column tid-BM;  side[NT+tid]: sx | sw
+  const float *row_tau = side, *row_sx = side + C::NT;
+  const float *col_bias = side + C::BM, *col_sw = side + C::NT + C::BM;
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
-    // per-lane row constants of this row block first (independent loads), then the compares
     float tau[16], rs[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      tau[e] = 0.f; rs[e] = 0.f;
-      if constexpr (!DENSE) {
-        const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
-        tau[e] = (v > 0.f) ? v : __builtin_inff();  // degenerate / padded token: emit nothing
-      }
-      if constexpr (C::I8) rs[e] = (t < T) ? ep.sx[t] : 0.f;
+      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      tau[e] = DENSE ? 0.f : row_tau[row];
+      rs[e] = C::I8 ? row_sx[row] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int col = wc * C::TN + j * 32 + l31;       // column inside the tile
       const int n = n0 + col;
       const int feat = n * ep.bias_stride + ep.bias_off;
-      const float bn = ep.bias ? ep.bias[feat] : 0.f;
-      float cs = 1.f;
-      if constexpr (C::I8) cs = ep.sw[feat];
+      const float bn = col_bias[col];
+      const float cs = C::I8 ? col_sw[col] : 1.f;
       const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -270,6 +269,28 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int l31 = lane & 31, kh = lane >> 5;
 
+  // Row / column constants of the epilogue: fetched NOW into two registers per thread, parked in
+  // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
+  //   threads [0, BM)      : tau (THRESH) and sx (int8) of row m0 + tid
+  //   threads [BM, BM+BN)  : bias and sw (int8) of column n0 + tid - BM
+  float side0 = 0.f, side1 = 0.f;
+  {
+    const int tid = threadIdx.x;
+    if (tid < C::BM) {
+      const int t = m0 + tid;
+      if constexpr (!DENSE) {
+        const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
+        side0 = (v > 0.f) ? v : __builtin_inff();     // degenerate / padded token: emit nothing
+      }
+      if constexpr (C::I8) side1 = (t < T) ? ep.sx[t] : 0.f;
+    } else if (tid < C::BM + C::BN) {
+      const int feat = (n0 + tid - C::BM) * ep.bias_stride + ep.bias_off;
+      side0 = ep.bias ? ep.bias[feat] : 0.f;
+      if constexpr (C::I8) side1 = ep.sw[feat];
+    }
+  }
+  const bool has_out = C::I8 && op.Ao != nullptr;
+
   f32x16 acc[C::MI][C::NI];
 #pragma unroll
   for (int i = 0; i < C::MI; ++i)
@@ -286,54 +307,58 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     for (int j = 0; j < C::NI; ++j) abl_b[j] = *reinterpret_cast<const i32x4 *>(op.B + (size_t)(n0 + j * 32 + l31) * op.ldB + kh * 16);
   }
 
-  if constexpr (C::I8) {
-    if (op.Ao) {
-      // leading outlier tile: its own staging round trip (1 of nk+1 tiles), then acc *= m[t]
-      gemm_stage<C>(op.Ao, 128, op.Bo, 128, m0, n0, Tp, N, 0, smem, 0, wave, lane);
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      gemm_compute<C>(acc, smem, smem + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
-#pragma unroll
-      for (int i = 0; i < C::MI; ++i) {
-        int ms[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          ms[e] = (t < T) ? op.mscale[t] : 1;
-        }
-#pragma unroll
-        for (int j = 0; j < C::NI; ++j) {
-          i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] *= ms[e];
-          acc[i][j] = __builtin_bit_cast(f32x16, v);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // every wave is done reading slot 0 before it is refilled
-    }
-  }
-
-  const int nk = op.nk;
+  // tile sequence: [outlier tile (int8, optional)] then the nk main k-tiles
+  const int lead = has_out ? 1 : 0;
+  const int ntiles = op.nk + lead;
+  auto stage = [&](int tile, int slot) {
+    if (tile < lead)
+      gemm_stage<C>(op.Ao, 128, op.Bo, 128, m0, n0, Tp, N, 0, smem, slot, wave, lane);
+    else
+      gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, lane);
+  };
 #pragma unroll
   for (int s = 0; s < C::STAGES - 1; ++s)
-    if (s < nk) gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)s * C::ROWB, smem, s, wave, lane);
+    if (s < ntiles) stage(s, s);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    // k-tile kt has landed once at most STAGES-2 younger groups of this wave are outstanding
-    if (kt + C::STAGES - 2 < nk) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
+  auto iteration = [&](int kt) {
+    // tile kt has landed once at most STAGES-2 younger groups of this wave are outstanding
+    if (kt + C::STAGES - 2 < ntiles) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // all waves' pieces of kt landed; slot of kt-1 is free again
     const int nkt = kt + C::STAGES - 1;
     if constexpr (!C::ABL_NOSTAGE) {
-      if (nkt < nk)
-        gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)nkt * C::ROWB, smem,
-                      nkt % C::STAGES, wave, lane);
+      if (nkt < ntiles) stage(nkt, nkt % C::STAGES);
     }
     const unsigned char *sA = smem + (kt % C::STAGES) * C::STAGE_BYTES;
     gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+  };
+  int kt0 = 0;
+  if constexpr (C::I8) {
+    if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
+      iteration(0);
+      kt0 = 1;
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          const int m = (t < T) ? op.mscale[t] : 1;
+#pragma unroll
+          for (int j = 0; j < C::NI; ++j) {
+            i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
+            v[e] *= m;
+            acc[i][j] = __builtin_bit_cast(f32x16, v);
+          }
+        }
+    }
   }
-  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem);
+  for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
+
+  // park the epilogue constants in LDS (side buffer behind the ring)
+  float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
+  side[threadIdx.x] = side0;
+  side[C::NT + threadIdx.x] = side1;
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
 }
 
 // Host launcher.  Requires Tp % BM == 0 and N % BN == 0 (checked by the caller's plan).

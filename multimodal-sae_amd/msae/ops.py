@@ -25,13 +25,15 @@ _WS: dict = {}
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Tensor:
-    """Grow-only per-device scratch buffer (uint8, 256-B aligned by the caching allocator)."""
-    ws = _WS.get(dev)
+    """Grow-only scratch buffer per (device, stream) -- calls enqueued on different streams may run
+    concurrently and must not share scratch (uint8, 256-B aligned by the caching allocator)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
-            del _WS[dev]
+            del _WS[key]
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _WS[dev] = ws
+        _WS[key] = ws
     return ws
 
 
