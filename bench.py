@@ -37,6 +37,7 @@ import torch.distributed as dist
 
 D_MODEL, WIDTH = 4096, 131072
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_I8_TOPS = 5000.0       # dense int8 MFMA = 2x the bf16 rate (guide: i8 "~2x bf16", ubench >= 4404)
 PEAK_HBM_GBS = 8000.0
 STAGES = ["prep", "sample_gemm", "threshold_topk", "main_gemm", "select_rescore", "exact_fallback"]
 
@@ -106,6 +107,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=8192, help="tokens per step (whole job)")
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-feature-sharded", action="store_true",
+                    help="N > 1: skip the second (feature-sharded, RCCL merge) measurement")
     ap.add_argument("--cpu-sample", type=int, default=256)
     args = ap.parse_args()
 
@@ -126,87 +129,108 @@ def main():
 
     lib = _hip.load()
     T, d, N, k = args.tokens, D_MODEL, WIDTH, args.k
-    n_loc = N // world
-    W_enc, b_enc, W_dec_shard, b_dec, x = make_inputs(dev, T, d, N, rows=(rank * n_loc, (rank + 1) * n_loc))
-    if world > 1:
-        # decode is token-sharded with a replicated W_dec (2 GiB of 288 GB)
-        _, _, W_dec, _, _ = make_inputs(dev, 1, d, N)
-    else:
-        W_dec = W_dec_shard
-    del W_dec_shard
-    engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world,
-                        group=dist.group.WORLD if ddp else None,
-                        force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
+    # ---- headline: tokens are independent units -> every rank runs the full SAE on ITS OWN batch of
+    # T tokens (the reference's own multi-GPU mode, launch/cache/cache.py:66), no data-path collective
+    W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=rank)
+    engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
 
-    def step():
-        # streaming loop: the reconstruction all-gather of step i overlaps the encode of step i+1
-        return engine.forward(x, async_gather=ddp)
+    def timed(eng, xin, steps, warmup, profile):
+        for _ in range(warmup):
+            eng.forward(xin, async_gather=eng.collective)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(steps)]
+        if profile:   # stage events are recorded on the launch stream during the timed region
+            lib.msae_profile_begin(steps)
+            eng.decode_events, eng.decode_event_i = dec_ev, 0
+        if ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = eng.forward(xin, async_gather=eng.collective)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if ddp:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        stage, dec_ms = np.zeros((0, 6)), float("nan")
+        if profile:
+            buf = (ctypes.c_float * (steps * 6))()
+            n_steps = ctypes.c_int(0)
+            lib.msae_profile_end(buf, ctypes.byref(n_steps))
+            stage = np.array(buf[:]).reshape(steps, 6)[: n_steps.value]
+            if eng.decode_event_i:
+                dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev[: eng.decode_event_i]]))
+            eng.decode_events = None
+        if ddp:
+            tmax = torch.tensor([el], device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, out, stage, dec_ms
 
-    for _ in range(args.warmup):
-        step()
-    engine.synchronize()
-    torch.cuda.synchronize()
+    elapsed, out, stage, dec_ms = timed(engine, x, args.steps, args.warmup, profile=True)
 
-    # stage events are recorded on the launch stream during the timed region
-    lib.msae_profile_begin(args.steps)
-    dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-    engine.decode_events = dec_ev
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    engine.synchronize()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    stage_ms = (ctypes.c_float * (args.steps * 6))()
-    n_steps = ctypes.c_int(0)
-    lib.msae_profile_end(stage_ms, ctypes.byref(n_steps))
-    stage = np.array(stage_ms[:]).reshape(args.steps, 6)[: n_steps.value]
-    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev[: engine.decode_event_i]])) \
-        if engine.decode_event_i else float("nan")
-    engine.decode_events = None
-
-    if ddp:
-        tmax = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- second result (N > 1): the north-star's feature-sharded engine on ONE replicated batch --
+    # per-shard encode + TopK, RCCL all-gather + merge, token-sharded decode + all-gather (strong scaling)
+    feature = None
+    if ddp and (world > 1 or os.environ.get("MSAE_FORCE_COLLECTIVES") == "1") and not args.no_feature_sharded:
+        n_loc = N // world
+        _, _, _, _, x0 = make_inputs(dev, T, d, 8192, seed=0)       # the same tokens on every rank
+        lo, hi = rank * n_loc, (rank + 1) * n_loc
+        eng_f = ShardedSae(W_enc[lo:hi], b_enc[lo:hi], W_dec, b_dec, k, rank=rank, world=world,
+                           group=dist.group.WORLD,
+                           force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
+        el_f, out_f, _, _ = timed(eng_f, x0, args.steps, args.warmup, profile=False)
+        feature = {"value": T * args.steps / el_f, "unit": "tokens/s", "ms_per_step": el_f / args.steps * 1e3,
+                   "scaling": "strong", "tokens_per_step": T, "k_loc": eng_f.k_loc,
+                   "second_round_tokens": eng_f.second_round_tokens,
+                   "parallelism": f"feature-sharded x{world}: per-shard exact top-k_loc, RCCL all-gather + merge, "
+                                  "token-sharded decode + all-gather of the reconstruction"}
+        del eng_f
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = T * args.steps / elapsed
+        value = world * T * args.steps / elapsed
+        n_loc = N
         res = {
             "metric": "tokens/sec through SAE encode+TopK+decode, d=4096 width=131072",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)"
+                     if os.environ.get("MSAE_COARSE", "int8")[0] != "b" else
+                     "bf16 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: d_model=4096 width=131072 k=%d, T=%d bf16 "
                                    "activations/step resident in HBM, random-init unit-norm f32 weights"
                                    % (k, T),
-                       "tokens_per_step": T, "k": k,
-                       "parallelism": "single GPU" if world == 1 else f"feature-sharded x{world} (RCCL all-gather merge)"},
+                       "tokens_per_step": T * world, "k": k,
+                       "parallelism": "single GPU" if world == 1 else
+                       f"dp{world}: token-sharded replicas, {T} tokens/step/GPU, no data-path collective"},
         }
         if len(stage):
             mean = stage.mean(0)
             t_gemm = float(mean[3]) * 1e-3
             flops = 2.0 * T * d * n_loc
             ach = flops / t_gemm / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<THRESH>", "achieved": ach,
-                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                               "traffic": load_traffic("gemm_bf16_kernel"), "launch_ms": float(mean[3])}
+            i8 = os.environ.get("MSAE_COARSE", "int8")[0] != "b"
+            peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
+            kname = "gemm_kernel<int8,THRESH>" if i8 else "gemm_kernel<bf16,THRESH>"
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak,
+                               "ops": "2*T*d*N multiply-adds counted as 2 ops each (int8 MACs on the int8 path)",
+                               "traffic": load_traffic(kname), "launch_ms": float(mean[3])}
             res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
             res["stage_ms"]["decode"] = dec_ms
-            bytes_dec = (T // world) * (k * d * 4 + k * 8 + d * 4)
+            bytes_dec = T * (k * d * 4 + k * 8 + d * 4)
             res["decode_hbm"] = {"achieved": bytes_dec / (dec_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": bytes_dec / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             st = out["status"]
             res["fast_path_verified_frac"] = float((st == 0).float().mean().item())
+        if feature is not None:
+            res["feature_sharded"] = feature
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
         print(json.dumps(res))

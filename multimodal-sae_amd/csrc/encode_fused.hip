@@ -517,6 +517,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // tau = r-th largest of the 1/32 sample: ~32*r survivors, Gamma(r)-distributed.  r = 16 keeps
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
     p.r = k / 2 > 16 ? k / 2 : 16;
+    if (const char *e = getenv("MSAE_TUNE_R")) p.r = atoi(e);   // tuning hook
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
     p.step = k / 8 > 8 ? k / 8 : 8;
