@@ -338,11 +338,12 @@ struct RescoreArgs {
 };
 
 // Wave-wide bitonic sort (descending) of n = power-of-two u64 keys in LDS by ONE 64-lane wave.
+template <int NT>
 __device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n, int lane) {
   for (int size = 2; size <= n; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       __syncthreads();
-      for (int i = lane; i < (n >> 1); i += 64) {
+      for (int i = lane; i < (n >> 1); i += NT) {
         const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
         const bool desc = ((lo & size) == 0);
         const unsigned long long x = s[lo], y = s[hi];
@@ -364,13 +365,15 @@ __device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n,
 //     v_k(exact) > max(best not-yet-rescored coarse, tau) + eps,   eps = 4 * max|coarse - exact|
 // does not hold and candidates remain, the next `step` (doubling) are re-scored too, up to `r_max`.  Tokens
 // that still fail (or overflowed their list / have tau <= 0) go to the exact path.
-__global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
+template <int NW>   // waves per token: 1 for k <= 64, 4 for larger k (longer lists, more rows per round)
+__global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
   const int nrp = next_pow2(p.r_max + 1);
   unsigned long long *res = keys + p.cap;
-  const int lane = threadIdx.x;
+  constexpr int NT = 64 * NW;
+  const int lane = threadIdx.x;   // thread index within the token's workgroup
   const int t = blockIdx.x;
   const int cnt = p.cnt[t];
   const int n = cnt < p.cap ? cnt : p.cap;
@@ -378,9 +381,9 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const
   const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
 
   const int np = next_pow2(n > 2 ? n : 2);
-  for (int i = lane; i < np; i += 64) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
-  for (int i = lane; i < nrp; i += 64) res[i] = 0ull;
-  wave_sort_desc_u64(keys, np, lane);   // coarse value desc (index asc on ties)
+  for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
+  wave_sort_desc_u64<NT>(keys, np, lane);   // coarse value desc (index asc on ties)
   const int has_set = p.set_feature >= 0 ? 1 : 0;
   if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
 
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const
   int target = n < p.n_rescore ? n : p.n_rescore;
   bool ok = false;
   for (;;) {
-    for (int c0 = done; c0 < target; c0 += 64) {
+    for (int c0 = done; c0 < target; c0 += NT) {
       const int c = c0 + lane;
       const bool active = c < target;
       const unsigned long long key = active ? keys[c] : keys[c0];
@@ -420,7 +423,16 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const
     float maxerr = my_err;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxerr = fmaxf(maxerr, __shfl_xor(maxerr, off, 64));
-    wave_sort_desc_u64(res, nrp, lane);
+    if constexpr (NW > 1) {   // combine the waves' maxima through LDS (behind res[])
+      float *werr = reinterpret_cast<float *>(res + nrp);
+      __syncthreads();
+      if ((lane & 63) == 0) werr[lane >> 6] = maxerr;
+      __syncthreads();
+      maxerr = werr[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) maxerr = fmaxf(maxerr, werr[w]);
+    }
+    wave_sort_desc_u64<NT>(res, nrp, lane);
     const float eps = 4.f * maxerr + 1e-30f;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
     float bound = tau;
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(64) void select_rescore_kernel(RescoreArgs p, const
     __syncthreads();
   }
 
-  for (int j = lane; j < p.k; j += 64) {
+  for (int j = lane; j < p.k; j += NT) {
     const unsigned long long key = res[j];
     p.idx[(size_t)t * p.k + j] = key ? rank_key_index(key) : 0;
     p.vals[(size_t)t * p.k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
@@ -516,7 +528,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.S = N / SAMPLE_STRIDE;
     // tau = r-th largest of the 1/32 sample: ~32*r survivors, Gamma(r)-distributed.  r = 16 keeps
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
-    p.r = k / 2 > 16 ? k / 2 : 16;
+    p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
     if (const char *e = getenv("MSAE_TUNE_R")) p.r = atoi(e);   // tuning hook
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
@@ -527,7 +539,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // rounds extend the re-scored set (step doubling) up to here; once every listed candidate is
     // re-scored the bound falls back to tau, which sits ~8k ranks below v_k, so reaching r_max with
     // the band still violated is practically impossible and the exact fallback stays idle
-    p.r_max = 8 * k;
+    p.r_max = k <= 64 ? 8 * k : 3 * k;
     if (p.r_max > p.cap) p.r_max = p.cap;
     if (p.i8) {
       p.off_xq = take((size_t)p.Tp * d);
@@ -663,10 +675,16 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     const int nrp = next_pow2(pl.r_max + 1);
-    const size_t smem = ((size_t)pl.cap + nrp) * 8;
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(select_rescore_kernel, dim3(T), dim3(64), smem, s, ra, (const float *)a32, W_enc);
+    const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
+    if (k <= 64) {
+      MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<1>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(select_rescore_kernel<1>, dim3(T), dim3(64), smem, s, ra, (const float *)a32, W_enc);
+    } else {
+      MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<4>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(select_rescore_kernel<4>, dim3(T), dim3(256), smem, s, ra, (const float *)a32, W_enc);
+    }
   }
   prof_mark(5, s);
   // exact recompute of flagged tokens (device-side count; empty grids exit immediately)
