@@ -535,3 +535,27 @@ def test_train_step_matches_reference_adam_step(dev, golden_dir):
     fired = torch.zeros(sae.num_latents, dtype=torch.bool)
     fired[torch.from_numpy(g["step_fired"])] = True
     assert torch.equal(ts.num_tokens_since_fired.cpu() == 0, fired)
+
+
+def test_batched_grad_times_act_attribution(dev, golden_dir):
+    """score[t,j] = act * <grad, W_dec[idx]> for every active feature from one backward == the
+    reference's per-feature quantity (clean - corrupted).grad summed over d, with corrupted = the
+    reconstruction with that one latent zeroed (features/patching/attribution.py:174-182)."""
+    from msae.features import feature_scores, grad_times_act
+
+    g = np.load(golden_dir / "g5_hooks.npz")
+    sae = _golden_sae(dev, g)
+    x = _t(g["attr_x"], dev).flatten(0, 1).float()
+    top = sae.encode(x)
+    grad = torch.randn(x.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+    scores = grad_times_act(sae, top.top_acts, top.top_indices, grad)
+    clean = sae.decode(top.top_acts, top.top_indices)
+    for t, j in ((0, 0), (2, 3), (5, 7)):
+        acts = top.top_acts.clone()
+        acts[t, j] = 0.0                                    # "off_features" for this (token, feature)
+        corrupted = sae.decode(acts, top.top_indices)
+        ref = ((clean - corrupted) * grad).sum(-1)[t]
+        assert abs(scores[t, j].item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+    feats, total = feature_scores(sae, top.top_acts, top.top_indices, grad)
+    dense = torch.zeros(sae.num_latents, device=dev).index_add_(0, top.top_indices.reshape(-1), scores.reshape(-1))
+    assert torch.allclose(total, dense[feats])
