@@ -195,3 +195,34 @@ def test_load_filter_and_load_saes_local(tmp_path):
     only = load_saes(str(tmp_path), filters=filt, device="cpu")
     assert list(only) == ["model.layers.10"] and only["model.layers.10"].num_latents == 32
     assert load_single_sae(str(tmp_path), "model.layers.2", device="cpu").d_in == 8
+
+
+def test_cache_files_round_trip_through_the_reader_rule(golden_dir, tmp_path):
+    """Files written by save_splits/concate_safetensors are found and decoded by the restated
+    FeatureDataset / TensorBuffer rule (features/loader.py:74-90,143-196)."""
+    from msae.features import FeatureDataset, split_path
+    from msae.features import cache as C
+
+    g = np.load(golden_dir / "g4_cache.npz")
+    module, width = "model.layers.24", int(g["N"])
+    loc = torch.from_numpy(g["nofilter_locations"])
+    act = torch.from_numpy(g["nofilter_activations"])
+    fc = C.FeatureCache.__new__(C.FeatureCache)
+    fc.width = width
+    fc.cache = C.Cache(shard_size=0)
+    fc.cache.feature_locations[module], fc.cache.feature_activations[module] = loc, act
+    fc.save_splits(4, str(tmp_path), rank=0, include_split_end=True)
+    fc.concate_safetensors(4, str(tmp_path))
+    ds = FeatureDataset(str(tmp_path), width, 4)
+    assert len(ds) == 4
+    seen = 0
+    for rec in ds:
+        mask = loc[:, 2] == rec.feature
+        assert torch.equal(rec.locations, loc[mask][:, :2]) and torch.equal(rec.activations, act[mask])
+        assert split_path(str(tmp_path), module, width, 4, rec.feature).endswith(
+            f"{rec.feature // 16 * 16}_{rec.feature // 16 * 16 + 15}.safetensors")
+        seen += len(rec.activations)
+    assert seen == len(act)
+    sel = {module: torch.tensor([int(loc[0, 2]), int(loc[-1, 2])])}
+    got = {r.feature for r in FeatureDataset(str(tmp_path), width, 4, modules=[module], features=sel)}
+    assert got == set(sel[module].tolist())
