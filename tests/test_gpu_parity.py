@@ -559,3 +559,32 @@ def test_batched_grad_times_act_attribution(dev, golden_dir):
     feats, total = feature_scores(sae, top.top_acts, top.top_indices, grad)
     dense = torch.zeros(sae.num_latents, device=dev).index_add_(0, top.top_indices.reshape(-1), scores.reshape(-1))
     assert torch.allclose(total, dense[feats])
+
+
+@pytest.mark.parametrize("kind", ["bos_token", "many_outlier_dims", "heavy_tails", "constant_rows"])
+def test_fused_encode_hostile_activation_statistics(dev, coarse, kind):
+    """Activation statistics that stress the int8 quantisation (a massive-norm BOS-like token, more
+    outlier dims than the outlier tile holds, heavy tails, degenerate rows).  Whatever the coarse
+    pass does, the outputs must equal the exact path bit for bit and no token may stay unresolved."""
+    from msae import ops
+
+    d, N, T, k = 1024, 8192, 512, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 21)
+    g = torch.Generator(device=dev).manual_seed(22)
+    x = torch.randn(T, d, generator=g, device=dev)
+    if kind == "bos_token":
+        x[0] *= 150.0
+        x[:, 7] *= 40.0
+    elif kind == "many_outlier_dims":
+        x[:, torch.randperm(d, generator=torch.Generator().manual_seed(1))[:200].to(dev)] *= 12.0
+    elif kind == "heavy_tails":
+        x = x * torch.exp(1.5 * torch.randn(T, d, generator=g, device=dev))
+    elif kind == "constant_rows":
+        x[:64] = 0.0
+        x[64:128] = 1.0
+    x = x.to(torch.bfloat16)
+    prepared = ops.prepare_encoder(W_enc)
+    v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)
+    ev, ei = ops.topk(ops.pre_acts(x, W_enc, b_enc, b_dec), k)
+    assert (status < 2).all(), f"{(status >= 2).sum().item()} unresolved tokens"
+    assert torch.equal(i, ei) and torch.equal(v, ev)
