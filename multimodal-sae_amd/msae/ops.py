@@ -280,16 +280,25 @@ class _SparseEncode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi):
-        pre = pre_acts(x, W_enc, b_enc, b_dec)
         vals, idxs = [], []
-        v, i = topk(pre, k)
-        vals.append(v); idxs.append(i)
-        if k_aux > 0:
-            v, i = topk(torch.where(dead_mask[None], pre, -torch.inf), k_aux)  # sae.py:217-220
+        if k_aux == 0 and max(k, k_multi) <= 256:
+            # no AuxK term: the fused encoder gives the canonical top-max(k, 4k); the top-k is its
+            # prefix (same order), and the dense [T, N] latents are never built
+            kk = max(k, k_multi)
+            v, i, _ = encode_topk(x, W_enc, b_enc, b_dec, prepare_encoder(W_enc), kk)
+            vals.append(v[..., :k].contiguous()); idxs.append(i[..., :k].contiguous())
+            if k_multi > 0:
+                vals.append(v); idxs.append(i)
+        else:
+            pre = pre_acts(x, W_enc, b_enc, b_dec)
+            v, i = topk(pre, k)
             vals.append(v); idxs.append(i)
-        if k_multi > 0:
-            v, i = topk(pre, k_multi)                                           # sae.py:233
-            vals.append(v); idxs.append(i)
+            if k_aux > 0:
+                v, i = topk(torch.where(dead_mask[None], pre, -torch.inf), k_aux)  # sae.py:217-220
+                vals.append(v); idxs.append(i)
+            if k_multi > 0:
+                v, i = topk(pre, k_multi)                                           # sae.py:233
+                vals.append(v); idxs.append(i)
         ctx.save_for_backward(x, W_enc, b_dec, torch.cat(idxs, -1), torch.cat(vals, -1))
         ctx.splits = [t.shape[-1] for t in vals]
         ctx.has_b_enc = b_enc is not None

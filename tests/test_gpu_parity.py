@@ -588,3 +588,22 @@ def test_fused_encode_hostile_activation_statistics(dev, coarse, kind):
     ev, ei = ops.topk(ops.pre_acts(x, W_enc, b_enc, b_dec), k)
     assert (status < 2).all(), f"{(status >= 2).sum().item()} unresolved tokens"
     assert torch.equal(i, ei) and torch.equal(v, ev)
+
+
+def test_training_forward_fused_path_equals_dense_path(dev):
+    """Without an AuxK term Sae.forward encodes through the fused kernel; selections, losses and
+    gradients must equal the dense path's (same indices, same values -> same sparse backward)."""
+    from msae import Sae, SaeConfig, ops
+
+    d, N, k, T = 256, 8192, 16, 300
+    sae = Sae(d, SaeConfig(num_latents=N, k=k, multi_topk=True), device=dev)
+    x = _rand_x(dev, T, d, 33).float()
+    fused = ops.sparse_encode(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec, k, None, 0, 4 * k)
+    pre = ops.pre_acts(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec)
+    for (v, i), kk in zip(fused, (k, 4 * k)):
+        ev, ei = ops.topk(pre, kk)
+        assert torch.equal(i, ei) and torch.equal(v, ev)
+    out = sae(x)                       # dead_mask None -> fused path
+    (out.fvu + out.multi_topk_fvu / 8).backward()
+    assert sae.encoder.weight.grad is not None and torch.isfinite(sae.encoder.weight.grad).all()
+    assert int((sae.encoder.weight.grad.abs().sum(1) > 0).sum()) > 0

@@ -81,7 +81,10 @@ int main(int argc, char **argv) {
   CK(hipDeviceSynchronize());
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
   RUN(256, 256, 2, 2, 4, false);
+  RUN(256, 256, 2, 2, 4, false, 24);   // staging only, 8 waves
+  RUN(256, 256, 2, 4, 4, false);       // 16 waves, 64x64 per wave
+  RUN(256, 256, 2, 4, 4, false, 24);   // staging only, 16 waves
+  RUN(256, 256, 2, 4, 4, true);        // int8, 16 waves
   RUN(256, 256, 2, 2, 4, true);
-  RUN(128, 128, 2, 2, 2, false);
   return 0;
 }
