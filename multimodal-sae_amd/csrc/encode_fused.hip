@@ -1,28 +1,30 @@
-// encode_fused.hip -- fused Sae.encode: bf16 MFMA candidate pass + exact f32 re-score + TopK.
+// encode_fused.hip -- fused Sae.encode: MFMA candidate pass (int8 or bf16) + exact f32 re-score + TopK.
 //
 // Replaces Sae.encode = select_topk(pre_acts(x)) (reference sae/sae.py:172-185) without ever
 // writing the dense [T][N] latents (512 KiB/token at N = 131072) to HBM.
 //
 // Pipeline per call (all on one stream, no host synchronisation):
-//   1. prep_x        xb[T][d] = bf16(x - b_dec)                           (HBM, tiny)
+//   1. prep_x        a32[T][d] = f32(x) - b_dec  (the exact SAE input)
+//      int8 pass:    column max over the batch -> outlier dims -> per-token scale sx[t], int8 rows xq,
+//                    outlier dims in their own 128-wide k-tile at scale m[t]*sx[t]; the matching
+//                    columns of Wq are gathered into an outlier tile.  (bf16 pass: xb = bf16(a32).)
 //   2. gemm<DENSE>   coarse pre-acts of a 1/32 strided SAMPLE of the features -> [T][S] f32
-//   3. topk (r-th)   tau[t] = r-th largest sample value: expected ~32*r features of the full
-//                    width exceed tau[t]
-//   4. gemm<THRESH>  THE DOMINANT KERNEL.  [T][d] x [d][N] on v_mfma_f32_32x32x16_bf16, LDS tiles
-//                    filled by global_load_lds (16 B/lane), XOR-swizzled, double-buffered;
-//                    epilogue: +b_enc, compare with tau[t], append (feature, coarse) of the rare
-//                    survivors to a per-token candidate list.  Roofline: bf16 MFMA, 2*d*N FLOP
-//                    per token; HBM traffic is the weights once per 8 token tiles.
+//   3. kth value     tau[t] = r-th largest sample value: ~32*r features of the full width exceed it
+//   4. gemm<THRESH>  THE DOMINANT KERNEL (gemm_mfma.h): [T][d] x [d][N] on the matrix cores;
+//                    epilogue: scales, +b_enc, compare with tau[t], append (feature, coarse) of the
+//                    rare survivors to a per-token candidate list.  Roofline: MFMA, 2*d*N op/token.
 //   5. select_rescore per token: order candidates by coarse value, re-score the best k+extra with
 //                    the exact ascending-k f32 fma chain over the f32 W_enc rows, take the
 //                    canonical top-k, and verify the guard band
-//                        v_k(exact) > max(best non-rescored coarse, tau) + eps_t.
-//                    Tokens that fail (or overflowed / had tau <= 0) are flagged.
+//                        v_k(exact) > max(best non-rescored coarse, tau) + eps_t,
+//                    eps_t = 4 * max|coarse - exact| measured on the re-scored set, extending the
+//                    set (16, 32, 64 ... more) while it fails.  Tokens that still fail (or
+//                    overflowed / had tau <= 0) are flagged.
 //   6. exact path    flagged tokens (normally none) are recomputed by encode_f32 + topk through a
 //                    device-side row list; their results overwrite step 5's.
 //
 // Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the guard
-// band holds, and ARE that path's outputs when it does not.
+// band holds, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
 #include <cstdlib>
 
 #include "common.h"
@@ -529,7 +531,6 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // tau = r-th largest of the 1/32 sample: ~32*r survivors, Gamma(r)-distributed.  r = 16 keeps
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
     p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
-    if (const char *e = getenv("MSAE_TUNE_R")) p.r = atoi(e);   // tuning hook
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
     p.step = k / 8 > 8 ? k / 8 : 8;
