@@ -114,10 +114,14 @@ int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec, c
 int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const float *W_dec, int A,
                              int k, int N, int d, float *g_acts, void *stream);
 
-/* g_W_dec[idx[a][j]][:] += acts[a][j] * grad_out[a][:]  accumulated into a dense, caller-zeroed
- * [N][d] buffer (the layout autograd expects for Sae.W_dec.grad). */
+/* g_W_dec[n][:] = sum over (a, j) with idx[a][j] == n of acts[a][j] * grad_out[a][:], written to
+ * the WHOLE dense [N][d] buffer (the layout autograd expects for Sae.W_dec.grad; rows without a
+ * pair are zero; no pre-zeroing needed).  Pairs are grouped by feature with a counting sort and
+ * summed in ascending pair order, so the result is bit-reproducible.  d % 4 == 0. */
+size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N);
 int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
-                             int k, int N, int d, float *g_W_dec, void *stream);
+                             int k, int N, int d, float *g_W_dec, void *ws, size_t ws_bytes,
+                             void *stream);
 
 /* ---- feature-cache sparsify ------------------------------------------------------------------
  * From the per-token top-k (vals/idx[B*S][k], any order) produce the reference cache's COO

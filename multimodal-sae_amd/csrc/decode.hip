@@ -131,19 +131,113 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
   if (lane == 0) g_acts[pair] = acc;
 }
 
-// g_W_dec[idx[a][j]][:] += acts[a][j] * grad_out[a][:]      (kernels.py:10-175)
-// grid: (A*k, ceil(d/256)); hardware f32 atomics (rows touched by several tokens collide).
-__global__ __launch_bounds__(256) void decode_bwd_wdec_kernel(
-    const int32_t *__restrict__ idx, const float *__restrict__ acts,
-    const float *__restrict__ grad_out, int k, int N, int d, float *__restrict__ g_W) {
-  const long pair = blockIdx.x;
-  const int a = (int)(pair / k);
-  const int col = blockIdx.y * 256 + threadIdx.x;
-  if (col >= d) return;
-  const int i = idx[pair];
-  const float v = acts[pair];
-  if ((unsigned)i >= (unsigned)N || v == 0.f) return;
-  unsafeAtomicAdd(g_W + (size_t)i * d + col, v * grad_out[(size_t)a * d + col]);
+// ---- g_W[n][:] = sum over pairs (a, j) with idx[a][j] == n of acts[a][j] * grad_out[a][:] -------------
+// Replaces triton_sparse_transpose_dense_matmul (kernels.py:10-175: torch.sort of the A*k indices,
+// a 2-GiB zeros() and run-length tl.atomic_add).  Here: counting sort of the pairs by feature
+// (histogram -> exclusive scan -> fill), then ONE wave per feature row accumulates its pairs in
+// registers in ascending pair order and writes the row once -- no atomics on the 2-GiB gradient,
+// no zero-fill (rows without pairs are written as zeros), and a fixed summation order (for rows
+// with at most 64 pairs), so the weight gradients are reproducible run to run.  HBM-bound: N*d*4 B written + (A*k)*d*4 B of grad_out
+// rows read (mostly L2 / Infinity-Cache hits: grad_out is A*d*4 B).
+__global__ __launch_bounds__(256) void wgrad_count_kernel(const int32_t *__restrict__ idx,
+                                                          const float *__restrict__ acts, long pairs,
+                                                          int N, int *__restrict__ counts) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const int i = idx[p];
+  if ((unsigned)i < (unsigned)N && acts[p] != 0.f) atomicAdd(counts + i, 1);
+}
+
+// single workgroup: offsets[n] = exclusive prefix of counts; cursor = copy; offsets[N] = total
+__global__ __launch_bounds__(1024) void wgrad_scan_kernel(const int *__restrict__ counts, int N,
+                                                          int *__restrict__ offsets,
+                                                          int *__restrict__ cursor) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < N ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wave_tot[w];
+    if (i < N) { offsets[i] = pre + incl - v; cursor[i] = pre + incl - v; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[N] = carry;
+}
+
+__global__ __launch_bounds__(256) void wgrad_fill_kernel(const int32_t *__restrict__ idx,
+                                                         const float *__restrict__ acts, long pairs,
+                                                         int N, int *__restrict__ cursor,
+                                                         int *__restrict__ perm) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const int i = idx[p];
+  if ((unsigned)i < (unsigned)N && acts[p] != 0.f) perm[atomicAdd(cursor + i, 1)] = (int)p;
+}
+
+// one wave per feature row n; lane owns float4 columns lane, lane+64, ... ; d % 4 == 0
+__global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restrict__ acts,
+                                                          const float *__restrict__ grad_out,
+                                                          const int *__restrict__ offsets,
+                                                          int *__restrict__ perm, int k, int N, int d,
+                                                          float *__restrict__ g_W) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int beg = offsets[n], end = offsets[n + 1];
+  // deterministic order: sort the segment by pair id -- lane 0, in place, insertion sort.  Rows hit
+  // by more than 64 pairs (very dense features) keep the fill order: their sum order may vary.
+  if (lane == 0 && end - beg > 1 && end - beg <= 64) {
+    for (int a = beg + 1; a < end; ++a) {
+      const int key = perm[a];
+      int b = a - 1;
+      while (b >= beg && perm[b] > key) { perm[b + 1] = perm[b]; --b; }
+      perm[b + 1] = key;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int c0 = lane * 4; c0 < d; c0 += 256 * 4) {     // 4 column chunks in flight per pass
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = beg; e < end; ++e) {
+      const int p = perm[e];
+      const float v = acts[p];
+      const float *g = grad_out + (size_t)(p / k) * d;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 256;
+        if (c < d) {
+          const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c);
+          acc[u][0] = __builtin_fmaf(v, gv[0], acc[u][0]); acc[u][1] = __builtin_fmaf(v, gv[1], acc[u][1]);
+          acc[u][2] = __builtin_fmaf(v, gv[2], acc[u][2]); acc[u][3] = __builtin_fmaf(v, gv[3], acc[u][3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * 256;
+      if (c < d) *reinterpret_cast<f32x4 *>(g_W + (size_t)n * d + c) = acc[u];
+    }
+  }
+}
+
+__global__ void wgrad_zero_kernel(int *p, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0;
 }
 
 }  // namespace
@@ -180,13 +274,34 @@ extern "C" int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_ou
   return msae_launch_status();
 }
 
+extern "C" size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N) {
+  if (A < 0 || k <= 0 || N <= 0) return 0;
+  return msae_align_up((size_t)(N + 1) * 4, 256) * 3 + msae_align_up((size_t)A * k * 4, 256);
+}
+
 extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
                                         const float *grad_out, int A, int k, int N, int d,
-                                        float *g_W_dec, void *stream) {
-  if (A < 0 || k <= 0 || N <= 0 || d <= 0) return MSAE_EINVAL;
-  if (A == 0) return 0;
-  dim3 grid((unsigned)((long)A * k), (d + 255) / 256);
-  hipLaunchKernelGGL(decode_bwd_wdec_kernel, grid, dim3(256), 0, (hipStream_t)stream, idx, acts,
-                     grad_out, k, N, d, g_W_dec);
+                                        float *g_W_dec, void *ws, size_t ws_bytes, void *stream) {
+  if (A < 0 || k <= 0 || N <= 0 || d <= 0 || d % 4 != 0) return MSAE_EINVAL;
+  if (!ws || ws_bytes < msae_decode_bwd_wdec_ws_bytes(A, k, N)) return MSAE_EWS;
+  if (!msae_aligned(grad_out, 16) || !msae_aligned(g_W_dec, 16) || !msae_aligned(ws, 256)) return MSAE_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t seg = msae_align_up((size_t)(N + 1) * 4, 256);
+  int *counts = reinterpret_cast<int *>(ws);
+  int *offsets = reinterpret_cast<int *>(static_cast<unsigned char *>(ws) + seg);
+  int *cursor = reinterpret_cast<int *>(static_cast<unsigned char *>(ws) + 2 * seg);
+  int *perm = reinterpret_cast<int *>(static_cast<unsigned char *>(ws) + 3 * seg);
+  const long pairs = (long)A * k;
+  hipLaunchKernelGGL(wgrad_zero_kernel, dim3(256), dim3(256), 0, s, counts, N + 1);
+  if (pairs > 0) {
+    const unsigned pb = (unsigned)((pairs + 255) / 256);
+    hipLaunchKernelGGL(wgrad_count_kernel, dim3(pb), dim3(256), 0, s, idx, acts, pairs, N, counts);
+    hipLaunchKernelGGL(wgrad_scan_kernel, dim3(1), dim3(1024), 0, s, counts, N, offsets, cursor);
+    hipLaunchKernelGGL(wgrad_fill_kernel, dim3(pb), dim3(256), 0, s, idx, acts, pairs, N, cursor, perm);
+  } else {
+    hipLaunchKernelGGL(wgrad_zero_kernel, dim3(256), dim3(256), 0, s, offsets, N + 1);
+  }
+  hipLaunchKernelGGL(wgrad_accum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, acts, grad_out, offsets, perm,
+                     k, N, d, g_W_dec);
   return msae_launch_status();
 }

@@ -38,8 +38,9 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p]),
     "msae_decode_bwd_acts_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p]),
+    "msae_decode_bwd_wdec_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msae_decode_bwd_wdec_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                         c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "msae_sparsify_count": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_void_p, c_void_p]),
     "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,

@@ -186,15 +186,17 @@ def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: T
     k = idx.shape[-1]
     A = idx.numel() // k
     g_acts = torch.empty_like(acts) if need_acts else acts.new_empty(0)
-    g_w = torch.zeros_like(W) if need_w else W.new_empty(0)
+    g_w = torch.empty_like(W) if need_w else W.new_empty(0)   # the kernel writes every row
     with torch.cuda.device(dev):
         st = _hip.stream_of(g)
         if need_acts:
             _hip.check(lib.msae_decode_bwd_acts_f32(_hip.ptr(idx), _hip.ptr(g), _hip.ptr(W), A, k, N, d,
                                                     _hip.ptr(g_acts), st), "msae_decode_bwd_acts_f32")
         if need_w:
+            ws = _workspace(dev, lib.msae_decode_bwd_wdec_ws_bytes(A, k, N))
             _hip.check(lib.msae_decode_bwd_wdec_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(g), A, k, N,
-                                                    d, _hip.ptr(g_w), st), "msae_decode_bwd_wdec_f32")
+                                                    d, _hip.ptr(g_w), _hip.ptr(ws), ws.numel(), st),
+                       "msae_decode_bwd_wdec_f32")
     return g_acts, g_w
 
 

@@ -26,7 +26,8 @@ class SaeTrainStep:
         self.dead_feature_threshold = dead_feature_threshold
         if lr is None:  # trainer.py:131: 2e-4 scaled by 1/sqrt(N / 2^14)
             lr = 2e-4 / (sae.num_latents / (2 ** 14)) ** 0.5
-        self.optimizer = torch.optim.Adam(sae.parameters(), lr=lr)
+        # fused=True: one kernel over all parameters instead of ~9 foreach passes (23 -> ~5 ms at C2)
+        self.optimizer = torch.optim.Adam(sae.parameters(), lr=lr, fused=sae.device.type == "cuda")
         self.num_tokens_since_fired = torch.zeros(sae.num_latents, dtype=torch.long, device=sae.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
