@@ -46,9 +46,14 @@ class Cache:
     """Accumulates COO feature records per hooked module (cache.py:23-92)."""
 
     def __init__(self, shard_size: int, filters: Optional[Dict[str, Tensor]] = None,
-                 batch_size: int = 64):
+                 batch_size: int = 64, spill_dir: Optional[str] = None):
+        """`spill_dir`: stream every batch's records to disk instead of holding the whole run in host
+        RAM (the reference keeps everything in Python lists until save_splits, cache.py:56-57);
+        `save()` reads them back in batch order, so the final tensors are identical."""
         self.feature_locations = defaultdict(list)
         self.feature_activations = defaultdict(list)
+        self.spill_dir = spill_dir
+        self._spilled = defaultdict(list)
         self.filters = filters
         self.batch_size = batch_size
         self.shard_size = shard_size  # rows held by lower ranks (cache.py:39)
@@ -72,16 +77,25 @@ class Cache:
         row_base = batch_number * self.batch_size + self.shard_size  # cache.py:55
         loc, act = ops.sparsify(top_acts, top_indices, num_latents, row_base=row_base, thresh=1e-5,
                                 filter_bitmap=self._bitmap(module_path, num_latents, top_acts.device))
-        self.feature_locations[module_path].append(loc.cpu())
-        self.feature_activations[module_path].append(act.cpu())
+        self._append(module_path, loc.cpu(), act.cpu())
+
+    def _append(self, module_path: str, loc: Tensor, act: Tensor):
+        if self.spill_dir is None:
+            self.feature_locations[module_path].append(loc)
+            self.feature_activations[module_path].append(act)
+            return
+        d = os.path.join(self.spill_dir, module_path)
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"batch_{len(self._spilled[module_path]):08d}.safetensors")
+        save_file({"locations": loc.contiguous(), "activations": act.contiguous()}, path)
+        self._spilled[module_path].append(path)
 
     def add(self, latents: Tensor, batch_number: int, module_path: str):
         """Legacy entry point taking DENSE `[B,S,N]` latents (cache.py:42-57)."""
         loc, act = self.get_nonzeros(latents, module_path)
         loc, act = loc.cpu(), act.cpu()
         loc[:, 0] += batch_number * self.batch_size + self.shard_size
-        self.feature_locations[module_path].append(loc)
-        self.feature_activations[module_path].append(act)
+        self._append(module_path, loc, act)
 
     def get_nonzeros(self, latents: Tensor, module_path: str):
         keep = latents.abs() > 1e-5  # cache.py:80-81
@@ -92,6 +106,13 @@ class Cache:
         return loc[mask], act[mask]
 
     def save(self):
+        for module_path, paths in self._spilled.items():      # streamed batches come back in order
+            parts = [load_file(p) for p in paths]
+            self.feature_locations[module_path] = [p["locations"] for p in parts]
+            self.feature_activations[module_path] = [p["activations"] for p in parts]
+            for p in paths:
+                os.remove(p)
+        self._spilled.clear()
         for module_path in list(self.feature_locations.keys()):
             self.feature_locations[module_path] = torch.cat(self.feature_locations[module_path], dim=0)
             self.feature_activations[module_path] = torch.cat(self.feature_activations[module_path], dim=0)

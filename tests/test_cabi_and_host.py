@@ -226,3 +226,21 @@ def test_cache_files_round_trip_through_the_reader_rule(golden_dir, tmp_path):
     sel = {module: torch.tensor([int(loc[0, 2]), int(loc[-1, 2])])}
     got = {r.feature for r in FeatureDataset(str(tmp_path), width, 4, modules=[module], features=sel)}
     assert got == set(sel[module].tolist())
+
+
+def test_cache_spill_to_disk_equals_in_memory(tmp_path):
+    """Streaming every batch to disk (spill_dir) yields the same final tensors as the reference's
+    keep-everything-in-RAM accumulation."""
+    from msae.features import Cache
+
+    g = torch.Generator().manual_seed(0)
+    caches = [Cache(shard_size=7, batch_size=2), Cache(shard_size=7, batch_size=2, spill_dir=str(tmp_path))]
+    for b in range(3):
+        dense = torch.relu(torch.randn(2, 3, 32, generator=g) - 1.0)
+        for c in caches:
+            c.add(dense, b, "model.layers.24")
+    for c in caches:
+        c.save()
+    assert torch.equal(caches[0].feature_locations["model.layers.24"], caches[1].feature_locations["model.layers.24"])
+    assert torch.equal(caches[0].feature_activations["model.layers.24"], caches[1].feature_activations["model.layers.24"])
+    assert not any(f.endswith(".safetensors") for _, _, fs in __import__("os").walk(tmp_path) for f in fs)
