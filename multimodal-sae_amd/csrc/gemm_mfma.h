@@ -30,6 +30,8 @@
 // Epilogues: DENSE  out[t][n] = value + bias[feature(n)]                      (sample pass)
 //            THRESH append (feature, value + bias) to token t's candidate list when > tau[t]
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -71,7 +73,12 @@ struct GemmCfg {
   static constexpr int KS = 4;                   // MFMA k-steps per tile (32 B per lane-half each)
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int LDS_RING_BYTES = STAGES * STAGE_BYTES;
-  static constexpr int LDS_BYTES = LDS_RING_BYTES + 2 * NT * 4;   // + side buffer of epilogue constants
+  // behind the ring: side buffer of epilogue constants, then the THRESH epilogue's candidate queue.
+  // Neither overlaps the ring: the next tile's first k-tile is already landing in it meanwhile.
+  static constexpr int SIDE_BYTES = 2 * NT * 4;
+  static constexpr int QCAP = 3072;
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
+  static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
   static constexpr int A_PIECES = A_BYTES / 1024;
@@ -177,19 +184,19 @@ __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const 
 // Epilogue.  DENSE stores every value.  THRESH compares with the per-token threshold; survivors are
 // rare (~1 per 500 outputs) but each needs a slot in its token's candidate list, i.e. a RETURNING
 // global atomic (~2 us round trip).  Doing that inline serialises ~30 round trips per wave -- as
-// long as the whole k-loop.  So survivors are first queued in LDS (the operand ring is free by
-// now; an LDS atomic returns in ~100 cycles) and then flushed, one queue entry per lane: the
+// long as the whole k-loop.  So survivors are first queued in LDS (its own region behind the ring;
+// an LDS atomic returns in ~100 cycles) and then flushed, one queue entry per lane: the
 // global atomics of the whole workgroup are in flight together.
 template <class C, bool DENSE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
                                               unsigned char *smem, const float *side) {
   const int l31 = lane & 31, kh = lane >> 5;
-  constexpr int QCAP = 8192;                           // 64 KiB of the (>= 128 KiB) ring
-  unsigned *q_count = reinterpret_cast<unsigned *>(smem);
-  unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + 16);
+  constexpr int QCAP = C::QCAP;
+  unsigned *q_count = reinterpret_cast<unsigned *>(smem + C::LDS_RING_BYTES + C::SIDE_BYTES);
+  unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + C::LDS_RING_BYTES + C::SIDE_BYTES + 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                        // ring reads done everywhere; side[] written
+  __builtin_amdgcn_s_barrier();                        // side[] written; previous tile's flush done
   if constexpr (!DENSE) {
     if (threadIdx.x == 0) *q_count = 0u;
     __syncthreads();
@@ -261,13 +268,30 @@ template <class C, bool DENSE>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int Tp, int N, int nM, int nN,
                                                      GemmEpilogue ep) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // persistent workgroups: the grid is one workgroup per CU (a multiple of 8, so a workgroup's
+  // tiles keep its XCD's super-tile affinity) and each walks tile ids blockIdx.x, +gridDim.x, ...
+  // The k-tiles of all its output tiles form ONE flat sequence through the 2-slot ring: the last
+  // iteration of a tile already stages the first k-tile of the next one, whose latency is then
+  // hidden behind the epilogue.
+  int seq = 0;                                   // flat k-tile counter; ring slot = seq & 1
+  for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
+  // the thread id is made opaque per tile: otherwise every lane-dependent address of the
+  // prologue and the epilogue is hoisted out of this loop and lives across the k-loop (spills)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int lane = tid_ & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int wr = wave / C::WN, wc = wave % C::WN;
-  int tm, tn;
-  gemm_map_tile(blockIdx.x, nM, nN, tm, tn);
-  const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int l31 = lane & 31, kh = lane >> 5;
+  int tm, tn;
+  gemm_map_tile(tile_id, nM, nN, tm, tn);
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const bool has_next = tile_id + (int)gridDim.x < nM * nN;
+  int m0n = 0, n0n = 0;
+  if (has_next) {
+    gemm_map_tile(tile_id + gridDim.x, nM, nN, tm, tn);
+    m0n = tm * C::BM, n0n = tn * C::BN;
+  }
 
   // Row / column constants of the epilogue: fetched NOW into two registers per thread, parked in
   // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   //   threads [BM, BM+BN)  : bias and sw (int8) of column n0 + tid - BM
   float side0 = 0.f, side1 = 0.f;
   {
-    const int tid = threadIdx.x;
+    const int tid = tid_;
     if (tid < C::BM) {
       const int t = m0 + tid;
       if constexpr (!DENSE) {
@@ -310,27 +334,24 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // tile sequence: [outlier tile (int8, optional)] then the nk main k-tiles
   const int lead = has_out ? 1 : 0;
   const int ntiles = op.nk + lead;
-  auto stage = [&](int tile, int slot) {
+  auto stage = [&](int tm0, int tn0, int tile, int slot) {
     if (tile < lead)
-      gemm_stage<C>(op.Ao, 128, op.Bo, 128, m0, n0, Tp, N, 0, smem, slot, wave, lane);
+      gemm_stage<C>(op.Ao, 128, op.Bo, 128, tm0, tn0, Tp, N, 0, smem, slot, wave, lane);
     else
-      gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, m0, n0, Tp, N, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, lane);
+      gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, tm0, tn0, Tp, N, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, lane);
   };
-#pragma unroll
-  for (int s = 0; s < C::STAGES - 1; ++s)
-    if (s < ntiles) stage(s, s);
+  if (tile_id == (int)blockIdx.x) stage(m0, n0, 0, 0);   // later tiles: staged by their predecessor
 
   auto iteration = [&](int kt) {
-    // tile kt has landed once at most STAGES-2 younger groups of this wave are outstanding
-    if (kt + C::STAGES - 2 < ntiles) wait_vmcnt<C::PPW *(C::STAGES - 2)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // all waves' pieces of kt landed; slot of kt-1 is free again
-    const int nkt = kt + C::STAGES - 1;
+    wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
+    __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
     if constexpr (!C::ABL_NOSTAGE) {
-      if (nkt < ntiles) stage(nkt, nkt % C::STAGES);
+      if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
+      else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     }
-    const unsigned char *sA = smem + (kt % C::STAGES) * C::STAGE_BYTES;
+    const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
     gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+    ++seq;
   };
   int kt0 = 0;
   if constexpr (C::I8) {
@@ -356,9 +377,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 
   // park the epilogue constants in LDS (side buffer behind the ring)
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
-  side[threadIdx.x] = side0;
-  side[C::NT + threadIdx.x] = side1;
+  side[tid_] = side0;
+  side[C::NT + tid_] = side1;
   gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
+  }
 }
 
 // Host launcher.  Requires Tp % BM == 0 and N % BN == 0 (checked by the caller's plan).
@@ -368,6 +390,14 @@ inline int gemm_launch(const GemmOperands &op, int T, int Tp, int N, const GemmE
   const int nM = Tp / C::BM, nN = N / C::BN;
   auto kern = gemm_kernel<C, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(nM * nN), dim3(C::NT), C::LDS_BYTES, s, op, T, Tp, N, nM, nN, ep);
+  static int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 8 ? cus / 8 * 8 : 8;
+  }();
+  const char *np_env = getenv("MSAE_GEMM_NONPERSISTENT");
+  const int per_cu = C::LDS_BYTES > 80 * 1024 ? 1 : 2;
+  const int grid = (np_env || nM * nN <= n_cu * per_cu) ? nM * nN : n_cu * per_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, op, T, Tp, N, nM, nN, ep);
   return (int)hipGetLastError();
 }

@@ -82,9 +82,6 @@ int main(int argc, char **argv) {
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
   RUN(256, 256, 2, 2, 4, false);
   RUN(256, 256, 2, 2, 4, false, 24);   // staging only, 8 waves
-  RUN(256, 256, 2, 4, 4, false);       // 16 waves, 64x64 per wave
-  RUN(256, 256, 2, 4, 4, false, 24);   // staging only, 16 waves
-  RUN(256, 256, 2, 4, 4, true);        // int8, 16 waves
   RUN(256, 256, 2, 2, 4, true);
   return 0;
 }

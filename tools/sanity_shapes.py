@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/multimodal-sae_
 import bench
 from msae import ops
 dev = torch.device('cuda:0')
-for (T, d, N, k) in ((8192, 4096, 131072, 256), (4096, 4096, 262144, 32), (2880, 4096, 131072, 32), (8192, 768, 24576, 32)):
+for (T, d, N, k) in ((65536, 4096, 131072, 32), (8192, 4096, 131072, 256), (4096, 4096, 262144, 32), (2880, 4096, 131072, 32), (8192, 768, 24576, 32)):
     W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, T, d, N)
     prep = ops.prepare_encoder(W_enc)
     for _ in range(2): v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, k)
