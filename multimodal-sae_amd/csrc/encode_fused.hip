@@ -329,6 +329,10 @@ using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
 constexpr int G_BM = GemmBf16::BM;
 
 // ---- candidate select + exact re-score ----------------------------------------------------------
+#ifndef MSAE_RESCORE_U
+#define MSAE_RESCORE_U 16
+#endif
+static_assert(MSAE_RESCORE_U * 4 == 64, "one re-scoring batch must be the 64 floats fast_shape_ok() guarantees");
 struct RescoreArgs {
   const float *a32; const float *W_enc, *b_enc;
   const float *tau_vals; int tau_ld, tau_col;
@@ -394,7 +398,11 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
   int target = n < p.n_rescore ? n : p.n_rescore;
   bool ok = false;
+  int rounds = 0;
+  const int first_target = target;
+  (void)first_target; (void)rounds;
   for (;;) {
+    ++rounds;
     for (int c0 = done; c0 < target; c0 += NT) {
       const int c = c0 + lane;
       const bool active = c < target;
@@ -403,17 +411,31 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       const float coarse = f32_from_order_key((unsigned)(key >> 32));
       const float *__restrict__ w = W_enc + (size_t)f * p.d;
       float acc = 0.f;
-      for (int kk = 0; kk < p.d; kk += 32) {     // d % 64 == 0 on this path
-        f32x4 wv[8];
+      // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
+      // other is in flight, so the lane never drains its loads (bytes in flight per CU are what
+      // bounds this kernel: ~7 waves/CU x 48 lanes x RS_U..2*RS_U x 16 B against ~64 KB needed)
+      constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U;   // floats per batch
+      f32x4 wa[RS_U], wb[RS_U];
+      auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
+        for (int u = 0; u < RS_U; ++u) dst[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
+      };
+      auto consume = [&](const f32x4 (&src)[RS_U], int kk) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          acc = __builtin_fmaf(a[kk + 4 * u + 0], wv[u][0], acc);   // a[] is wave-uniform: SGPRs
-          acc = __builtin_fmaf(a[kk + 4 * u + 1], wv[u][1], acc);
-          acc = __builtin_fmaf(a[kk + 4 * u + 2], wv[u][2], acc);
-          acc = __builtin_fmaf(a[kk + 4 * u + 3], wv[u][3], acc);
+        for (int u = 0; u < RS_U; ++u) {
+          acc = __builtin_fmaf(a[kk + 4 * u + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
+          acc = __builtin_fmaf(a[kk + 4 * u + 1], src[u][1], acc);
+          acc = __builtin_fmaf(a[kk + 4 * u + 2], src[u][2], acc);
+          acc = __builtin_fmaf(a[kk + 4 * u + 3], src[u][3], acc);
         }
+      };
+      fetch(wa, 0);
+      for (int kk = 0; kk < p.d; kk += 2 * RS_B) {     // d % RS_B == 0 on this path (fast_shape_ok)
+        const bool has_b = kk + RS_B < p.d;
+        if (has_b) fetch(wb, kk + RS_B);
+        consume(wa, kk);
+        if (kk + 2 * RS_B < p.d) fetch(wa, kk + 2 * RS_B);
+        if (has_b) consume(wb, kk + RS_B);
       }
       const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
       if (active) {
@@ -462,6 +484,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
                        (done + has_set < p.k ? 16 : 0) | 32;
     if (p.status) p.status[t] = ok ? 0 : reason;
+#ifdef MSAE_RESCORE_DEBUG   // rows / rounds histogram (tools/rescore_stats.py); breaks the status contract
+    if (p.status && ok) p.status[t] = (rounds << 24) | (first_target << 12) | done;
+#endif
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
       if (slot < FB_MAX) p.flagged[slot] = t;
@@ -590,7 +615,6 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
-
   prof_mark(0, s);
   hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T);
   hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, s, flagged, (size_t)(FB_MAX + 64));

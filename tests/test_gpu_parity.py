@@ -204,7 +204,7 @@ def coarse(request, dev):
     ops.set_coarse_mode("int8")
 
 
-@pytest.mark.parametrize("T,d,N,k", [(384, 4096, 16384, 32), (300, 1024, 8192, 64)])
+@pytest.mark.parametrize("T,d,N,k", [(384, 4096, 16384, 32), (300, 1024, 8192, 64), (130, 192, 8192, 32), (70, 448, 16384, 16)])
 def test_fused_encode_bit_exact_vs_oracle(dev, coarse, T, d, N, k):
     from msae import ops
 

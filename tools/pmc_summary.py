@@ -12,7 +12,7 @@ for d in sys.argv[2:]:
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                name = row["Kernel_Name"].split("(")[0][-90:]
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-90:]
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for name, ctrs in acc.items():
             for c, vals in ctrs.items():
