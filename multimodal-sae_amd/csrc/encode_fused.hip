@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
   m_out = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
   const float scale = m_in > 0.f ? m_in / 127.f : (m_out > 0.f ? m_out / 127.f : 1.f);
   int m = (int)ceilf(m_out / (127.f * scale));
-  m = m < 1 ? 1 : (m > 32768 ? 32768 : m);
+  m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
   if (threadIdx.x == 0) { sx[t] = scale; mscale[t] = m; }
   const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
   for (int c = threadIdx.x * 16; c < d; c += 4096) {

@@ -75,7 +75,7 @@ struct GemmCfg {
   static constexpr int LDS_RING_BYTES = STAGES * STAGE_BYTES;
   // behind the ring: side buffer of epilogue constants, then the THRESH epilogue's candidate queue.
   // Neither overlaps the ring: the next tile's first k-tile is already landing in it meanwhile.
-  static constexpr int SIDE_BYTES = 2 * NT * 4;
+  static constexpr int SIDE_BYTES = 3 * NT * 4;   // tau|bias, sx|sw, outlier multiplier (one float/int per thread each)
   static constexpr int QCAP = 3072;
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   //   threads [0, BM)      : tau (THRESH) and sx (int8) of row m0 + tid
   //   threads [BM, BM+BN)  : bias and sw (int8) of column n0 + tid - BM
   float side0 = 0.f, side1 = 0.f;
+  int side2 = 1;
   {
     const int tid = tid_;
     if (tid < C::BM) {
@@ -306,7 +307,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
         side0 = (v > 0.f) ? v : __builtin_inff();     // degenerate / padded token: emit nothing
       }
-      if constexpr (C::I8) side1 = (t < T) ? ep.sx[t] : 0.f;
+      if constexpr (C::I8) {
+        side1 = (t < T) ? ep.sx[t] : 0.f;
+        if (op.Ao != nullptr) side2 = op.mscale[t];   // rows [T, Tp) hold 1
+      }
     } else if (tid < C::BM + C::BN) {
       const int feat = (n0 + tid - C::BM) * ep.bias_stride + ep.bias_off;
       side0 = ep.bias ? ep.bias[feat] : 0.f;
@@ -342,8 +346,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   };
   if (tile_id == (int)blockIdx.x) stage(m0, n0, 0, 0);   // later tiles: staged by their predecessor
 
-  auto iteration = [&](int kt) {
+  int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
+  auto iteration = [&](int kt, bool park_m = false) {
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
+    if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
+      side_m[tid_] = side2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
     if constexpr (!C::ABL_NOSTAGE) {
       if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
@@ -356,18 +365,19 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   int kt0 = 0;
   if constexpr (C::I8) {
     if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
-      iteration(0);
+      iteration(0, true);
       kt0 = 1;
+      // |acc| <= 128 * 127 * 127 < 2^23 here and m < 2^23: the full-rate 24-bit multiply is exact
+      // (v_mul_lo_u32 is quarter rate: 128 of them per lane cost ~2 us per tile)
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int t = m0 + wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          const int m = (t < T) ? op.mscale[t] : 1;
+          const int m = side_m[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
 #pragma unroll
           for (int j = 0; j < C::NI; ++j) {
             i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
-            v[e] *= m;
+            v[e] = __mul24(v[e], m);
             acc[i][j] = __builtin_bit_cast(f32x16, v);
           }
         }
