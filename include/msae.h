@@ -145,6 +145,23 @@ int msae_sparsify_write(const float *vals, const int32_t *idx, int B, int S, int
 int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, int k, float *vals, int32_t *idx,
                     int32_t *flagged, void *stream);
 
+/* ---- parameter-sized passes of one optimisation step (training) ----
+ * msae_unit_norm_rows_f32: W[r][:] /= ||W[r][:]||_2 + eps, in place
+ *                          (Sae.set_decoder_norm_to_unit_norm, sae_auto_interp/sae/sae.py:249-255).
+ * msae_grad_sumsq_f32:     *accum += sum(g^2) (device scalar; the total-norm half of
+ *                          clip_grad_norm_, train/sae/sae/trainer.py:390).
+ * msae_adam_rows_f32:      one pass over a [rows][d] parameter: g = G * min(1, max_norm /
+ *                          (sqrt(*total_sumsq) + 1e-6)) (total_sumsq NULL: no clipping); if `project`,
+ *                          g -= <g, W[r]> W[r] per row (Sae.remove_gradient_parallel_to_decoder_
+ *                          directions, sae.py:257-271); then Adam (torch.optim.Adam arithmetic, no
+ *                          weight decay, trainer.py:139-146,395) on W, M, V in place, `step` >= 1.
+ *                          G is read only. */
+int msae_unit_norm_rows_f32(float *W, int N, int d, float eps, void *stream);
+int msae_grad_sumsq_f32(const float *g, size_t n, float *accum, void *stream);
+int msae_adam_rows_f32(float *W, const float *G, float *M, float *V, int rows, int d,
+                       const float *total_sumsq, float max_norm, int project, float lr, float beta1,
+                       float beta2, float eps, int step, void *stream);
+
 /* ---- stage timing of msae_encode_topk's fused path (measurement aid for bench.py) --------------
  * Between _begin and _end every fused msae_encode_topk call records HIP events, on the stream it
  * launches on, at the boundaries of its 6 stages:

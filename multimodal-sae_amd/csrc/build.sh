@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function"
 OBJS=""
-for f in capi decode topk sparsify encode_f32 encode_fused; do
+for f in capi decode topk sparsify encode_f32 encode_fused train; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   OBJS="$OBJS $OUT/$f.o"
 done

@@ -47,6 +47,10 @@ PROTOTYPES = {
                                     c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_set_coarse_mode": (c_int, [c_int]),
     "msae_merge_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "msae_unit_norm_rows_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
+    "msae_grad_sumsq_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "msae_adam_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float,
+                                   c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "msae_profile_begin": (c_int, [c_int]),
     "msae_profile_end": (c_int, [c_void_p, c_void_p]),
 }

@@ -337,3 +337,46 @@ def sparse_encode(x: Tensor, W_enc: Tensor, b_enc: Tensor, b_dec: Tensor, k: int
     """-> [(acts, idx)] for the top-k, (optional) AuxK and (optional) Multi-TopK selections."""
     out = _SparseEncode.apply(x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi)
     return [(out[2 * j], out[2 * j + 1]) for j in range(len(out) // 2)]
+
+
+# ---- parameter-sized passes of one optimisation step (csrc/train.hip) --------------------------------
+def unit_norm_rows_(W: Tensor, eps: float) -> Tensor:
+    """W /= ||W||_row + eps, in place, one read + one write (sae.py:249-255)."""
+    dev = _hip.require_device(W)
+    assert W.dtype == torch.float32 and W.dim() == 2 and W.is_contiguous()
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_unit_norm_rows_f32(_hip.ptr(W), W.shape[0], W.shape[1], float(eps),
+                                                       _hip.stream_of(W)), "msae_unit_norm_rows_f32")
+    return W
+
+
+def grad_sumsq_(accum: Tensor, g: Tensor) -> Tensor:
+    """accum (f32 device scalar) += sum(g^2): the total-norm half of clip_grad_norm_, no host sync."""
+    dev = _hip.require_device(g, accum)
+    assert g.dtype == torch.float32 and g.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == 1
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_grad_sumsq_f32(_hip.ptr(g), g.numel(), _hip.ptr(accum), _hip.stream_of(g)),
+                   "msae_grad_sumsq_f32")
+    return accum
+
+
+def adam_rows_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, *,
+               total_sumsq: Optional[Tensor] = None, max_norm: float = 1.0, project: bool = False,
+               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
+    """One fused pass: clip by the global gradient norm, optionally remove the component of each
+    gradient row parallel to the parameter row (sae.py:257-271), Adam update of p, m, v in place."""
+    dev = _hip.require_device(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == p.shape
+    if p.dim() == 2:
+        rows, d = p.shape
+    else:   # vectors: any row length works without the projection
+        assert not project
+        d = 1024 if p.numel() % 1024 == 0 else p.numel()
+        rows = p.numel() // d
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_adam_rows_f32(
+            _hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), rows, d,
+            _hip.ptr(total_sumsq) if total_sumsq is not None else None, float(max_norm), int(project),
+            float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), _hip.stream_of(p)),
+            "msae_adam_rows_f32")

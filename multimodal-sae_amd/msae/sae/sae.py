@@ -205,7 +205,11 @@ class Sae(nn.Module):
     def set_decoder_norm_to_unit_norm(self):
         assert self.W_dec is not None, "Decoder weight was not initialized."
         eps = torch.finfo(self.W_dec.dtype).eps
-        self.W_dec.data /= torch.norm(self.W_dec.data, dim=1, keepdim=True) + eps
+        W = self.W_dec.data
+        if W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
+            ops.unit_norm_rows_(W, eps)       # one read + one write of the 2 GiB matrix
+        else:                                 # module still on the host (construction, checkpoint tools)
+            W /= torch.norm(W, dim=1, keepdim=True) + eps
 
     @torch.no_grad()
     def remove_gradient_parallel_to_decoder_directions(self):

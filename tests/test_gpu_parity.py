@@ -607,3 +607,53 @@ def test_training_forward_fused_path_equals_dense_path(dev):
     (out.fvu + out.multi_topk_fvu / 8).backward()
     assert sae.encoder.weight.grad is not None and torch.isfinite(sae.encoder.weight.grad).all()
     assert int((sae.encoder.weight.grad.abs().sum(1) > 0).sum()) > 0
+
+
+# ---- fused optimiser-side passes (csrc/train.hip) vs the torch ops the reference trainer runs ---------
+@pytest.mark.parametrize("N,d", [(512, 4096), (300, 768), (37, 50)])
+def test_unit_norm_rows_matches_torch(dev, N, d):
+    from msae import ops
+
+    W = torch.randn(N, d, generator=torch.Generator().manual_seed(1)).to(dev) * 3.0
+    eps = torch.finfo(torch.float32).eps
+    ref = W / (torch.norm(W, dim=1, keepdim=True) + eps)          # sae.py:252-255
+    ops.unit_norm_rows_(W, eps)
+    torch.testing.assert_close(W, ref, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,d,project,big_grads", [(256, 4096, True, True), (256, 4096, False, False),
+                                                   (33, 50, True, True), (64, 768, True, False)])
+def test_fused_clip_project_adam_matches_torch(dev, N, d, project, big_grads):
+    """clip_grad_norm_(1.0) -> remove_gradient_parallel_to_decoder_directions -> torch.optim.Adam
+    (trainer.py:390-400, sae.py:257-271) on a matrix + a bias vector, three steps."""
+    from msae import ops
+
+    gen = torch.Generator().manual_seed(7)
+    W0 = torch.randn(N, d, generator=gen).to(dev)
+    b0 = torch.randn(N, generator=gen).to(dev)
+    Wr, br = torch.nn.Parameter(W0.clone()), torch.nn.Parameter(b0.clone())
+    opt = torch.optim.Adam([Wr, br], lr=1e-3)
+    W, b = W0.clone(), b0.clone()
+    mW, vW, mb, vb = (torch.zeros_like(t) for t in (W, W, b, b))
+    sumsq = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        scale = 5.0 if big_grads else 1e-3                         # clipping active / inactive
+        gW = torch.randn(N, d, generator=gen).to(dev) * scale
+        gb = torch.randn(N, generator=gen).to(dev) * scale
+        # reference sequence
+        Wr.grad, br.grad = gW.clone(), gb.clone()
+        torch.nn.utils.clip_grad_norm_([Wr, br], 1.0)
+        if project:
+            along = (Wr.grad * Wr.data).sum(dim=1, keepdim=True)
+            Wr.grad -= along * Wr.data
+        opt.step()
+        # fused
+        sumsq.zero_()
+        ops.grad_sumsq_(sumsq, gW)
+        ops.grad_sumsq_(sumsq, gb)
+        ops.adam_rows_(W, gW, mW, vW, step, 1e-3, total_sumsq=sumsq, project=project)
+        ops.adam_rows_(b, gb, mb, vb, step, 1e-3, total_sumsq=sumsq)
+        torch.testing.assert_close(W, Wr.data, rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(b, br.data, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mW, opt.state[Wr]["exp_avg"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(vW, opt.state[Wr]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
