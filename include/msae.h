@@ -82,6 +82,10 @@ int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_
  * msae_encoder_prepared_bytes(N, d) bytes and stay valid while the encoder is used. */
 size_t msae_encoder_prepared_bytes(int N, int d);
 int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream);
+/* Same buffer after a weight update (one training step): rebuilds only the operands that the coarse
+ * mode in force (msae_set_coarse_mode) reads -- the other mode's operands go stale, so call
+ * msae_encoder_prepare again before switching modes. */
+int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void *stream);
 
 /* Operand type of the fused encoder's candidate pass: 1 = int8 MFMA (default: per-token / per-feature
  * scales, massive-activation dims in a separately scaled k-tile), 0 = bf16 MFMA.  Either way the

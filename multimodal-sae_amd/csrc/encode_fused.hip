@@ -769,25 +769,38 @@ extern "C" size_t msae_encoder_prepared_bytes(int N, int d) {
   return make_prepared(N, d).bytes;
 }
 
-extern "C" int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream) {
+namespace {
+// modes: bit 0 = bf16 operands, bit 1 = int8 operands
+int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hipStream_t s) {
   if (N <= 0 || d <= 0 || !prepared) return MSAE_EINVAL;
   if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
-  hipStream_t s = (hipStream_t)stream;
   Prepared p = make_prepared(N, d);
   MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
   if (p.S) {
     if (!msae_aligned(W_enc, 16)) return MSAE_EALIGN;
     unsigned char *base = static_cast<unsigned char *>(prepared);
-    hipLaunchKernelGGL(prepare_weights_kernel, dim3(4096), dim3(256), 0, s, W_enc, N, d,
-                       reinterpret_cast<unsigned short *>(base + p.off_wb),
-                       reinterpret_cast<unsigned short *>(base + p.off_ws));
-    if (i8_shape_ok(N, d))
+    if (modes & 1)
+      hipLaunchKernelGGL(prepare_weights_kernel, dim3(4096), dim3(256), 0, s, W_enc, N, d,
+                         reinterpret_cast<unsigned short *>(base + p.off_wb),
+                         reinterpret_cast<unsigned short *>(base + p.off_ws));
+    if ((modes & 2) && i8_shape_ok(N, d))
       hipLaunchKernelGGL(quant_w_kernel, dim3(N), dim3(256), 0, s, W_enc, N, d,
                          reinterpret_cast<float *>(base + p.off_sw),
                          reinterpret_cast<signed char *>(base + p.off_wq),
                          reinterpret_cast<signed char *>(base + p.off_wqs));
   }
   return msae_launch_status();
+}
+}  // namespace
+
+extern "C" int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream) {
+  return prepare_impl(W_enc, N, d, prepared, 3, (hipStream_t)stream);
+}
+
+// After a weight update (training): rebuild only the operands the coarse mode in force reads.
+extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void *stream) {
+  const bool i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
+  return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
 }
 
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k) {

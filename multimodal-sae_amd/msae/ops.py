@@ -101,18 +101,35 @@ def set_coarse_mode(mode: str) -> None:
     _hip.check(_hip.load().msae_set_coarse_mode({"bf16": 0, "int8": 1}[mode]), "msae_set_coarse_mode")
 
 
-def prepare_encoder(W_enc: Tensor) -> Tensor:
-    """One-time bf16 copy (+ sampled rows) of the encoder weights for the fused path."""
+def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_only: bool = False) -> Tensor:
+    """Coarse-pass operands of the encoder weights for the fused path (bf16 copy, int8 quantisation,
+    sampled rows).  Once per weight load; `out` + `active_mode_only` is the per-step refresh of a
+    training loop (rebuilds only what the coarse mode in force reads, into the same buffer)."""
     dev = _hip.require_device(W_enc)
     lib = _hip.load()
     W = _f32c(W_enc)
     N, d = W.shape
     nbytes = lib.msae_encoder_prepared_bytes(N, d)
-    prepared = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if out is None or out.numel() != nbytes or out.device != dev:
+        out, active_mode_only = torch.empty(nbytes, dtype=torch.uint8, device=dev), False
+    fn = lib.msae_encoder_refresh if active_mode_only else lib.msae_encoder_prepare
     with torch.cuda.device(dev):
-        _hip.check(lib.msae_encoder_prepare(_hip.ptr(W), N, d, _hip.ptr(prepared), _hip.stream_of(W)),
-                   "msae_encoder_prepare")
-    return prepared
+        _hip.check(fn(_hip.ptr(W), N, d, _hip.ptr(out), _hip.stream_of(W)), "msae_encoder_prepare")
+    return out
+
+
+_TRAIN_PREPARED: dict = {}
+
+
+def _refresh_train_operands(W_enc: Tensor) -> Tensor:
+    """Per-step operands of a weight that changes every step: one buffer per parameter, rebuilt in
+    place for the coarse mode in force (the encode that follows runs in that same mode)."""
+    key = (W_enc.device, W_enc.data_ptr(), tuple(W_enc.shape))
+    buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True)
+    if len(_TRAIN_PREPARED) > 8 and key not in _TRAIN_PREPARED:
+        _TRAIN_PREPARED.clear()
+    _TRAIN_PREPARED[key] = buf
+    return buf
 
 
 @torch.library.custom_op("msae::encode_topk", mutates_args=())
@@ -287,7 +304,7 @@ class _SparseEncode(torch.autograd.Function):
             # no AuxK term: the fused encoder gives the canonical top-max(k, 4k); the top-k is its
             # prefix (same order), and the dense [T, N] latents are never built
             kk = max(k, k_multi)
-            v, i, _ = encode_topk(x, W_enc, b_enc, b_dec, prepare_encoder(W_enc), kk)
+            v, i, _ = encode_topk(x, W_enc, b_enc, b_dec, _refresh_train_operands(W_enc), kk)
             vals.append(v[..., :k].contiguous()); idxs.append(i[..., :k].contiguous())
             if k_multi > 0:
                 vals.append(v); idxs.append(i)

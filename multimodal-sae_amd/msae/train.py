@@ -85,6 +85,7 @@ class SaeTrainStep:
                            max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps,
                            project=sae.cfg.normalize_decoder and p is sae.W_dec)
             p.grad = None
+            torch.autograd.graph.increment_version(p)    # p changed behind autograd's back: caches keyed on it go stale
         n_tok = torch.tensor(hiddens.shape[0], device=sae.device)
         self._all_reduce(n_tok)
         self.num_tokens_since_fired += n_tok

@@ -621,6 +621,15 @@ def test_unit_norm_rows_matches_torch(dev, N, d):
     torch.testing.assert_close(W, ref, rtol=2e-6, atol=1e-7)
 
 
+def _close_but_for_adam_sign_flips(got, ref, lr):
+    """Adam's update is lr * m / (sqrt(v) + eps): for an element whose (projected) gradient is a
+    cancellation residue near eps the ratio is ill-conditioned, so two correct implementations that
+    round the clip coefficient differently may disagree there -- by at most one update."""
+    bad = (got - ref).abs() > 2e-6 + 1e-5 * ref.abs()
+    assert bad.float().mean().item() < 1e-5, f"{int(bad.sum())} of {bad.numel()} elements differ"
+    assert (got - ref).abs().max().item() <= 2.1 * lr
+
+
 @pytest.mark.parametrize("N,d,project,big_grads", [(256, 4096, True, True), (256, 4096, False, False),
                                                    (33, 50, True, True), (64, 768, True, False)])
 def test_fused_clip_project_adam_matches_torch(dev, N, d, project, big_grads):
@@ -653,7 +662,27 @@ def test_fused_clip_project_adam_matches_torch(dev, N, d, project, big_grads):
         ops.grad_sumsq_(sumsq, gb)
         ops.adam_rows_(W, gW, mW, vW, step, 1e-3, total_sumsq=sumsq, project=project)
         ops.adam_rows_(b, gb, mb, vb, step, 1e-3, total_sumsq=sumsq)
-        torch.testing.assert_close(W, Wr.data, rtol=1e-5, atol=2e-6)
-        torch.testing.assert_close(b, br.data, rtol=1e-5, atol=2e-6)
+        _close_but_for_adam_sign_flips(W, Wr.data, 1e-3)
+        _close_but_for_adam_sign_flips(b, br.data, 1e-3)
     torch.testing.assert_close(mW, opt.state[Wr]["exp_avg"], rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(vW, opt.state[Wr]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+
+
+def test_encode_after_train_step_uses_updated_weights(dev):
+    """The optimiser kernels write parameters through raw pointers; the Sae's cached coarse-pass
+    operands must be rebuilt afterwards (and the per-step refresh must serve both coarse modes)."""
+    from msae import Sae, SaeConfig, ops
+    from msae.train import SaeTrainStep
+
+    torch.manual_seed(0)
+    sae = Sae(256, SaeConfig(num_latents=8192, k=32), device=dev)
+    x = torch.randn(300, 256, device=dev)
+    before = sae.encode(x)                                   # populates the operand cache
+    ts = SaeTrainStep(sae, lr=5e-2)
+    for mode in ("int8", "bf16", "int8"):
+        ops.set_coarse_mode(mode)
+        ts.step(x)
+        got = sae.encode(x)
+        ref_v, ref_i = ops.topk(ops.pre_acts(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec), 32)
+        assert torch.equal(got.top_indices, ref_i) and torch.equal(got.top_acts, ref_v), mode
+    assert not torch.equal(before.top_acts, got.top_acts)

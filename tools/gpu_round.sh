@@ -22,3 +22,8 @@ find $OUT/prof -name "*stats*" | head;
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f; done
 # drop the bulky per-dispatch trace, keep the stats
 find $OUT/prof -name "*kernel_trace*" -size +2M -delete
+echo "== training step (BASELINE configs[3]) =="
+timeout 300 python tools/train_step_bench.py > $OUT/train_step.txt 2>&1; tail -1 $OUT/train_step.txt
+rm -rf $OUT/prof_train
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o tr -- python tools/train_step_bench.py > /dev/null 2> $OUT/rocprof_train.err; echo "rocprof train exit $?"
+find $OUT/prof_train -name "*kernel_trace*" -size +2M -delete
