@@ -23,6 +23,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -40,6 +41,8 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROAR
 PEAK_I8_TOPS = 5000.0       # dense int8 MFMA = 2x the bf16 rate (guide: i8 "~2x bf16", ubench >= 4404)
 PEAK_HBM_GBS = 8000.0
 STAGES = ["prep", "sample_gemm", "threshold_topk", "main_gemm", "select_rescore", "exact_fallback"]
+
+SHARDED_LEG_TIMEOUT_S = 240   # watchdog of the second (RCCL) leg; the headline line is printed regardless
 
 
 def make_inputs(dev, T, d, N, seed=0, rows=None):
@@ -172,24 +175,7 @@ def main():
 
     elapsed, out, stage, dec_ms = timed(engine, x, args.steps, args.warmup, profile=True)
 
-    # ---- second result (N > 1): the north-star's feature-sharded engine on ONE replicated batch --
-    # per-shard encode + TopK, RCCL all-gather + merge, token-sharded decode + all-gather (strong scaling)
-    feature = None
-    if ddp and (world > 1 or os.environ.get("MSAE_FORCE_COLLECTIVES") == "1") and not args.no_feature_sharded:
-        n_loc = N // world
-        _, _, _, _, x0 = make_inputs(dev, T, d, 8192, seed=0)       # the same tokens on every rank
-        lo, hi = rank * n_loc, (rank + 1) * n_loc
-        eng_f = ShardedSae(W_enc[lo:hi], b_enc[lo:hi], W_dec, b_dec, k, rank=rank, world=world,
-                           group=dist.group.WORLD,
-                           force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
-        el_f, out_f, _, _ = timed(eng_f, x0, args.steps, args.warmup, profile=False)
-        feature = {"value": T * args.steps / el_f, "unit": "tokens/s", "ms_per_step": el_f / args.steps * 1e3,
-                   "scaling": "strong", "tokens_per_step": T, "k_loc": eng_f.k_loc,
-                   "second_round_tokens": eng_f.second_round_tokens,
-                   "parallelism": f"feature-sharded x{world}: per-shard exact top-k_loc, RCCL all-gather + merge, "
-                                  "token-sharded decode + all-gather of the reconstruction"}
-        del eng_f
-
+    res = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * T * args.steps / elapsed
@@ -229,13 +215,55 @@ def main():
                                  "unit": "GB/s", "frac": bytes_dec / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             st = out["status"]
             res["fast_path_verified_frac"] = float((st == 0).float().mean().item())
-        if feature is not None:
-            res["feature_sharded"] = feature
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
-        print(json.dumps(res))
+    # One JSON line is owed whatever happens in the second, collective-heavy leg: if it stalls
+    # (a wedged RCCL call cannot be caught), a watchdog prints the headline result and ends the job.
+    emitted = threading.Event()
+
+    def emit(extra=None):
+        if rank == 0 and not emitted.is_set():
+            emitted.set()
+            if extra is not None:
+                res["feature_sharded"] = extra
+            print(json.dumps(res), flush=True)
+
+    def on_stall():
+        emit({"error": f"feature-sharded leg did not finish within {SHARDED_LEG_TIMEOUT_S} s"})
+        os._exit(0)
+
+    # ---- second result (N > 1): the north-star's feature-sharded engine on ONE replicated batch --
+    # per-shard encode + TopK, RCCL all-gather + merge, token-sharded decode + all-gather (strong scaling)
+    feature = None
+    run_sharded = (ddp and (world > 1 or os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
+                   and not args.no_feature_sharded)
+    if run_sharded:
+        watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, on_stall)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            n_loc = N // world
+            _, _, _, _, x0 = make_inputs(dev, T, d, 8192, seed=0)       # the same tokens on every rank
+            lo, hi = rank * n_loc, (rank + 1) * n_loc
+            eng_f = ShardedSae(W_enc[lo:hi], b_enc[lo:hi], W_dec, b_dec, k, rank=rank, world=world,
+                               group=dist.group.WORLD,
+                               force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
+            el_f, out_f, _, _ = timed(eng_f, x0, args.steps, args.warmup, profile=False)
+            feature = {"value": T * args.steps / el_f, "unit": "tokens/s", "ms_per_step": el_f / args.steps * 1e3,
+                       "scaling": "strong", "tokens_per_step": T, "k_loc": eng_f.k_loc,
+                       "second_round_tokens": eng_f.second_round_tokens,
+                       "parallelism": f"feature-sharded x{world}: per-shard exact top-k_loc, RCCL all-gather + merge, "
+                                      "token-sharded decode + all-gather of the reconstruction"}
+            del eng_f
+        except Exception as e:   # the other ranks may now be stuck in a collective: the watchdog ends them
+            feature = {"error": f"{type(e).__name__}: {e}"}
+            emit(feature)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
+    emit(feature)
     if ddp:
         dist.barrier()
+        if run_sharded:
+            watchdog.cancel()
         dist.destroy_process_group()
 
 
