@@ -17,6 +17,11 @@
 //     swz(r) = (r >> 1) & 7: every ds_read_b128 fragment read is bank-conflict-free
 //     (SQ_LDS_BANK_CONFLICT = 0 measured).  global_load_lds writes lane-linear, so the permutation
 //     is applied to the per-lane SOURCE address and again on the read;
+//   * the fragment reads of a k-tile are inline-asm ds_read_b128 with COUNTED lgkmcnt waits (the
+//     compiler waits lgkmcnt(0) after every group of reads): the 6 reads of k-step ks+1 are in
+//     flight while the 8 MFMAs of ks execute (-5 % on the int8 pass);
+//   * workgroups are persistent (one per CU) and walk their tiles as one flat k-sequence: the last
+//     k-iteration of a tile already stages the first k-tile of the next one;
 //   * tile -> workgroup map is XCD-aware: the 32 workgroups resident on one XCD's 32 CUs form an
 //     8 (M) x 4 (N) super-tile sharing 8 A-tiles and 4 B-tiles in that XCD's private L2.
 //
@@ -25,7 +30,8 @@
 //   kernel is partly DVFS-bound), int8 2x that; 128x128: 1.0.  Ablations: MFMA+barriers only
 //   5.4 ms, LDS-DMA staging only 5.4 ms (~12.7 TB/s L2->LDS, independent of ring depth and row
 //   pitch), both 7.3 ms.  Deeper rings (half-size k-tiles x 4 slots), a two-group ping-pong
-//   schedule, s_setprio and an L2 prefetch were all measured equal or worse and are not kept.
+//   schedule, s_setprio, an L2 prefetch and issuing the DMA behind the first MFMA group were all
+//   measured equal or worse and are not kept.
 //
 // Epilogues: DENSE  out[t][n] = value + bias[feature(n)]                      (sample pass)
 //            THRESH append (feature, value + bias) to token t's candidate list when > tau[t]
@@ -142,9 +148,83 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // one k-tile of MFMAs out of the LDS images sA / sB
 template <class C>
+__device__ __forceinline__ void gemm_mfma_step(f32x16 (&acc)[C::MI][C::NI], const i32x4 (&a)[C::MI],
+                                               const i32x4 (&b)[C::NI]) {
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) {
+      if constexpr (C::I8)   // the accumulator registers hold i32 on this path
+        acc[i][j] = __builtin_bit_cast(
+            f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
+      else
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                            __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+}
+
+// ---- hand-scheduled k-tile ----------------------------------------------------------------------------
+// The compiler waits lgkmcnt(0) after every group of fragment reads, so a read issued for the NEXT
+// k-step stalls the MFMAs of the current one.  Here the ds_read_b128 are inline asm (invisible to
+// the compiler's wait-count pass) with counted waits: the 6 reads of k-step ks+1 stay in flight
+// while the 8 MFMAs of ks execute.  The "+v" ties make every MFMA depend on the wait that covers
+// its operands.
+template <int IMM>
+__device__ __forceinline__ i32x4 lds_read_b128(unsigned addr) {
+  i32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+  return v;
+}
+template <int N, class C>
+__device__ __forceinline__ void lgkm_wait_tied(i32x4 (&a)[C::MI], i32x4 (&b)[C::NI]) {
+  static_assert(C::MI == 4 && C::NI == 2, "operand list below is written for a 128x64 wave tile");
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])
+               : "n"(N)
+               : "memory");
+}
+template <class C>
+__device__ __forceinline__ void gemm_read_frags(i32x4 (&a)[C::MI], i32x4 (&b)[C::NI], unsigned addrA,
+                                                unsigned addrB) {
+  a[0] = lds_read_b128<0 * 4096>(addrA); a[1] = lds_read_b128<1 * 4096>(addrA);
+  a[2] = lds_read_b128<2 * 4096>(addrA); a[3] = lds_read_b128<3 * 4096>(addrA);
+  b[0] = lds_read_b128<0 * 4096>(addrB); b[1] = lds_read_b128<1 * 4096>(addrB);
+}
+template <class C>
+__device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
+                                                 int wr, int wc, int l31, int kh) {
+  static_assert(C::KS == 4, "four k-steps per tile");
+  const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
+  const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
+  const unsigned rowB = base + (unsigned)C::A_BYTES + (unsigned)(wc * C::TN + l31) * 128u;
+  const unsigned sw = (unsigned)gemm_swz(l31);       // same swizzle for every 32-row block of A and B
+  unsigned off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) off[ks] = (((unsigned)(ks * 2 + kh)) ^ sw) << 4;
+  i32x4 a0[C::MI], b0[C::NI], a1[C::MI], b1[C::NI];
+  gemm_read_frags<C>(a0, b0, rowA + off[0], rowB + off[0]);
+  gemm_read_frags<C>(a1, b1, rowA + off[1], rowB + off[1]);
+  lgkm_wait_tied<6, C>(a0, b0);
+  gemm_mfma_step<C>(acc, a0, b0);
+  gemm_read_frags<C>(a0, b0, rowA + off[2], rowB + off[2]);
+  lgkm_wait_tied<6, C>(a1, b1);
+  gemm_mfma_step<C>(acc, a1, b1);
+  gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
+  lgkm_wait_tied<6, C>(a0, b0);
+  gemm_mfma_step<C>(acc, a0, b0);
+  lgkm_wait_tied<0, C>(a1, b1);
+  gemm_mfma_step<C>(acc, a1, b1);
+}
+
+template <class C>
 __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                              const unsigned char *sB, int wr, int wc, int l31, int kh,
                                              i32x4 (&abl_a)[C::MI], i32x4 (&abl_b)[C::NI]) {
+  if constexpr (!C::ABL_NOREAD && !C::ABL_NOMFMA) {
+    gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh);
+    return;
+  }
+  // ablation builds only (tools/gemm_sweep): compiler-scheduled reads / no reads / no MFMA
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) {
     const int chunk = ks * 2 + kh;
@@ -166,17 +246,7 @@ __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const 
 #pragma unroll
       for (int j = 0; j < C::NI; ++j) asm volatile("" ::"v"(b[j]));
     } else {
-#pragma unroll
-      for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-        for (int j = 0; j < C::NI; ++j) {
-          if constexpr (C::I8)   // the accumulator registers hold i32 on this path
-            acc[i][j] = __builtin_bit_cast(
-                f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
-                                                                __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-        }
+      gemm_mfma_step<C>(acc, a, b);
     }
   }
 }

@@ -83,5 +83,6 @@ int main(int argc, char **argv) {
   RUN(256, 256, 2, 2, 4, false);
   RUN(256, 256, 2, 2, 4, false, 24);   // staging only, 8 waves
   RUN(256, 256, 2, 2, 4, true);
+  RUN(256, 256, 2, 2, 4, true, 24);    // staging only, int8 byte layout
   return 0;
 }
