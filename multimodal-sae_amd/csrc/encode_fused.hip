@@ -557,11 +557,15 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
     p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
+    // first round / first extension, tuned on MI355X at k = 32 (same box, re-score stage ms):
+    //   int8  k+16,+8: 1.52   k+20,+16: 1.40   k+24,+16: 1.40   k+32,+16: 1.56   k+8,+8: 1.81
+    //   bf16  flat (1.04-1.05) from k+6 to k+12
+    // the int8 pass is ~3x noisier than bf16, so its guard band needs more margin; a round is a
+    // full row-streaming latency, so too small a first round costs more than a few extra rows
+    const int base = k / 8 > 8 ? k / 8 : 8;
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
-    p.step = k / 8 > 8 ? k / 8 : 8;
-    // first round: k + 8 rows of W_enc per token at k = 32 (bf16 coarse pass); the int8 pass is
-    // ~3x noisier, so its guard band needs about twice the margin
-    p.n_rescore = k + (p.i8 ? 2 : 1) * p.step;
+    p.n_rescore = k + (p.i8 ? 5 * base / 2 : base);
+    p.step = p.i8 ? 2 * base : base;
     // rounds extend the re-scored set (step doubling) up to here; once every listed candidate is
     // re-scored the bound falls back to tau, which sits ~8k ranks below v_k, so reaching r_max with
     // the band still violated is practically impossible and the exact fallback stays idle

@@ -14,5 +14,5 @@ for call in range(3):
     s = s.cpu()
     rounds, first, rows = s >> 24, (s >> 12) & 0xFFF, s & 0xFFF
     print(f"call {call}: rounds hist {torch.bincount(rounds).tolist()}  mean rows {rows.float().mean():.1f}  "
-          f"rows hist(48,64,96,160,256) {[int((rows == r).sum()) for r in (48, 64, 96, 160, 256)]}"
+          f"rows hist {dict(zip(*[t.tolist() for t in torch.unique(rows, return_counts=True)]))}"
           f"")
