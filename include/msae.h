@@ -28,7 +28,7 @@
  *
  * Numerics contract: all dot products are ascending-k f32 fused
  * multiply-add chains (v_mfma_f32_32x32x2_f32 / v_fma_f32), bit-identical to oracle/sae_oracle.c.
- * msae_encode_topk selects candidates with a bf16 MFMA pass and re-scores them with the exact f32
+ * msae_encode_topk selects candidates with an int8 (or bf16) MFMA pass and re-scores them with the exact f32
  * chain, so its outputs are bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever its
  * per-token guard band holds; tokens where it does not are reported in `status` and recomputed
  * by the exact path inside the same call.
@@ -169,7 +169,7 @@ int msae_adam_rows_f32(float *W, const float *G, float *M, float *V, int rows, i
 /* ---- stage timing of msae_encode_topk's fused path (measurement aid for bench.py) --------------
  * Between _begin and _end every fused msae_encode_topk call records HIP events, on the stream it
  * launches on, at the boundaries of its 6 stages:
- *   0 prep (zero + x->bf16)   1 sample GEMM   2 threshold TopK   3 main bf16 MFMA GEMM
+ *   0 prep (zero + quantise x) 1 sample GEMM   2 threshold TopK   3 main int8/bf16 MFMA GEMM
  *   4 select + exact re-score 5 exact fallback of flagged tokens
  * _end synchronises on the recorded events and returns stage_ms[n_steps][6] (HOST pointers). */
 int msae_profile_begin(int max_steps);

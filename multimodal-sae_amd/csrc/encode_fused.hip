@@ -362,10 +362,12 @@ __device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n,
 // ONE WAVE per token (64-thread workgroup).  dynamic LDS: keys[cap] u64 | res[nrp] u64.
 //
 // The candidate list is ordered by coarse value; lane c re-scores candidate c with the exact
-// ascending-k f32 chain: it walks row f of W_enc with 8 x 16-B loads in flight (one 128-B line
-// per batch) while the token's f32 activation vector a32[t][:] arrives through wave-uniform
-// scalar loads.  No LDS staging of operands, so ~32 tokens per CU keep ~160 KB of row reads in
-// flight (HBM-bound: (k + step) * d * 4 B per token).
+// ascending-k f32 chain: it walks row f of W_enc with two software-pipelined batches of 16 x 16-B
+// loads (256 B = two lines per batch) while the token's f32 activation vector a32[t][:] arrives
+// through wave-uniform scalar loads.  No LDS staging of operands: the data in flight lives in
+// VGPRs (7 waves x ~52 lanes x 512 B = ~186 KB per CU), which is what keeps the HBM pipe full --
+// streaming the rows through LDS instead caps it at the ring size and measured 2.5 ms vs 1.4.
+// HBM-bound: ~57 rows x d x 4 B per token.
 //
 // Rounds: the best `n_rescore` candidates are re-scored; if the guard band
 //     v_k(exact) > max(best not-yet-rescored coarse, tau) + eps,   eps = 4 * max|coarse - exact|

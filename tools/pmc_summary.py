@@ -19,5 +19,5 @@ for d in sys.argv[2:]:
                 out.setdefault(name, {})[c] = {"mean": sum(vals) / len(vals), "n": len(vals)}
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 for name, ctrs in sorted(out.items()):
-    if any(k in name for k in ("gemm_bf16", "select_rescore", "decode_fwd", "topk_rows", "pre_acts")):
+    if any(k in name for k in ("gemm_kernel", "select_rescore", "decode_fwd", "topk_rows", "pre_acts")):
         print(name[-70:], {c: round(v["mean"], 1) for c, v in ctrs.items()})
