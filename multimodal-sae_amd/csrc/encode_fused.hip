@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ a
   const int rows_per = (T + gridDim.y - 1) / gridDim.y;
   const int t0 = blockIdx.y * rows_per, t1 = min(T, t0 + rows_per);
   f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
   for (int t = t0; t < t1; ++t) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);
     m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
@@ -496,6 +497,13 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   }
 }
 
+// three scratch ranges in one launch (candidate counters, flag list, column maxima)
+__global__ void zero3_i32_kernel(int *p0, size_t n0, int *p1, size_t n1, int *p2, size_t n2) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n0; i += (size_t)gridDim.x * 256) p0[i] = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) p1[i] = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) p2[i] = 0;
+}
+
 __global__ void zero_i32_kernel(int *p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
 }
@@ -622,8 +630,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
   prof_mark(0, s);
-  hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T);
-  hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, s, flagged, (size_t)(FB_MAX + 64));
+  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)(FB_MAX + 64),
+                     pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
   hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.i8 ? T : pl.Tp, d,
                      pl.i8 ? (unsigned short *)nullptr : xb, a32);
 
@@ -641,8 +649,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     signed char *wqos = reinterpret_cast<signed char *>(ws + pl.off_wqos);
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
-    hipLaunchKernelGGL(zero_i32_kernel, dim3(4), dim3(256), 0, s, reinterpret_cast<int *>(colmax), (size_t)d);
-    const int ychunks = T >= 64 ? 64 : 1;
+    const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     hipLaunchKernelGGL(colmax_kernel, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, a32, T, d, colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     hipLaunchKernelGGL(quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, a32, T, d, odims, is_out, xq, xqo, sx, ms);
