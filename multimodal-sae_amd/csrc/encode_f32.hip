@@ -96,9 +96,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void pre_acts_f32_kernel(
     int T, int d, int N, int relu, float *__restrict__ out, int ld_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (n_rows) T = min(T, *n_rows);
-  const int m0 = blockIdx.y * F_BM, n0 = blockIdx.x * F_BN;
-  if (m0 >= T) return;
+  const int n0 = blockIdx.x * F_BN;
   constexpr int STAGE = (F_BM + F_BN) * F_PITCH;  // floats per stage: A tile then B tile
+  // row tiles blockIdx.y, +gridDim.y, ...: with a device-side row count the launch is sized for a
+  // few tiles only and a workgroup walks as many as the count needs (none -> it leaves at once)
+  for (int m0 = blockIdx.y * F_BM; m0 < T; m0 += gridDim.y * F_BM) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -155,6 +157,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void pre_acts_f32_kernel(
       }
     }
   }
+  __syncthreads();   // LDS stages are rewritten by the next row tile
+  }
 }
 
 template <int DT>
@@ -164,7 +168,9 @@ int launch_dt(const void *x, const float *W, const float *b_enc, const float *b_
   const size_t xb = (DT == MSAE_F32) ? 16 : 8;
   const bool vec = (d % 4 == 0) && msae_aligned(x, xb) && msae_aligned(W, 16) &&
                    (!b_dec || msae_aligned(b_dec, 16));
-  dim3 grid((N + F_BN - 1) / F_BN, (T + F_BM - 1) / F_BM);
+  int tiles_m = (T + F_BM - 1) / F_BM;
+  if (n_rows && tiles_m > 2) tiles_m = 2;   // device-side count: workgroups loop over the row tiles
+  dim3 grid((N + F_BN - 1) / F_BN, tiles_m);
   const size_t smem = F_LDS_FLOATS * sizeof(float);
   if (vec) {
     auto kern = pre_acts_f32_kernel<DT, true>;
@@ -190,7 +196,7 @@ int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const f
                          int relu, float *out, int ld_out, hipStream_t s) {
   if (T < 0 || d <= 0 || N <= 0 || ld_out < N) return MSAE_EINVAL;
   if (T == 0) return 0;
-  if ((T + F_BM - 1) / F_BM > 65535) return MSAE_ENOTIMPL;
+  if (!n_rows && (T + F_BM - 1) / F_BM > 65535) return MSAE_ENOTIMPL;
   switch (x_dtype) {
     case MSAE_F32: return launch_dt<MSAE_F32>(x, W_enc, b_enc, b_dec, rows, n_rows, T, d, N, relu, out, ld_out, s);
     case MSAE_BF16: return launch_dt<MSAE_BF16>(x, W_enc, b_enc, b_dec, rows, n_rows, T, d, N, relu, out, ld_out, s);

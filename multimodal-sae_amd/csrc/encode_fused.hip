@@ -41,7 +41,18 @@ bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float
 namespace {
 
 constexpr int SAMPLE_STRIDE = 32, SAMPLE_OFF = 13;
-constexpr int FB_MAX = 128;         // tokens the in-call exact fallback can absorb
+// Tokens the in-call exact fallback can absorb: its dense scratch rows are budgeted at 1 GiB
+// (2048 rows at N = 131072), never fewer than 128 and never more than the call has tokens.  The
+// exact kernels take the flagged count from device memory and loop over it, so capacity costs
+// memory, not launches.
+constexpr size_t FB_BUDGET_BYTES = (size_t)1 << 30;
+inline int fallback_capacity(int T, int N) {
+  size_t cap = FB_BUDGET_BYTES / ((size_t)N * 4);
+  const size_t t128 = ((size_t)T + 127) / 128 * 128;
+  if (cap > t128) cap = t128;
+  if (cap < 128) cap = 128;
+  return (int)(cap / 128 * 128);
+}
 constexpr int EXACT_T_MAX = 0;      // fused path for every T (T=1: 1 GiB bf16 stream beats the f32 tile 4x)
 
 // ---- prepared encoder ------------------------------------------------------------------------
@@ -341,7 +352,7 @@ struct RescoreArgs {
   int T, d, N, k, n_rescore, step, r_max;
   int set_feature; float set_value; int zero_feature;
   float *vals; int32_t *idx; int32_t *status;
-  int *flagged; int *n_flagged;
+  int *flagged; int *n_flagged; int fb_cap;
 };
 
 // Wave-wide bitonic sort (descending) of n = power-of-two u64 keys in LDS by ONE 64-lane wave.
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
 #endif
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
-      if (slot < FB_MAX) p.flagged[slot] = t;
+      if (slot < p.fb_cap) p.flagged[slot] = t;
     }
   }
 }
@@ -520,17 +531,17 @@ __global__ void edit_dense_kernel(float *dense, int ld, int rows, const int *n_r
 
 // exact results of the flagged tokens overwrite the fast-path results
 __global__ void scatter_fallback_kernel(const float *fb_vals, const int32_t *fb_idx, const int *flagged,
-                                        const int *n_flagged, int k, float *vals, int32_t *idx,
+                                        const int *n_flagged, int fb_cap, int k, float *vals, int32_t *idx,
                                         int32_t *status) {
-  const int i = blockIdx.x;
-  const int nf = min(*n_flagged, FB_MAX);
-  if (i >= nf) return;
-  const int t = flagged[i];
-  for (int j = threadIdx.x; j < k; j += blockDim.x) {
-    vals[(size_t)t * k + j] = fb_vals[(size_t)i * k + j];
-    idx[(size_t)t * k + j] = fb_idx[(size_t)i * k + j];
+  const int nf = min(*n_flagged, fb_cap);
+  for (int i = blockIdx.x; i < nf; i += gridDim.x) {
+    const int t = flagged[i];
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+      vals[(size_t)t * k + j] = fb_vals[(size_t)i * k + j];
+      idx[(size_t)t * k + j] = fb_idx[(size_t)i * k + j];
+    }
+    if (threadIdx.x == 0 && status) status[t] = 1;
   }
-  if (threadIdx.x == 0 && status) status[t] = 1;
 }
 
 // ---- stage profiling (bench.py roofline): HIP events recorded on the launch stream ------------------
@@ -549,7 +560,7 @@ inline void prof_mark(int i, hipStream_t s) {
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
   bool fast, i8;
-  int Tp, S, r, cap, n_rescore, step, r_max;
+  int Tp, S, r, cap, n_rescore, step, r_max, fb_cap;
   size_t off_xq, off_xqo, off_sx, off_ms, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
       off_fbi, off_dense, bytes;
@@ -599,10 +610,11 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.off_taui = take((size_t)T * p.r * 4);
     p.off_cnt = take((size_t)T * 4);
     p.off_cand = take((size_t)T * p.cap * 8);
-    p.off_flag = take((size_t)(FB_MAX + 64) * 4);
-    p.off_fbdense = take((size_t)FB_MAX * N * 4);
-    p.off_fbv = take((size_t)FB_MAX * k * 4);
-    p.off_fbi = take((size_t)FB_MAX * k * 4);
+    p.fb_cap = fallback_capacity(T, N);
+    p.off_flag = take((size_t)(p.fb_cap + 64) * 4);
+    p.off_fbdense = take((size_t)p.fb_cap * N * 4);
+    p.off_fbv = take((size_t)p.fb_cap * k * 4);
+    p.off_fbi = take((size_t)p.fb_cap * k * 4);
   } else {
     p.off_dense = take((size_t)T * N * 4);
   }
@@ -623,14 +635,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   int *cnt = reinterpret_cast<int *>(ws + pl.off_cnt);
   unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + pl.off_cand);
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
-  int *n_flagged = flagged + FB_MAX;
+  int *n_flagged = flagged + pl.fb_cap;
   float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
   float *fbv = reinterpret_cast<float *>(ws + pl.off_fbv);
   int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
   prof_mark(0, s);
-  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)(FB_MAX + 64),
+  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)(pl.fb_cap + 64),
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
   hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.i8 ? T : pl.Tp, d,
                      pl.i8 ? (unsigned short *)nullptr : xb, a32);
@@ -712,6 +724,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.step = pl.step; ra.r_max = pl.r_max;
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
+    ra.fb_cap = pl.fb_cap;
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
     if (k <= 64) {
@@ -726,16 +739,16 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   }
   prof_mark(5, s);
   // exact recompute of flagged tokens (device-side count; empty grids exit immediately)
-  rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, flagged, n_flagged, FB_MAX, d, N, 1, fbdense,
+  rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, flagged, n_flagged, pl.fb_cap, d, N, 1, fbdense,
                             N, s);
   if (rc) return rc;
   if (set_feature >= 0 || zero_feature >= 0)
-    hipLaunchKernelGGL(edit_dense_kernel, dim3(1), dim3(256), 0, s, fbdense, N, FB_MAX, n_flagged,
+    hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_flagged,
                        set_feature, set_value, zero_feature);
-  rc = msae_topk_launch(fbdense, FB_MAX, N, k, N, n_flagged, fbv, fbi, s);
+  rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_flagged, fbv, fbi, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(scatter_fallback_kernel, dim3(FB_MAX), dim3(64), 0, s, fbv, fbi, flagged,
-                     n_flagged, k, vals, idx, status);
+  hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, flagged,
+                     n_flagged, pl.fb_cap, k, vals, idx, status);
   prof_mark(6, s);
   if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
   return msae_launch_status();

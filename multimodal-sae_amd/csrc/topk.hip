@@ -131,16 +131,17 @@ __device__ __forceinline__ void radix_pass(const float *row, int N, unsigned pre
 
 template <bool VEC>
 __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ latents,
-                                                               int N, int k, int ld,
+                                                               int T, int N, int k, int ld,
                                                                const int *__restrict__ n_rows,
                                                                float *__restrict__ vals,
                                                                int32_t *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (n_rows && (int)blockIdx.x >= *n_rows) return;  // device-side row count (exact fallback)
+  if (n_rows) T = min(T, *n_rows);         // device-side row count (exact fallback)
   TkShared &sh = *reinterpret_cast<TkShared *>(smem_raw);
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem_raw + sizeof(TkShared));
-  const float *row = latents + (size_t)blockIdx.x * ld;
   const int kp = next_pow2(k);
+  for (int rowi = blockIdx.x; rowi < T; rowi += gridDim.x) {   // rows blockIdx.x, +gridDim.x, ...
+  const float *row = latents + (size_t)rowi * ld;
 
   if (threadIdx.x == 0) {
     sh.remaining = (unsigned)k;
@@ -210,8 +211,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
   for (int j = threadIdx.x; j < k; j += TK_THREADS) {
     const unsigned long long kk = keys[j];
     const int ix = rank_key_index(kk);
-    idx[(size_t)blockIdx.x * k + j] = ix;
-    vals[(size_t)blockIdx.x * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
+    idx[(size_t)rowi * k + j] = ix;
+    vals[(size_t)rowi * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
+  }
+  __syncthreads();   // sh / keys are reused by the next row
   }
 }
 
@@ -316,11 +319,12 @@ int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const in
   if (T == 0) return 0;
   const size_t smem = sizeof(TkShared) + (size_t)next_pow2(k) * sizeof(unsigned long long);
   const bool vec = (N % 4 == 0) && (ld % 4 == 0) && msae_aligned(latents, 16);
+  const int grid = (n_rows && T > 128) ? 128 : T;   // device-side count: workgroups loop over the rows
   if (vec)
-    hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(T), dim3(TK_THREADS), smem, s, latents, N, k, ld,
+    hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(grid), dim3(TK_THREADS), smem, s, latents, T, N, k, ld,
                        n_rows, vals, idx);
   else
-    hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(T), dim3(TK_THREADS), smem, s, latents, N, k,
+    hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(grid), dim3(TK_THREADS), smem, s, latents, T, N, k,
                        ld, n_rows, vals, idx);
   return msae_launch_status();
 }

@@ -152,13 +152,32 @@ class Sae(nn.Module):
         return self._prepared
 
     def encode(self, x: Tensor, *, set_feature: int = -1, set_value: float = 0.0,
-               zero_feature: int = -1, return_status: bool = False):
+               zero_feature: int = -1, return_status: bool = False, resolve: bool = True):
         """Fused encode + TopK (sae.py:183-185).  `set_feature/set_value` and `zero_feature` apply
         the steering / attribution hooks' edits of the dense latents (steering.py:113-114,
-        patching/utils.py:43-48) inside the kernel, before TopK."""
+        patching/utils.py:43-48) inside the kernel, before TopK.
+
+        The kernel verifies every token and recomputes the ones it cannot verify (degenerate
+        activations: all-zero rows, fewer than k positive latents, ...) exactly inside the call, up
+        to a scratch budget (csrc/encode_fused.hip:fallback_capacity).  `resolve` (one device->host
+        read of a flag per call) finishes whatever exceeded that budget through the exact dense ops,
+        so the result never depends on how many tokens were degenerate; pass resolve=False in a
+        loop that must not synchronise and inspect `status` (>= 2: unresolved) yourself."""
         acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
                                             self._prepared_weights(), self.cfg.k, set_feature,
                                             float(set_value), zero_feature)
+        if resolve and bool((status >= 2).any()):
+            rows = torch.nonzero(status.reshape(-1) >= 2).flatten()
+            xf = x.reshape(-1, x.shape[-1])
+            av, iv, sv = acts.view(-1, self.cfg.k), idx.view(-1, self.cfg.k), status.view(-1)
+            for part in rows.split(1024):                      # 1024 x N f32 of dense scratch at a time
+                pre = ops.pre_acts(xf[part], self.encoder.weight, self.encoder.bias, self.b_dec)
+                if set_feature >= 0:
+                    pre[:, set_feature] = set_value
+                if zero_feature >= 0:
+                    pre[:, zero_feature] = 0.0
+                av[part], iv[part] = ops.topk(pre, self.cfg.k)
+                sv[part] = 1
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 

@@ -690,3 +690,27 @@ def test_encode_after_train_step_uses_updated_weights(dev):
         ref_v, ref_i = ops.topk(ops.pre_acts(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec), 32)
         assert torch.equal(got.top_indices, ref_i) and torch.equal(got.top_acts, ref_v), mode
     assert not torch.equal(before.top_acts, got.top_acts)
+
+
+def test_many_degenerate_tokens_are_all_recomputed_exactly(dev):
+    """More unverifiable tokens than the in-call exact fallback has scratch rows for (1 GiB: 2048 at
+    N = 131072): the kernel recomputes as many as fit (status 1), reports the rest (status >= 2), and
+    Sae.encode finishes those through the exact dense ops -- the result does not depend on how many
+    tokens were degenerate (zero rows, e.g. masked padding positions)."""
+    from msae import Sae, SaeConfig, ops
+
+    torch.manual_seed(1)
+    d, N, k, T = 128, 131072, 32, 3000
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)   # encoder bias is zero (sae.py:52)
+    x = torch.randn(T, d, device=dev)
+    dead = torch.randperm(T, device=dev)[:2600]
+    x[dead] = 0.0                                             # every pre-activation is exactly 0
+    v_raw, i_raw, st_raw = ops.encode_topk(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec,
+                                           ops.prepare_encoder(sae.encoder.weight), k)
+    st_raw = st_raw.cpu()
+    assert int((st_raw == 1).sum()) == 2048 and int((st_raw >= 2).sum()) == 2600 - 2048
+    out, status = sae.encode(x, return_status=True)
+    assert int((status >= 2).sum()) == 0
+    for part in torch.arange(T, device=dev).split(512):
+        ref_v, ref_i = ops.topk(ops.pre_acts(x[part], sae.encoder.weight, sae.encoder.bias, sae.b_dec), k)
+        assert torch.equal(out.top_indices[part], ref_i) and torch.equal(out.top_acts[part], ref_v)
