@@ -98,8 +98,11 @@ int msae_set_coarse_mode(int mode);
  *   set_feature >= 0 : latents[:, set_feature] = set_value       (steering.py:113-114)
  *   zero_feature >= 0: latents[:, zero_feature] = 0               (patching/utils.py:43-48)
  * status (optional, int32[T]): 0 = fast path verified; 1 = token recomputed by the exact path
- * inside the call; 2 = flagged but not recomputed (more than 128 flagged tokens in one call: the
- * caller re-runs those through msae_pre_acts_f32 + msae_topk_f32). */
+ * inside the call; >= 2 = flagged but not recomputed: more flagged tokens in one call than the
+ * in-call fallback has scratch rows for (1 GiB of f32[rows][N], at least 128, at most T: 2048 at
+ * N = 131072); the caller re-runs those through msae_pre_acts_f32 + msae_topk_f32 (the Python
+ * Sae.encode does).  Bits above 2 tell why the fast path gave up (4 list overflow, 8 threshold
+ * <= 0, 16 fewer than k candidates, 32 guard band). */
 size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,
