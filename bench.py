@@ -46,8 +46,10 @@ SHARDED_LEG_TIMEOUT_S = 240   # watchdog of the second (RCCL) leg; the headline 
 
 
 def make_inputs(dev, T, d, N, seed=0, rows=None):
-    """Synthetic SAE + activations.  `rows` = (lo, hi) slice of the feature axis held by this rank."""
-    g = torch.Generator(device=dev).manual_seed(1234 + seed)
+    """Synthetic SAE + activations.  `rows` = (lo, hi) slice of the feature axis held by this rank.
+    The SAE (weights, biases) is the same on every rank; `seed` only selects the activation batch."""
+    gw = torch.Generator(device=dev).manual_seed(1234)
+    g = torch.Generator(device=dev).manual_seed(4321 + seed)
     lo, hi = rows if rows else (0, N)
     # generate per 8192-row block so every rank draws identical values for its slice
     W_enc = torch.empty(hi - lo, d, device=dev)
@@ -64,8 +66,8 @@ def make_inputs(dev, T, d, N, seed=0, rows=None):
             W_enc[s0 - lo:s1 - lo] = we[s0 - b0:s1 - b0]
             W_dec[s0 - lo:s1 - lo] = wd[s0 - b0:s1 - b0]
         del we, wd
-    b_enc = (torch.randn(N, generator=g, device=dev) * 0.02)[lo:hi].contiguous()
-    b_dec = torch.randn(d, generator=g, device=dev) * 0.1
+    b_enc = (torch.randn(N, generator=gw, device=dev) * 0.02)[lo:hi].contiguous()
+    b_dec = torch.randn(d, generator=gw, device=dev) * 0.1
     x = torch.randn(T, d, generator=g, device=dev) + 0.25 * torch.randn(d, generator=g, device=dev)
     for j in range(4):
         x[:, (j * 977 + 13) % d] *= 20.0

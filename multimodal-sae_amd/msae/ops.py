@@ -166,6 +166,29 @@ def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_f
             x.new_empty(x.shape[:-1], dtype=torch.int32))
 
 
+def encode_topk_resolved(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
+                         prepared: Optional[Tensor], k: int, set_feature: int = -1,
+                         set_value: float = 0.0, zero_feature: int = -1):
+    """encode_topk, then the tokens the call reported as unresolved (status >= 2: more unverifiable
+    tokens than the in-call exact fallback has scratch for) recomputed through the exact dense ops.
+    Costs one device->host flag read per call; results never depend on how many tokens were
+    degenerate."""
+    acts, idx, status = encode_topk(x, W_enc, b_enc, b_dec, prepared, k, set_feature, set_value, zero_feature)
+    if bool((status >= 2).any()):
+        rows = torch.nonzero(status.reshape(-1) >= 2).flatten()
+        xf = x.reshape(-1, x.shape[-1])
+        av, iv, sv = acts.view(-1, k), idx.view(-1, k), status.view(-1)
+        for part in rows.split(1024):                          # 1024 x N f32 of dense scratch at a time
+            pre = pre_acts(xf[part], W_enc, b_enc, b_dec)
+            if set_feature >= 0:
+                pre[:, set_feature] = set_value
+            if zero_feature >= 0:
+                pre[:, zero_feature] = 0.0
+            av[part], iv[part] = topk(pre, k)
+            sv[part] = 1
+    return acts, idx, status
+
+
 # ---- decoder (differentiable, mirrors TritonDecoder: kernels.py:403-429) ---------------------------
 def _idx32(top_indices: Tensor) -> Tensor:
     return top_indices.detach().to(torch.int32).contiguous()
@@ -304,7 +327,7 @@ class _SparseEncode(torch.autograd.Function):
             # no AuxK term: the fused encoder gives the canonical top-max(k, 4k); the top-k is its
             # prefix (same order), and the dense [T, N] latents are never built
             kk = max(k, k_multi)
-            v, i, _ = encode_topk(x, W_enc, b_enc, b_dec, _refresh_train_operands(W_enc), kk)
+            v, i, _ = encode_topk_resolved(x, W_enc, b_enc, b_dec, _refresh_train_operands(W_enc), kk)
             vals.append(v[..., :k].contiguous()); idxs.append(i[..., :k].contiguous())
             if k_multi > 0:
                 vals.append(v); idxs.append(i)

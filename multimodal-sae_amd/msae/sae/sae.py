@@ -163,21 +163,10 @@ class Sae(nn.Module):
         read of a flag per call) finishes whatever exceeded that budget through the exact dense ops,
         so the result never depends on how many tokens were degenerate; pass resolve=False in a
         loop that must not synchronise and inspect `status` (>= 2: unresolved) yourself."""
-        acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
-                                            self._prepared_weights(), self.cfg.k, set_feature,
-                                            float(set_value), zero_feature)
-        if resolve and bool((status >= 2).any()):
-            rows = torch.nonzero(status.reshape(-1) >= 2).flatten()
-            xf = x.reshape(-1, x.shape[-1])
-            av, iv, sv = acts.view(-1, self.cfg.k), idx.view(-1, self.cfg.k), status.view(-1)
-            for part in rows.split(1024):                      # 1024 x N f32 of dense scratch at a time
-                pre = ops.pre_acts(xf[part], self.encoder.weight, self.encoder.bias, self.b_dec)
-                if set_feature >= 0:
-                    pre[:, set_feature] = set_value
-                if zero_feature >= 0:
-                    pre[:, zero_feature] = 0.0
-                av[part], iv[part] = ops.topk(pre, self.cfg.k)
-                sv[part] = 1
+        fn = ops.encode_topk_resolved if resolve else ops.encode_topk
+        acts, idx, status = fn(x, self.encoder.weight, self.encoder.bias, self.b_dec,
+                               self._prepared_weights(), self.cfg.k, set_feature, float(set_value),
+                               zero_feature)
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 
