@@ -249,7 +249,13 @@ def main():
                                group=dist.group.WORLD,
                                force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
             el_f, out_f, _, _ = timed(eng_f, x0, args.steps, args.warmup, profile=False)
+            # the merged result against this rank's own full-width encode of the same tokens
+            # (every rank holds the whole SAE in the headline mode): bit-identical or it is a bug
+            chk_v, chk_i, _ = ops.encode_topk(x0[:256], W_enc, b_enc, b_dec, ops.prepare_encoder(W_enc), k)
+            same = bool(torch.equal(chk_i, out_f["top_indices"][:256]) and
+                        torch.equal(chk_v, out_f["top_acts"][:256]))
             feature = {"value": T * args.steps / el_f, "unit": "tokens/s", "ms_per_step": el_f / args.steps * 1e3,
+                       "bit_identical_to_single_gpu_on_256_tokens": same,
                        "scaling": "strong", "tokens_per_step": T, "k_loc": eng_f.k_loc,
                        "second_round_tokens": eng_f.second_round_tokens,
                        "parallelism": f"feature-sharded x{world}: per-shard exact top-k_loc, RCCL all-gather + merge, "

@@ -471,6 +471,8 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
+    fs = res["feature_sharded"]
+    assert "error" not in fs and fs["value"] > 0 and fs["bit_identical_to_single_gpu_on_256_tokens"] is True
 
 
 @pytest.mark.parametrize("T,G,kl,k", [(100, 8, 16, 32), (33, 2, 32, 32), (17, 4, 24, 32), (5, 8, 64, 256)])
