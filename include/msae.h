@@ -29,9 +29,12 @@
  * Numerics contract: all dot products are ascending-k f32 fused
  * multiply-add chains (v_mfma_f32_32x32x2_f32 / v_fma_f32), bit-identical to oracle/sae_oracle.c.
  * msae_encode_topk selects candidates with an int8 (or bf16) MFMA pass and re-scores them with the exact f32
- * chain, so its outputs are bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever its
- * per-token guard band holds; tokens where it does not are reported in `status` and recomputed
- * by the exact path inside the same call.
+ * chain, so its outputs are bit-identical to msae_pre_acts_f32 + msae_topk_f32 for every token it
+ * VERIFIES: all features whose coarse value plus z sigma(token, feature) of the operand type's
+ * rounding noise reaches the exact k-th value were re-scored (z = 7: a feature is missed only if its
+ * own error exceeds 7 of its own sigma, < 3e-13 per token; every re-scored pair also checks the
+ * error model).  Tokens it cannot verify are reported in `status` and recomputed by the exact path
+ * inside the same call.
  */
 #ifndef MSAE_H_
 #define MSAE_H_
@@ -93,17 +96,25 @@ int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void 
  * environment variable MSAE_COARSE=bf16|int8 sets the initial value.  Changes the workspace size. */
 int msae_set_coarse_mode(int mode);
 
+/* Width z of the error band of the candidate pass, in standard deviations of its per-(token,
+ * feature) rounding noise (default 7; 1 <= z <= 64; environment MSAE_GUARD_Z sets the initial value).
+ * A larger z re-scores more rows per token; results of verified tokens do not depend on it. */
+int msae_set_guard_z(float z);
+
 /* Fused Sae.encode: vals/idx[T][k] = canonical top-k of relu((x - b_dec) W_enc^T + b_enc), with
  * the reference hooks' edits of the dense latents applied before TopK:
  *   set_feature >= 0 : latents[:, set_feature] = set_value       (steering.py:113-114)
  *   zero_feature >= 0: latents[:, zero_feature] = 0               (patching/utils.py:43-48)
  * status (optional, int32[T]): 0 = fast path verified; 1 = token recomputed by the exact path
- * inside the call; >= 2 = flagged but not recomputed: more flagged tokens in one call than the
- * in-call fallback has scratch rows for (1 GiB of f32[rows][N], at least 128, at most T: 2048 at
- * N = 131072); the caller re-runs those through msae_pre_acts_f32 + msae_topk_f32 (the Python
- * Sae.encode does).  Bits above 2 tell why the fast path gave up (4 list overflow, 8 threshold
- * <= 0, 16 fewer than k candidates, 32 guard band). */
+ * inside the call (every flagged token is: the fallback runs ceil(T / rows) passes over a 1 GiB
+ * scratch of f32[rows][N], 2048 rows at N = 131072, sized on the device -- no host round trip).
+ * Values >= 2 exist only between the kernels of one call: 2 | reason bits (4 list overflow, 8
+ * threshold <= 0, 16 fewer than k candidates, 32 too many rows inside the band, 64 a re-scored pair
+ * was more than 6 sigma from its coarse value: the error model does not describe this token). */
 size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k);
+/* Diagnostics (tools/soak_fused.py): with detail on, a token recomputed inside the call reports
+ * status = 1 | reason << 8 (reason = the bits above) instead of 1, so `status & 0xFF` is the code. */
+int msae_set_status_detail(int on);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,
                      int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,

@@ -13,18 +13,33 @@
 //   4. gemm<THRESH>  THE DOMINANT KERNEL (gemm_mfma.h): [T][d] x [d][N] on the matrix cores;
 //                    epilogue: scales, +b_enc, compare with tau[t], append (feature, coarse) of the
 //                    rare survivors to a per-token candidate list.  Roofline: MFMA, 2*d*N op/token.
-//   5. select_rescore per token: order candidates by coarse value, re-score the best k+extra with
-//                    the exact ascending-k f32 fma chain over the f32 W_enc rows, take the
-//                    canonical top-k, and verify the guard band
-//                        v_k(exact) > max(best non-rescored coarse, tau) + eps_t,
-//                    eps_t = 4 * max|coarse - exact| measured on the re-scored set, extending the
-//                    set (16, 32, 64 ... more) while it fails.  Tokens that still fail (or
-//                    overflowed / had tau <= 0) are flagged.
+//   5. select_rescore per token: order candidates by their UPPER value u, re-score the best ones
+//                    with the exact ascending-k f32 fma chain over the f32 W_enc rows, take the
+//                    canonical top-k, and verify that EVERY feature whose u reaches the exact
+//                    k-th value v_k has been re-scored (at most one extension round).  Tokens
+//                    that fail (list overflow, tau <= 0, model violation ...) are flagged.
 //   6. exact path    flagged tokens (normally none) are recomputed by encode_f32 + topk through a
 //                    device-side row list; their results overwrite step 5's.
 //
-// Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the guard
-// band holds, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
+// Verification model.  The coarse value c(t,n) of the candidate pass differs from the exact
+// pre-activation p(t,n) by rounding noise whose variance is known per (token, feature) PAIR:
+//   int8:  p - c = sum_c [ a_c sw_n eps_c + sx_t delta_c w_c ],  eps, delta = rounding residuals in
+//          (-1/2, 1/2] steps (delta in m_t steps on the outlier dims), so
+//          sigma^2(t,n) = sw_n^2 |a_t|^2 / 12 + sx_t^2 (|W_n[in]|^2 + m_t^2 |W_n[out]|^2) / 12
+//   bf16:  p - c = -sum_c a_c w_c (da_c + dw_c), relative roundings of variance 2.75e-6 each, so
+//          sigma^2(t,n) <= 5.5e-6 |a_t|_4^2 |W_n|_4^2   (Cauchy-Schwarz on sum a_c^2 w_c^2)
+// both of the separable form  z^2 sigma^2 = P_t Q_n + R_t (Si_n + M_t So_n).  Every stage works on
+// u = c + z sigma (z = 7 by default): the sample threshold tau is a rank statistic of u, the GEMM
+// emits u > tau, and a token is verified when all features with u >= v_k were re-scored exactly --
+// a feature is then missed only if its own error exceeds z of ITS sigma (heterogeneous rows: spiky,
+// large-norm or near-dead encoder rows carry their own band).  Rows whose bulk lies below one int8
+// step (max > 127 rms) are rounded stochastically (hash dither), which keeps the residual unbiased
+// whatever direction the activations have, at variance sw^2/4.  The model is CHECKED on every
+// re-scored pair: |p - c| > 6 sigma flags the token (reason 64) and it goes to the exact path.
+// DESIGN.md section 4 gives the failure-probability arithmetic.
+//
+// Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the token
+// verifies, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
 #include <cstdlib>
 
 #include "common.h"
@@ -41,10 +56,11 @@ bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float
 namespace {
 
 constexpr int SAMPLE_STRIDE = 32, SAMPLE_OFF = 13;
-// Tokens the in-call exact fallback can absorb: its dense scratch rows are budgeted at 1 GiB
+// Tokens one pass of the in-call exact fallback absorbs: its dense scratch rows are budgeted at 1 GiB
 // (2048 rows at N = 131072), never fewer than 128 and never more than the call has tokens.  The
-// exact kernels take the flagged count from device memory and loop over it, so capacity costs
-// memory, not launches.
+// exact kernels take the flagged count from device memory and loop over it; ceil(T / capacity) passes
+// are enqueued (the ones without work exit at once), so EVERY flagged token is recomputed inside the
+// call whatever their number -- no host round trip, no "unresolved" leftovers.
 constexpr size_t FB_BUDGET_BYTES = (size_t)1 << 30;
 inline int fallback_capacity(int T, int N) {
   size_t cap = FB_BUDGET_BYTES / ((size_t)N * 4);
@@ -59,7 +75,7 @@ constexpr int EXACT_T_MAX = 0;      // fused path for every T (T=1: 1 GiB bf16 s
 struct Prepared {
   unsigned magic;
   int N, d, S;
-  size_t off_wb, off_ws, off_sw, off_wq, off_wqs, bytes;
+  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, bytes;
 };
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 
@@ -68,7 +84,8 @@ __host__ __device__ inline bool fast_shape_ok(int N, int d) {
 }
 __host__ __device__ inline bool i8_shape_ok(int N, int d) { return fast_shape_ok(N, d) && d % 128 == 0; }
 
-// 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | sw f32 [N] | Wq int8 [N][d] | sample int8 [S][d]
+// 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | row statistics (sw, Q_i8, |W_n|^2, Q_bf) f32x4 [N]
+// and [S] | bf16-pass column constants (1, Q_bf, 0, 0) f32x4 [N] and [S] | Wq int8 [N][d] | sample int8 [S][d]
 inline Prepared make_prepared(int N, int d) {
   Prepared p{};
   p.magic = PREP_MAGIC;
@@ -79,7 +96,10 @@ inline Prepared make_prepared(int N, int d) {
   p.off_wb = take(p.S ? (size_t)N * d * 2 : 0);
   p.off_ws = take((size_t)p.S * d * 2);
   const bool q = p.S && i8_shape_ok(N, d);
-  p.off_sw = take(q ? (size_t)N * 4 : 0);
+  p.off_wstat = take(p.S ? (size_t)N * 16 : 0);
+  p.off_wstat_s = take((size_t)p.S * 16);
+  p.off_colbf = take(p.S ? (size_t)N * 16 : 0);
+  p.off_colbf_s = take((size_t)p.S * 16);
   p.off_wq = take(q ? (size_t)N * d : 0);
   p.off_wqs = take(q ? (size_t)p.S * d : 0);
   p.bytes = o;
@@ -94,6 +114,30 @@ inline int coarse_mode() {
     g_coarse_mode = (e && e[0] == 'b') ? 0 : 1;
   }
   return g_coarse_mode;
+}
+
+int g_status_detail = 0;   // msae_set_status_detail
+
+// ---- width of the error band: u = coarse + z*sigma (MSAE_GUARD_Z / msae_set_guard_z; default 7) ----------
+float g_guard_z = -1.f;
+inline float guard_z() {
+  if (g_guard_z < 0.f) {
+    const char *e = getenv("MSAE_GUARD_Z");
+    const float v = e ? (float)atof(e) : 0.f;
+    g_guard_z = (v >= 1.f && v <= 64.f) ? v : 7.f;
+  }
+  return g_guard_z;
+}
+constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
+constexpr float GUARD_ZETA = 1.f;         // first round reaches zeta sigma below the k-th coarse value
+constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
+
+// z^2 sigma^2 of one (token, feature) pair; rc = (sx, m, P, -), cc = (sw, Q, Si, So).  Same expression as the
+// GEMM epilogue (gemm_mfma.h).
+__device__ __forceinline__ float band_sq(const f32x4 rc, const f32x4 cc, float zz12, bool i8) {
+  if (!i8) return rc[2] * cc[1];
+  const float rz = rc[0] * rc[0] * zz12;
+  return __builtin_fmaf(rc[2], cc[1], __builtin_fmaf(rz * rc[1] * rc[1], cc[3], rz * cc[2]));
 }
 
 // W_bf16[n][c] = bf16(W[n][c]); sample row j = row j*SAMPLE_STRIDE + SAMPLE_OFF.  grid-stride over 8-element groups.
@@ -140,45 +184,83 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
   }
 }
 
-// ---- int8 operands -----------------------------------------------------------------------------------
-// W side (once per weight load): sw[n] = max|W[n][:]| / 127, Wq[n][c] = rint(W[n][c] / sw[n]).
-// One 256-thread workgroup per row; d % 128 == 0.
-__global__ __launch_bounds__(256) void quant_w_kernel(const float *__restrict__ W, int N, int d,
-                                                      float *__restrict__ sw, signed char *__restrict__ wq,
-                                                      signed char *__restrict__ wqs) {
-  __shared__ float red[4];
+// ---- per-row statistics + int8 operands ---------------------------------------------------------------
+// W side (once per weight load), one 256-thread workgroup per row:
+//   sw[n] = max|W[n][:]| / 127,  |W_n|^2,  |W_n|_4^2 = sqrt(sum w^4)   -> wstat[n] = (sw, Q_i8, |W_n|^2, Q_bf)
+//   Wq[n][c] = rint(W[n][c] / sw[n])   (QUANT; d % 128 == 0)
+// A row whose rms lies below one step (max > 127 rms: its bulk quantises to 0, +-1) would leave a
+// STRUCTURED residual (the bulk itself), so such rows are rounded stochastically with a hash dither:
+// floor(s + r(n, c)), r uniform in [0, 1) -- unbiased for any activation direction, residual variance
+// <= 1/4 step^2 instead of 1/12: Q_i8 = 3 sw^2 for them.
+__device__ __forceinline__ float hash01(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
+}
+template <bool QUANT>
+__global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__restrict__ W, int N, int d,
+                                                              f32x4 *__restrict__ wstat, f32x4 *__restrict__ wstat_s,
+                                                              f32x4 *__restrict__ colbf, f32x4 *__restrict__ colbf_s,
+                                                              signed char *__restrict__ wq,
+                                                              signed char *__restrict__ wqs) {
+  __shared__ float red[3][4];
   const int n = blockIdx.x;
   const float *row = W + (size_t)n * d;
-  float m = 0.f;
+  float m = 0.f, s2 = 0.f, s4 = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
-    m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float q = v[e] * v[e];
+      m = fmaxf(m, fabsf(v[e]));
+      s2 += q;
+      s4 = __builtin_fmaf(q, q, s4);
+    }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  for (int off = 32; off > 0; off >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, off, 64));
+    s2 += __shfl_xor(s2, off, 64);
+    s4 += __shfl_xor(s4, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s4; }
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float scale = m > 0.f ? m / 127.f : 1.f;
-  if (threadIdx.x == 0) sw[n] = scale;
-  const float inv = 1.f / scale;
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  s4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  const float scale = m > 0.f ? m / 127.f : 0.f;          // an all-zero row: coarse value = bias exactly, no band
+  const bool dither = s2 < scale * scale * (float)d;       // rms below one step
   const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
-  for (int c = threadIdx.x * 16; c < d; c += 4096) {
-    i32x4 packed;
+  if (threadIdx.x == 0) {
+    const float q_bf = __builtin_sqrtf(s4);
+    const f32x4 st = {scale, scale * scale * (dither ? 3.f : 1.f), s2, q_bf};
+    const f32x4 cb = {1.f, q_bf, 0.f, 0.f};
+    wstat[n] = st;
+    colbf[n] = cb;
+    if (samp) { wstat_s[n / SAMPLE_STRIDE] = st; colbf_s[n / SAMPLE_STRIDE] = cb; }
+  }
+  if constexpr (QUANT) {
+    const float inv = m > 0.f ? 1.f / scale : 0.f;
+    for (int c = threadIdx.x * 16; c < d; c += 4096) {
+      i32x4 packed;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q);
-      unsigned w = 0;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q);
+        unsigned w = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int iv = (int)rintf(v[e] * inv);
-        iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
-        w |= ((unsigned)iv & 0xFFu) << (8 * e);
+        for (int e = 0; e < 4; ++e) {
+          const float sv = v[e] * inv;
+          int iv = dither ? (int)floorf(sv + hash01((unsigned long long)n * (unsigned)d + (unsigned)(c + 4 * q + e)))
+                          : (int)rintf(sv);
+          iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
+          w |= ((unsigned)iv & 0xFFu) << (8 * e);
+        }
+        packed[q] = (int)w;
       }
-      packed[q] = (int)w;
+      *reinterpret_cast<i32x4 *>(wq + (size_t)n * d + c) = packed;
+      if (samp) *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
     }
-    *reinterpret_cast<i32x4 *>(wq + (size_t)n * d + c) = packed;
-    if (samp) *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
   }
 }
 
@@ -241,29 +323,31 @@ __global__ __launch_bounds__(1024) void pick_outliers_kernel(const unsigned *__r
   }
 }
 
-// one workgroup per token row (rows >= T of the padded tile are zero): per-token scales and int8 rows
+// one workgroup per token row (rows >= T of the padded tile are zero): per-token scales, int8 rows and
+// the row constants of the error band, rowc[t] = (sx, m, P = z^2 |a_t|^2 / 12, 0)
 __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ a32, int T, int d,
                                                       const int *__restrict__ odims,
                                                       const unsigned char *__restrict__ is_out,
                                                       signed char *__restrict__ xq,
                                                       signed char *__restrict__ xqo,
-                                                      float *__restrict__ sx, int *__restrict__ mscale) {
-  __shared__ float red[2][4];
+                                                      f32x4 *__restrict__ rowc, float zz12) {
+  __shared__ float red[3][4];
   const int t = blockIdx.x;
   if (t >= T) {
     for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(xq + (size_t)t * d + c) = i32x4{0, 0, 0, 0};
     if (threadIdx.x < 8) *reinterpret_cast<i32x4 *>(xqo + (size_t)t * MAX_OUT + threadIdx.x * 16) = i32x4{0, 0, 0, 0};
-    if (threadIdx.x == 0) { sx[t] = 0.f; mscale[t] = 1; }
+    if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
   }
   const float *row = a32 + (size_t)t * d;
-  float m_in = 0.f, m_out = 0.f;
+  float m_in = 0.f, m_out = 0.f, ss = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
     const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float av = fabsf(v[e]);
+      ss = __builtin_fmaf(av, av, ss);
       if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else m_in = fmaxf(m_in, av);
     }
   }
@@ -271,15 +355,17 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
   for (int off = 32; off > 0; off >>= 1) {
     m_in = fmaxf(m_in, __shfl_xor(m_in, off, 64));
     m_out = fmaxf(m_out, __shfl_xor(m_out, off, 64));
+    ss += __shfl_xor(ss, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m_in; red[1][threadIdx.x >> 6] = m_out; }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m_in; red[1][threadIdx.x >> 6] = m_out; red[2][threadIdx.x >> 6] = ss; }
   __syncthreads();
   m_in = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
   m_out = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  ss = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
   const float scale = m_in > 0.f ? m_in / 127.f : (m_out > 0.f ? m_out / 127.f : 1.f);
   int m = (int)ceilf(m_out / (127.f * scale));
   m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
-  if (threadIdx.x == 0) { sx[t] = scale; mscale[t] = m; }
+  if (threadIdx.x == 0) rowc[t] = f32x4{scale, (float)m, zz12 * ss, 0.f};
   const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
   for (int c = threadIdx.x * 16; c < d; c += 4096) {
     i32x4 packed;
@@ -306,18 +392,42 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
   }
 }
 
-// Wq_o[n][j] = Wq[n][odims[j]] (0 where odims[j] < 0) for every feature row, and for the sample rows
+// bf16 pass: rowc[t] = (1, 1, P = z^2 * 5.5e-6 * |a_t|_4^2, 0); one 256-thread workgroup per token
+__global__ __launch_bounds__(256) void row_p4_kernel(const float *__restrict__ a32, int T, int d,
+                                                     f32x4 *__restrict__ rowc, float z2) {
+  __shared__ float red[4];
+  const int t = blockIdx.x;
+  const float *row = a32 + (size_t)t * d;
+  float s4 = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float q = v[e] * v[e]; s4 = __builtin_fmaf(q, q, s4); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s4 += __shfl_xor(s4, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s4;
+  __syncthreads();
+  s4 = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) rowc[t] = f32x4{1.f, 1.f, z2 * BF16_REL_VAR2 * __builtin_sqrtf(s4), 0.f};
+}
+
+// Wq_o[n][j] = Wq[n][odims[j]] (0 where odims[j] < 0) for every feature row, and for the sample rows;
+// with it the column constants of the error band for THIS batch's outlier dims:
+//   colc[n] = (sw, Q, Si = |W_n|^2 - So, So = sum over outlier dims of (sw Wq)^2)
 __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__restrict__ wq, int N, int d,
                                                         const int *__restrict__ odims,
+                                                        const f32x4 *__restrict__ wstat,
                                                         signed char *__restrict__ wqo,
-                                                        signed char *__restrict__ wqos) {
+                                                        signed char *__restrict__ wqos,
+                                                        f32x4 *__restrict__ colc, f32x4 *__restrict__ colc_s) {
   __shared__ int s_dims[MAX_OUT];
   if (threadIdx.x < MAX_OUT) s_dims[threadIdx.x] = odims[threadIdx.x];
   __syncthreads();
-  const int n = blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads per row, 16 bytes each
-  if (n >= N) return;
+  const int n = blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads per row, 16 bytes each (N % 32 == 0)
   const int j0 = (threadIdx.x & 7) * 16;
   i32x4 packed = {0, 0, 0, 0};
+  int sq = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     unsigned w = 0;
@@ -325,13 +435,24 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
     for (int e = 0; e < 4; ++e) {
       const int dim = s_dims[j0 + 4 * q + e];
       const int v = dim >= 0 ? (int)wq[(size_t)n * d + dim] : 0;
+      sq += v * v;
       w |= ((unsigned)v & 0xFFu) << (8 * e);
     }
     packed[q] = (int)w;
   }
+  sq += __shfl_xor(sq, 1, 64);
+  sq += __shfl_xor(sq, 2, 64);
+  sq += __shfl_xor(sq, 4, 64);
+  const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
   *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
-  if ((n % SAMPLE_STRIDE) == SAMPLE_OFF)
-    *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
+  if (samp) *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
+  if ((threadIdx.x & 7) == 0) {
+    const f32x4 st = wstat[n];
+    const float so = st[0] * st[0] * (float)sq;
+    const f32x4 cc = {st[0], st[1], fmaxf(st[2] - so, 0.f), so};
+    colc[n] = cc;
+    if (samp) colc_s[n / SAMPLE_STRIDE] = cc;
+  }
 }
 
 // ---- MFMA GEMM: gemm_mfma.h.  Tile choice from tools/gemm_sweep on MI355X (T=8192, d=4096,
@@ -349,8 +470,10 @@ struct RescoreArgs {
   const float *a32; const float *W_enc, *b_enc;
   const float *tau_vals; int tau_ld, tau_col;
   const int *cnt; const unsigned long long *cand; int cap;
-  int T, d, N, k, n_rescore, step, r_max;
+  int T, d, N, k, r_max;
   int set_feature; float set_value; int zero_feature;
+  const f32x4 *rowc, *colc;           // error-band constants per token / per feature
+  float zz12, z2; int i8;
   float *vals; int32_t *idx; int32_t *status;
   int *flagged; int *n_flagged; int fb_cap;
 };
@@ -371,20 +494,36 @@ __device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n,
   __syncthreads();
 }
 
-// ONE WAVE per token (64-thread workgroup).  dynamic LDS: keys[cap] u64 | res[nrp] u64.
+// number of keys (sorted descending, value in the upper 32 bits as an order key) whose value is >= v
+__device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, float v) {
+  const unsigned tk = f32_order_key(v);
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((unsigned)(keys[mid] >> 32) >= tk) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ONE WAVE per token (64-thread workgroup; 4 waves for k > 64).  dynamic LDS: keys[cap] u64 | res[nrp] u64.
 //
-// The candidate list is ordered by coarse value; lane c re-scores candidate c with the exact
-// ascending-k f32 chain: it walks row f of W_enc with two software-pipelined batches of 16 x 16-B
-// loads (256 B = two lines per batch) while the token's f32 activation vector a32[t][:] arrives
-// through wave-uniform scalar loads.  No LDS staging of operands: the data in flight lives in
-// VGPRs (7 waves x ~52 lanes x 512 B = ~186 KB per CU), which is what keeps the HBM pipe full --
-// streaming the rows through LDS instead caps it at the ring size and measured 2.5 ms vs 1.4.
-// HBM-bound: ~57 rows x d x 4 B per token.
+// The candidate list is ordered by the UPPER value u = coarse + z*sigma; lane c re-scores candidate c
+// with the exact ascending-k f32 chain: it walks row f of W_enc with two software-pipelined batches
+// of 16 x 16-B loads (256 B = two lines per batch) while the token's f32 activation vector a32[t][:]
+// arrives through wave-uniform scalar loads.  No LDS staging of operands: the data in flight lives in
+// VGPRs (7 waves x ~45 lanes x 512 B per CU), which is what keeps the HBM pipe full -- streaming the
+// rows through LDS instead caps it at the ring size and measured 2.5 ms vs 1.4.
+// HBM-bound: ~42 rows x d x 4 B per token.
 //
-// Rounds: the best `n_rescore` candidates are re-scored; if the guard band
-//     v_k(exact) > max(best not-yet-rescored coarse, tau) + eps,   eps = 4 * max|coarse - exact|
-// does not hold and candidates remain, the next `step` (doubling) are re-scored too, up to `r_max`.  Tokens
-// that still fail (or overflowed their list / have tau <= 0) go to the exact path.
+// Rounds.  Needed are exactly the candidates with u >= v_k (the exact k-th value): everything else
+// has p <= u < v_k.  v_k is not known beforehand, so round 1 takes the candidates with
+//     u >= (k-th largest coarse value among the first NT) - zeta * (their median sigma)
+// (the lanes look up the band of "their" candidate to get coarse = u - z*sigma), which is the needed
+// set plus about one row in 96 % of the tokens; the exact v_k of round 1 is a lower bound of the final
+// one, so ONE extension to every u >= v_k completes the rest.  A token verifies when
+//     all candidates with u >= v_k are re-scored  and  v_k > tau  (non-candidates have u <= tau)
+// and no re-scored pair contradicted the error model (|p - coarse| <= 6 sigma).  Tokens that fail (or
+// overflowed their list / have tau <= 0 / more than r_max rows to read) go to the exact path.
 template <int NW>   // waves per token: 1 for k <= 64, 4 for larger k (longer lists, more rows per round)
 __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
@@ -393,41 +532,79 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const int nrp = next_pow2(p.r_max + 1);
   unsigned long long *res = keys + p.cap;
   constexpr int NT = 64 * NW;
+  __shared__ float s_cc[NT], s_zs[NT], s_pick[2];
   const int lane = threadIdx.x;   // thread index within the token's workgroup
   const int t = blockIdx.x;
   const int cnt = p.cnt[t];
   const int n = cnt < p.cap ? cnt : p.cap;
   const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
   const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
+  const f32x4 rc = p.rowc[t];
+  const bool i8 = p.i8 != 0;
 
   const int np = next_pow2(n > 2 ? n : 2);
   for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
   for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
-  wave_sort_desc_u64<NT>(keys, np, lane);   // coarse value desc (index asc on ties)
+  wave_sort_desc_u64<NT>(keys, np, lane);   // upper value desc (index asc on ties)
   const int has_set = p.set_feature >= 0 ? 1 : 0;
   if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
 
-  float my_err = 0.f;
-  int step = p.step;
+  // ---- size of the first round ------------------------------------------------------------------
+  const int lim = n < p.r_max ? n : p.r_max;
+  int target = lim;
+  {
+    const int mt = n < NT ? n : NT;
+    float my_cc = -__builtin_inff(), my_zs = 0.f;
+    if (lane < mt) {
+      const unsigned long long key = keys[lane];
+      my_zs = __builtin_sqrtf(band_sq(rc, p.colc[rank_key_index(key)], p.zz12, i8));
+      my_cc = f32_from_order_key((unsigned)(key >> 32)) - my_zs;
+    }
+    s_cc[lane] = my_cc;
+    s_zs[lane] = my_zs;
+    if (lane < 2) s_pick[lane] = lane == 0 ? -__builtin_inff() : 0.f;
+    __syncthreads();
+    const int kk = p.k - has_set;
+    if (lane < mt && kk >= 1 && kk <= mt) {
+      int rank_c = 0, rank_z = 0;
+      for (int j = 0; j < mt; ++j) {
+        const float cj = s_cc[j], zj = s_zs[j];
+        rank_c += (cj > my_cc || (cj == my_cc && j < lane)) ? 1 : 0;
+        rank_z += (zj < my_zs || (zj == my_zs && j < lane)) ? 1 : 0;
+      }
+      if (rank_c == kk - 1) s_pick[0] = my_cc;
+      if (rank_z == mt / 2) s_pick[1] = my_zs;
+    }
+    __syncthreads();
+    if (kk >= 1 && kk <= mt && p.z2 > 0.f) {
+      const float thr1 = s_pick[0] - GUARD_ZETA * s_pick[1] * __builtin_amdgcn_rsqf(p.z2);
+      int n1 = count_ge(keys, n, thr1);
+      if (n1 < p.k + 4) n1 = p.k + 4;
+      target = n1 < lim ? n1 : lim;
+    }
+  }
+
+  const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
-  int target = n < p.n_rescore ? n : p.n_rescore;
-  bool ok = false;
+  bool ok = false, viol = false;
   int rounds = 0;
   const int first_target = target;
   (void)first_target; (void)rounds;
   for (;;) {
     ++rounds;
+    int my_viol = 0;
     for (int c0 = done; c0 < target; c0 += NT) {
       const int c = c0 + lane;
       const bool active = c < target;
       const unsigned long long key = active ? keys[c] : keys[c0];
       const int f = rank_key_index(key);
-      const float coarse = f32_from_order_key((unsigned)(key >> 32));
+      const float upper = f32_from_order_key((unsigned)(key >> 32));
+      const f32x4 cc = p.colc[f];
       const float *__restrict__ w = W_enc + (size_t)f * p.d;
       float acc = 0.f;
       // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
       // other is in flight, so the lane never drains its loads (bytes in flight per CU are what
-      // bounds this kernel: ~7 waves/CU x 48 lanes x RS_U..2*RS_U x 16 B against ~64 KB needed)
+      // bounds this kernel: ~7 waves/CU x 45 lanes x RS_U..2*RS_U x 16 B against ~64 KB needed)
       constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U;   // floats per batch
       f32x4 wa[RS_U], wb[RS_U];
       auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
@@ -454,36 +631,22 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
       if (active) {
         res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
-        my_err = fmaxf(my_err, fabsf(pre - coarse));
+        // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
+        const float zs2 = band_sq(rc, cc, p.zz12, i8);
+        const float diff = pre - (upper - __builtin_sqrtf(zs2));
+        if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
       }
     }
     done = target;
-    float maxerr = my_err;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxerr = fmaxf(maxerr, __shfl_xor(maxerr, off, 64));
-    if constexpr (NW > 1) {   // combine the waves' maxima through LDS (behind res[])
-      float *werr = reinterpret_cast<float *>(res + nrp);
-      __syncthreads();
-      if ((lane & 63) == 0) werr[lane >> 6] = maxerr;
-      __syncthreads();
-      maxerr = werr[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) maxerr = fmaxf(maxerr, werr[w]);
-    }
+    viol = viol || (__syncthreads_or(my_viol) != 0);
     wave_sort_desc_u64<NT>(res, nrp, lane);
-    const float eps = 4.f * maxerr + 1e-30f;
-    const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
-    float bound = tau;
-    if (n > done) bound = fmaxf(bound, f32_from_order_key((unsigned)(keys[done] >> 32)));
     const bool have_k = done + has_set >= p.k;
-    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && (v_k > bound + eps);
-    if (ok || done >= n || done >= p.r_max || !(tau > 0.f) || cnt > p.cap) break;
-    // extend the re-scored set; steps double.  (Measured: constant steps of 8 after a k+8 first
-    // round cost 2.2 ms instead of 1.55 ms -- round latency with few active lanes is not free.)
-    target = done + step;
-    step *= 2;
-    if (target > n) target = n;
-    if (target > p.r_max) target = p.r_max;
+    const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
+    const int needed = have_k ? count_ge(keys, n, v_k) : n;     // candidates with u >= v_k
+    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f;
+    if (ok || viol || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
+    target = needed > done ? needed : done + 1;
+    if (target > lim) target = lim;
     __syncthreads();
   }
 
@@ -494,9 +657,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   }
   if (lane == 0) {
     // not verified: 2 | reason bits (4 list overflow, 8 tau <= 0, 16 fewer than k candidates,
-    // 32 guard band still violated); the exact fallback rewrites it to 1 once it has recomputed t
+    // 32 more than r_max rows needed / v_k not above tau, 64 a re-scored pair contradicted the error
+    // model); the exact fallback rewrites it to 1 once it has recomputed t
     const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
-                       (done + has_set < p.k ? 16 : 0) | 32;
+                       (done + has_set < p.k ? 16 : 0) | (viol ? 64 : 32);
     if (p.status) p.status[t] = ok ? 0 : reason;
 #ifdef MSAE_RESCORE_DEBUG   // rows / rounds histogram (tools/rescore_stats.py); breaks the status contract
     if (p.status && ok) p.status[t] = (rounds << 24) | (first_target << 12) | done;
@@ -529,10 +693,19 @@ __global__ void edit_dense_kernel(float *dense, int ld, int rows, const int *n_r
   if (zero_feature >= 0) dense[(size_t)r * ld + zero_feature] = 0.f;
 }
 
+// counts[c] = number of flagged tokens in pass c of the exact fallback
+__global__ void fallback_counts_kernel(const int *n_flagged, int fb_cap, int chunks, int *counts) {
+  const int nf = *n_flagged;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    const int left = nf - c * fb_cap;
+    counts[c] = left < 0 ? 0 : (left > fb_cap ? fb_cap : left);
+  }
+}
+
 // exact results of the flagged tokens overwrite the fast-path results
 __global__ void scatter_fallback_kernel(const float *fb_vals, const int32_t *fb_idx, const int *flagged,
                                         const int *n_flagged, int fb_cap, int k, float *vals, int32_t *idx,
-                                        int32_t *status) {
+                                        int32_t *status, int detail) {
   const int nf = min(*n_flagged, fb_cap);
   for (int i = blockIdx.x; i < nf; i += gridDim.x) {
     const int t = flagged[i];
@@ -540,7 +713,8 @@ __global__ void scatter_fallback_kernel(const float *fb_vals, const int32_t *fb_
       vals[(size_t)t * k + j] = fb_vals[(size_t)i * k + j];
       idx[(size_t)t * k + j] = fb_idx[(size_t)i * k + j];
     }
-    if (threadIdx.x == 0 && status) status[t] = 1;
+    // status detail (msae_set_status_detail): keep why the fast path gave up, bits 8.. = the reason bits
+    if (threadIdx.x == 0 && status) status[t] = detail ? (1 | ((status[t] & ~3) << 8)) : 1;
   }
 }
 
@@ -560,8 +734,8 @@ inline void prof_mark(int i, hipStream_t s) {
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
   bool fast, i8;
-  int Tp, S, r, cap, n_rescore, step, r_max, fb_cap;
-  size_t off_xq, off_xqo, off_sx, off_ms, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
+  int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
+  size_t off_xq, off_xqo, off_rowc, off_colc, off_colc_s, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
       off_fbi, off_dense, bytes;
 };
@@ -578,31 +752,24 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
     p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
-    // first round / first extension, tuned on MI355X at k = 32 (same box, re-score stage ms):
-    //   int8  k+16,+8: 1.52   k+20,+16: 1.40   k+24,+16: 1.40   k+32,+16: 1.56   k+8,+8: 1.81
-    //   bf16  flat (1.04-1.05) from k+6 to k+12
-    // the int8 pass is ~3x noisier than bf16, so its guard band needs more margin; a round is a
-    // full row-streaming latency, so too small a first round costs more than a few extra rows
-    const int base = k / 8 > 8 ? k / 8 : 8;
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
-    p.n_rescore = k + (p.i8 ? 5 * base / 2 : base);
-    p.step = p.i8 ? 2 * base : base;
-    // rounds extend the re-scored set (step doubling) up to here; once every listed candidate is
-    // re-scored the bound falls back to tau, which sits ~8k ranks below v_k, so reaching r_max with
-    // the band still violated is practically impossible and the exact fallback stays idle
+    // most rows one token may read before it is handed to the exact path (the needed set is ~k + 10:
+    // reaching this means the band is not separating anything); at least k + 4 (first-round minimum)
     p.r_max = k <= 64 ? 8 * k : 3 * k;
+    if (p.r_max < k + 4) p.r_max = k + 4;
     if (p.r_max > p.cap) p.r_max = p.cap;
     if (p.i8) {
       p.off_xq = take((size_t)p.Tp * d);
       p.off_xqo = take((size_t)p.Tp * MAX_OUT);
-      p.off_sx = take((size_t)p.Tp * 4);
-      p.off_ms = take((size_t)p.Tp * 4);
+      p.off_colc = take((size_t)N * 16);
+      p.off_colc_s = take((size_t)p.S * 16);
       p.off_colmax = take((size_t)d * 4);
       p.off_odims = take((size_t)MAX_OUT * 4);
       p.off_isout = take((size_t)d);
       p.off_wqo = take((size_t)N * MAX_OUT);
       p.off_wqos = take((size_t)p.S * MAX_OUT);
     }
+    p.off_rowc = take((size_t)p.Tp * 16);
     p.off_xb = take(p.i8 ? 256 : (size_t)p.Tp * d * 2);
     p.off_a32 = take((size_t)T * d * 4);
     p.off_sample = take((size_t)T * p.S * 4);
@@ -611,7 +778,8 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.off_cnt = take((size_t)T * 4);
     p.off_cand = take((size_t)T * p.cap * 8);
     p.fb_cap = fallback_capacity(T, N);
-    p.off_flag = take((size_t)(p.fb_cap + 64) * 4);
+    p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
+    p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);   // token list [T] | count | per-pass counts
     p.off_fbdense = take((size_t)p.fb_cap * N * 4);
     p.off_fbv = take((size_t)p.fb_cap * k * 4);
     p.off_fbi = take((size_t)p.fb_cap * k * 4);
@@ -635,25 +803,28 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   int *cnt = reinterpret_cast<int *>(ws + pl.off_cnt);
   unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + pl.off_cand);
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
-  int *n_flagged = flagged + pl.fb_cap;
+  int *n_flagged = flagged + T;
+  int *fb_counts = flagged + T + 64;
   float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
   float *fbv = reinterpret_cast<float *>(ws + pl.off_fbv);
   int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
   prof_mark(0, s);
-  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)(pl.fb_cap + 64),
+  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)T + 64 + pl.fb_chunks,
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
   hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.i8 ? T : pl.Tp, d,
                      pl.i8 ? (unsigned short *)nullptr : xb, a32);
 
   GemmOperands op_main{}, op_samp{};
-  const float *q_sx = nullptr, *q_sw = nullptr;
+  const float z = guard_z(), zz12 = z * z / 12.f;
+  f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
+  const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   if (pl.i8) {
     signed char *xq = reinterpret_cast<signed char *>(ws + pl.off_xq);
     signed char *xqo = reinterpret_cast<signed char *>(ws + pl.off_xqo);
-    float *sx = reinterpret_cast<float *>(ws + pl.off_sx);
-    int *ms = reinterpret_cast<int *>(ws + pl.off_ms);
+    f32x4 *cc_main = reinterpret_cast<f32x4 *>(ws + pl.off_colc);
+    f32x4 *cc_samp = reinterpret_cast<f32x4 *>(ws + pl.off_colc_s);
     unsigned *colmax = reinterpret_cast<unsigned *>(ws + pl.off_colmax);
     int *odims = reinterpret_cast<int *>(ws + pl.off_odims);
     unsigned char *is_out = ws + pl.off_isout;
@@ -664,20 +835,22 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     hipLaunchKernelGGL(colmax_kernel, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, a32, T, d, colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
-    hipLaunchKernelGGL(quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, a32, T, d, odims, is_out, xq, xqo, sx, ms);
-    hipLaunchKernelGGL(gather_wo_kernel, dim3((N + 31) / 32), dim3(256), 0, s, wq, N, d, odims, wqo, wqos);
+    hipLaunchKernelGGL(quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, a32, T, d, odims, is_out, xq, xqo, rowc, zz12);
+    hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
+                       reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp);
+    colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(xq); op_main.ldA = d;
     op_main.B = reinterpret_cast<const unsigned char *>(wq); op_main.ldB = d;
     op_main.nk = d / 128;
     op_main.Ao = reinterpret_cast<const unsigned char *>(xqo);
     op_main.Bo = reinterpret_cast<const unsigned char *>(wqo);
-    op_main.mscale = ms;
     op_samp = op_main;
     op_samp.B = reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
-    q_sx = sx;
-    q_sw = reinterpret_cast<const float *>(prepared + pp.off_sw);
   } else {
+    hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z);
+    colc = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
+    colc_s = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf_s);
     op_main.A = reinterpret_cast<const unsigned char *>(xb); op_main.ldA = (size_t)d * 2;
     op_main.B = reinterpret_cast<const unsigned char *>(wb); op_main.ldB = (size_t)d * 2;
     op_main.nk = d / 64;
@@ -690,7 +863,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
     ep.dense = sample; ep.ld_dense = pl.S;
-    ep.sx = q_sx; ep.sw = q_sw;
+    ep.rowc = rowc; ep.colc = colc_s; ep.zz12 = zz12;
     const int grc = pl.i8 ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
     if (grc) return grc;
@@ -709,7 +882,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.cnt = cnt; ep.cand = cand; ep.cap = pl.cap;
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
-    ep.sx = q_sx; ep.sw = q_sw;
+    ep.rowc = rowc; ep.colc = colc; ep.zz12 = zz12;
     const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s)
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
     if (grc) return grc;
@@ -720,11 +893,11 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.a32 = a32; ra.W_enc = W_enc; ra.b_enc = b_enc;
     ra.tau_vals = tauv; ra.tau_ld = pl.r; ra.tau_col = pl.r - 1;
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
-    ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.n_rescore = pl.n_rescore;
-    ra.step = pl.step; ra.r_max = pl.r_max;
+    ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
+    ra.rowc = rowc; ra.colc = colc; ra.zz12 = zz12; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
-    ra.fb_cap = pl.fb_cap;
+    ra.fb_cap = T;
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
     if (k <= 64) {
@@ -738,17 +911,21 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     }
   }
   prof_mark(5, s);
-  // exact recompute of flagged tokens (device-side count; empty grids exit immediately)
-  rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, flagged, n_flagged, pl.fb_cap, d, N, 1, fbdense,
-                            N, s);
-  if (rc) return rc;
-  if (set_feature >= 0 || zero_feature >= 0)
-    hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_flagged,
-                       set_feature, set_value, zero_feature);
-  rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_flagged, fbv, fbi, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, flagged,
-                     n_flagged, pl.fb_cap, k, vals, idx, status);
+  // exact recompute of the flagged tokens, fb_cap at a time (device-side counts; passes without work
+  // exit immediately)
+  hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_flagged, pl.fb_cap, pl.fb_chunks, fb_counts);
+  for (int c = 0; c < pl.fb_chunks; ++c) {
+    const int *rows = flagged + (size_t)c * pl.fb_cap, *n_rows = fb_counts + c;
+    rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, rows, n_rows, pl.fb_cap, d, N, 1, fbdense, N, s);
+    if (rc) return rc;
+    if (set_feature >= 0 || zero_feature >= 0)
+      hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_rows,
+                         set_feature, set_value, zero_feature);
+    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, fbv, fbi, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, rows, n_rows, pl.fb_cap, k,
+                       vals, idx, status, g_status_detail);
+  }
   prof_mark(6, s);
   if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
   return msae_launch_status();
@@ -759,6 +936,17 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 extern "C" int msae_set_coarse_mode(int mode) {
   if (mode != 0 && mode != 1) return MSAE_EINVAL;
   g_coarse_mode = mode;
+  return 0;
+}
+
+extern "C" int msae_set_guard_z(float z) {
+  if (!(z >= 1.f && z <= 64.f)) return MSAE_EINVAL;
+  g_guard_z = z;
+  return 0;
+}
+
+extern "C" int msae_set_status_detail(int on) {
+  g_status_detail = on ? 1 : 0;
   return 0;
 }
 
@@ -809,11 +997,15 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
       hipLaunchKernelGGL(prepare_weights_kernel, dim3(4096), dim3(256), 0, s, W_enc, N, d,
                          reinterpret_cast<unsigned short *>(base + p.off_wb),
                          reinterpret_cast<unsigned short *>(base + p.off_ws));
-    if ((modes & 2) && i8_shape_ok(N, d))
-      hipLaunchKernelGGL(quant_w_kernel, dim3(N), dim3(256), 0, s, W_enc, N, d,
-                         reinterpret_cast<float *>(base + p.off_sw),
-                         reinterpret_cast<signed char *>(base + p.off_wq),
+    f32x4 *wstat = reinterpret_cast<f32x4 *>(base + p.off_wstat), *wstat_s = reinterpret_cast<f32x4 *>(base + p.off_wstat_s);
+    f32x4 *colbf = reinterpret_cast<f32x4 *>(base + p.off_colbf), *colbf_s = reinterpret_cast<f32x4 *>(base + p.off_colbf_s);
+    if ((modes & 2) && i8_shape_ok(N, d))   // row statistics (both passes' error bands) + int8 operands
+      hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
+                         colbf_s, reinterpret_cast<signed char *>(base + p.off_wq),
                          reinterpret_cast<signed char *>(base + p.off_wqs));
+    else
+      hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
+                         colbf_s, (signed char *)nullptr, (signed char *)nullptr);
   }
   return msae_launch_status();
 }

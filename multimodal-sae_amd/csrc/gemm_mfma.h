@@ -33,8 +33,12 @@
 //   schedule, s_setprio, an L2 prefetch and issuing the DMA behind the first MFMA group were all
 //   measured equal or worse and are not kept.
 //
-// Epilogues: DENSE  out[t][n] = value + bias[feature(n)]                      (sample pass)
-//            THRESH append (feature, value + bias) to token t's candidate list when > tau[t]
+// Epilogues work on the UPPER value u = v + z*sigma(t, n) of every output, v = coarse pre-activation
+// (value + bias) and z*sigma the width of the error band of the operand type (encode_fused.hip):
+//     z^2 sigma^2(t, n) = P_t Q_n + R_t (Si_n + M_t So_n),  R_t = sx_t^2 z^2/12, M_t = m_t^2 (int8 only)
+//   DENSE  out[t][n] = u                                                      (sample pass)
+//   THRESH append (feature, u) to token t's candidate list when u > tau[t]; the test is done on
+//          squares, (tau - v)^2 < z^2 sigma^2, so only the rare survivors pay a square root
 #pragma once
 #include <cstdlib>
 
@@ -50,8 +54,10 @@ struct GemmEpilogue {
   const float *tau_vals; int tau_ld, tau_col;   // THRESH: tau[t] = tau_vals[t*tau_ld + tau_col]
   int *cnt; unsigned long long *cand; int cap;  // candidate lists
   int skip_a, skip_b;            // features never emitted (hook edits replace their latents)
-  // int8 only: value = float(acc) * sx[t] * sw[feature]
-  const float *sx, *sw;
+  // error-band constants (encode_fused.hip): per token (sx, m as float, P, -), per COLUMN of this
+  // launch (sw, Q, Si, So).  int8: value = float(acc) * sx[t] * sw[n]; bf16 ignores sx, sw, Si, So.
+  const f32x4 *rowc, *colc;
+  float zz12;                    // z^2 / 12
 };
 
 // Operands of one launch.  A rows are tokens, B rows are features; ld* in BYTES.
@@ -59,9 +65,9 @@ struct GemmOperands {
   const unsigned char *A, *B;
   size_t ldA, ldB;
   int nk;                        // k-tiles of 128 B per row
-  // int8 only: optional leading outlier tile (one k-tile, rows 128 B apart) and its multiplier
+  // int8 only: optional leading outlier tile (one k-tile, rows 128 B apart); the accumulators are
+  // multiplied by the token's integer multiplier m (GemmEpilogue::rowc[t][1]) after it
   const unsigned char *Ao, *Bo;
-  const int *mscale;             // acc *= mscale[t] after the outlier tile
 };
 
 // FLAGS (tuning only; results invalid when an ABL bit is set):
@@ -81,8 +87,11 @@ struct GemmCfg {
   static constexpr int LDS_RING_BYTES = STAGES * STAGE_BYTES;
   // behind the ring: side buffer of epilogue constants, then the THRESH epilogue's candidate queue.
   // Neither overlaps the ring: the next tile's first k-tile is already landing in it meanwhile.
-  static constexpr int SIDE_BYTES = 3 * NT * 4;   // tau|bias, sx|sw, outlier multiplier (one float/int per thread each)
-  static constexpr int QCAP = 3072;
+  // side buffer, one float per thread and slot: tau|bias, sx|sw, m (int, parked early)|Q, P|Si, m|So
+  // (row threads | column threads)
+  static constexpr int SIDE_SLOTS = 5;
+  static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
+  static constexpr int QCAP = 2560;
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
@@ -271,46 +280,64 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     if (threadIdx.x == 0) *q_count = 0u;
     __syncthreads();
   }
-  // side[tid]: tau of row tid | bias of column tid-BM;  side[NT+tid]: sx | sw
-  const float *row_tau = side, *row_sx = side + C::NT;
-  const float *col_bias = side + C::BM, *col_sw = side + C::NT + C::BM;
+  // side[s*NT + tid]: slot s of row tid (tid < BM) or of column tid - BM
+  const float *row_c = side, *col_c = side + C::BM;
+  // column constants of this lane's NI columns stay in registers across the row loops
+  float c_bias[C::NI], c_sw[C::NI], c_q[C::NI], c_si[C::NI], c_so[C::NI];
+  bool c_live[C::NI];
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    const int col = wc * C::TN + j * 32 + l31;         // column inside the tile
+    c_bias[j] = col_c[col];
+    c_sw[j] = col_c[C::NT + col];
+    c_q[j] = col_c[2 * C::NT + col];
+    c_si[j] = col_c[3 * C::NT + col];
+    c_so[j] = col_c[4 * C::NT + col];
+    const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+    c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
+  }
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
-    float tau[16], rs[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      tau[e] = DENSE ? 0.f : row_tau[row];
-      rs[e] = C::I8 ? row_sx[row] : 0.f;
-    }
+      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
+      const int t = m0 + row;
+      const float tau = DENSE ? 0.f : row_c[row];
+      const float pz = row_c[3 * C::NT + row];         // P_t
+      float rs = 0.f, rz = 0.f, rzm = 0.f;
+      if constexpr (C::I8) {
+        rs = row_c[C::NT + row];                       // sx_t
+        const float mf = row_c[4 * C::NT + row];        // m_t (slot 2 holds the NEXT tile's multipliers already)
+        rz = rs * rs * ep.zz12;                        // R_t
+        rzm = rz * mf * mf;                            // R_t M_t
+      }
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-      const int col = wc * C::TN + j * 32 + l31;       // column inside the tile
-      const int n = n0 + col;
-      const int feat = n * ep.bias_stride + ep.bias_off;
-      const float bn = col_bias[col];
-      const float cs = C::I8 ? col_sw[col] : 1.f;
-      const bool live = (feat != ep.skip_a) && (feat != ep.skip_b);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v;
-        if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * cs) + bn;
-        else v = acc[i][j][e] + bn;
-        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
-        const int t = m0 + row;
-        if constexpr (DENSE) {
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n] = v;
+      for (int j = 0; j < C::NI; ++j) {
+        float v, s2;
+        if constexpr (C::I8) {
+          v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs * c_sw[j]) + c_bias[j];
+          s2 = __builtin_fmaf(pz, c_q[j], __builtin_fmaf(rzm, c_so[j], rz * c_si[j]));
         } else {
-          if (v > tau[e] && live) {
+          v = acc[i][j][e] + c_bias[j];
+          s2 = pz * c_q[j];
+        }
+        if constexpr (DENSE) {
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + wc * C::TN + j * 32 + l31] = v + __builtin_sqrtf(s2);
+        } else {
+          const float w = tau - v;                     // emit when v + sqrt(s2) > tau
+          if ((w < 0.f || s2 > w * w) && c_live[j]) {
+            const float u = v + __builtin_sqrtf(s2);
+            const int col = wc * C::TN + j * 32 + l31;
             const unsigned slot = atomicAdd(q_count, 1u);                       // LDS atomic
             if (slot < QCAP) {
-              queue[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(row << 16 | col);
+              queue[slot] = ((unsigned long long)__float_as_uint(u) << 32) | (unsigned)(row << 16 | col);
             } else {                                                              // queue full: slow path
+              const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
               const int gslot = atomicAdd(ep.cnt + t, 1);
               if (gslot < ep.cap)
                 ep.cand[(size_t)t * ep.cap + gslot] =
-                    ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
+                    ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
             }
           }
         }
@@ -323,13 +350,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
-      const float v = __uint_as_float((unsigned)(e >> 32));
+      const float u = __uint_as_float((unsigned)(e >> 32));
       const int t = m0 + row;
       const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
       const int gslot = atomicAdd(ep.cnt + t, 1);
       if (gslot < ep.cap)
         ep.cand[(size_t)t * ep.cap + gslot] =
-            ((unsigned long long)f32_order_key(v) << 32) | (unsigned)(0x7FFFFFFF - feat);
+            ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
     }
   }
 }
@@ -365,9 +392,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 
   // Row / column constants of the epilogue: fetched NOW into two registers per thread, parked in
   // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
-  //   threads [0, BM)      : tau (THRESH) and sx (int8) of row m0 + tid
-  //   threads [BM, BM+BN)  : bias and sw (int8) of column n0 + tid - BM
-  float side0 = 0.f, side1 = 0.f;
+  //   threads [0, BM)      : tau (THRESH) and (sx, m, P) of row m0 + tid
+  //   threads [BM, BM+BN)  : bias and (sw, Q, Si, So) of column n0 + tid - BM
+  float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
   int side2 = 1;
   {
     const int tid = tid_;
@@ -377,14 +404,22 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
         side0 = (v > 0.f) ? v : __builtin_inff();     // degenerate / padded token: emit nothing
       }
-      if constexpr (C::I8) {
-        side1 = (t < T) ? ep.sx[t] : 0.f;
-        if (op.Ao != nullptr) side2 = op.mscale[t];   // rows [T, Tp) hold 1
+      if (t < T) {
+        const f32x4 rc = ep.rowc[t];
+        side1 = rc[0];
+        side3 = rc[2];
+        side4 = 1.f;
+        if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
       }
     } else if (tid < C::BM + C::BN) {
-      const int feat = (n0 + tid - C::BM) * ep.bias_stride + ep.bias_off;
+      const int n = n0 + tid - C::BM;
+      const int feat = n * ep.bias_stride + ep.bias_off;
       side0 = ep.bias ? ep.bias[feat] : 0.f;
-      if constexpr (C::I8) side1 = ep.sw[feat];
+      const f32x4 cc = ep.colc[n];
+      side1 = cc[0];
+      side2 = __float_as_int(cc[1]);
+      side3 = cc[2];
+      side4 = cc[3];
     }
   }
   const bool has_out = C::I8 && op.Ao != nullptr;
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   auto iteration = [&](int kt, bool park_m = false) {
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
     if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
-      side_m[tid_] = side2;
+      if (tid_ < C::BM) side_m[tid_] = side2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
@@ -459,6 +494,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
   side[tid_] = side0;
   side[C::NT + tid_] = side1;
+  reinterpret_cast<int *>(side)[2 * C::NT + tid_] = side2;
+  side[3 * C::NT + tid_] = side3;
+  side[4 * C::NT + tid_] = side4;
   gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
   }
 }

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_set_coarse_mode": (c_int, [c_int]),
+    "msae_set_guard_z": (c_int, [c_float]),
+    "msae_set_status_detail": (c_int, [c_int]),
     "msae_merge_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_unit_norm_rows_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "msae_grad_sumsq_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),

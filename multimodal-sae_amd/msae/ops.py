@@ -101,6 +101,17 @@ def set_coarse_mode(mode: str) -> None:
     _hip.check(_hip.load().msae_set_coarse_mode({"bf16": 0, "int8": 1}[mode]), "msae_set_coarse_mode")
 
 
+def set_guard_z(z: float) -> None:
+    """Width of the candidate pass's error band in standard deviations of its per-(token, feature)
+    rounding noise (default 7).  Verified results do not depend on it; rows read per token do."""
+    _hip.check(_hip.load().msae_set_guard_z(float(z)), "msae_set_guard_z")
+
+
+def set_status_detail(on: bool) -> None:
+    """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
+    _hip.check(_hip.load().msae_set_status_detail(int(on)), "msae_set_status_detail")
+
+
 def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_only: bool = False) -> Tensor:
     """Coarse-pass operands of the encoder weights for the fused path (bf16 copy, int8 quantisation,
     sampled rows).  Once per weight load; `out` + `active_mode_only` is the per-step refresh of a
@@ -169,24 +180,10 @@ def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_f
 def encode_topk_resolved(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
                          prepared: Optional[Tensor], k: int, set_feature: int = -1,
                          set_value: float = 0.0, zero_feature: int = -1):
-    """encode_topk, then the tokens the call reported as unresolved (status >= 2: more unverifiable
-    tokens than the in-call exact fallback has scratch for) recomputed through the exact dense ops.
-    Costs one device->host flag read per call; results never depend on how many tokens were
-    degenerate."""
-    acts, idx, status = encode_topk(x, W_enc, b_enc, b_dec, prepared, k, set_feature, set_value, zero_feature)
-    if bool((status >= 2).any()):
-        rows = torch.nonzero(status.reshape(-1) >= 2).flatten()
-        xf = x.reshape(-1, x.shape[-1])
-        av, iv, sv = acts.view(-1, k), idx.view(-1, k), status.view(-1)
-        for part in rows.split(1024):                          # 1024 x N f32 of dense scratch at a time
-            pre = pre_acts(xf[part], W_enc, b_enc, b_dec)
-            if set_feature >= 0:
-                pre[:, set_feature] = set_value
-            if zero_feature >= 0:
-                pre[:, zero_feature] = 0.0
-            av[part], iv[part] = topk(pre, k)
-            sv[part] = 1
-    return acts, idx, status
+    """Historic name: the kernel now recomputes EVERY token it cannot verify inside the call (the exact
+    fallback loops over the flagged list on the device), so there is nothing left to resolve on the
+    host and no device->host read.  Same as encode_topk."""
+    return encode_topk(x, W_enc, b_enc, b_dec, prepared, k, set_feature, set_value, zero_feature)
 
 
 # ---- decoder (differentiable, mirrors TritonDecoder: kernels.py:403-429) ---------------------------

@@ -112,6 +112,7 @@ class Sae(nn.Module):
         sae = Sae(d_in, cfg, device=device, decoder=decoder)
         load_model(model=sae, filename=str(path / "sae.safetensors"), device=str(device),
                    strict=decoder)
+        sae.invalidate_prepared()
         return sae
 
     def save_to_disk(self, path: Union[Path, str]):
@@ -143,6 +144,15 @@ class Sae(nn.Module):
         instance of the reference's `sorted=False`."""
         return EncoderOutput(*ops.topk(latents, self.cfg.k))
 
+    def invalidate_prepared(self) -> None:
+        """Drop the cached coarse-pass operands (bf16 / int8 copies of encoder.weight).  They are
+        rebuilt when `encoder.weight`'s autograd version changes; an edit through `.data`, `copy_`
+        into `.data` or a raw-pointer kernel does NOT bump the version -- call this after one.  (Stale
+        operands cannot corrupt results silently in general: every re-scored pair checks the error
+        model and sends the token to the exact path -- but that is the slow path.)"""
+        self._prepared = None
+        self._prepared_key = None
+
     def _prepared_weights(self) -> Optional[Tensor]:
         w = self.encoder.weight
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
@@ -158,15 +168,13 @@ class Sae(nn.Module):
         patching/utils.py:43-48) inside the kernel, before TopK.
 
         The kernel verifies every token and recomputes the ones it cannot verify (degenerate
-        activations: all-zero rows, fewer than k positive latents, ...) exactly inside the call, up
-        to a scratch budget (csrc/encode_fused.hip:fallback_capacity).  `resolve` (one device->host
-        read of a flag per call) finishes whatever exceeded that budget through the exact dense ops,
-        so the result never depends on how many tokens were degenerate; pass resolve=False in a
-        loop that must not synchronise and inspect `status` (>= 2: unresolved) yourself."""
-        fn = ops.encode_topk_resolved if resolve else ops.encode_topk
-        acts, idx, status = fn(x, self.encoder.weight, self.encoder.bias, self.b_dec,
-                               self._prepared_weights(), self.cfg.k, set_feature, float(set_value),
-                               zero_feature)
+        activations: all-zero rows, fewer than k positive latents, tokens the error model of the
+        candidate pass does not describe ...) exactly inside the call, on the device; nothing is read
+        back, so the method is stream-ordered like every other op.  `status` (return_status=True):
+        0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored."""
+        acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
+                                            self._prepared_weights(), self.cfg.k, set_feature,
+                                            float(set_value), zero_feature)
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 

@@ -30,8 +30,9 @@ def _load(golden_dir, name):
     return g, W, x
 
 
-@pytest.mark.parametrize("name", ["g1_c1_d768_n4096", "g2_d4096_n16384"])
+@pytest.mark.parametrize("name", ["g1_c1_d768_n4096", "g2_d4096_n16384", "g2_c2_d4096_n131072"])
 def test_encode_topk_decode_matches_reference(golden_dir, name):
+    """The last case is BASELINE configs[1] at full width (weight generation takes ~a minute)."""
     g, (W_enc, b_enc, W_dec, b_dec), x = _load(golden_dir, name)
     pre = oracle.pre_acts(x, W_enc, b_enc, b_dec)
     assert _close(pre[:8, :256], g["pre_slice"])

@@ -1,18 +1,35 @@
-"""Rows / rounds of the re-scoring stage per token (needs a library built with -DMSAE_RESCORE_DEBUG,
-which reports (rounds << 24 | first-round rows << 12 | rows) in `status`)."""
-import sys, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/multimodal-sae_amd')
-import bench
+"""Rows / rounds of the re-scoring stage per token.  Needs the instrumented library (tools/build_dbg.sh,
+-DMSAE_RESCORE_DEBUG), which reports (rounds << 24 | first-round rows << 12 | rows) in `status`:
+
+    MSAE_HIP_LIB=tools/bin/libmsae_dbg.so python tools/rescore_stats.py [bench|trained_like|lognorm|...]
+"""
+import os, sys, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, REPO + '/multimodal-sae_amd', REPO + '/tests'):
+    sys.path.insert(0, p)
+import bench, hostile
 from msae import ops
 dev = torch.device('cuda:0')
 T, d, N, k = 8192, 4096, 131072, 32
-W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, T, d, N)
-prep = ops.prepare_encoder(W_enc)
-for call in range(3):
-    v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, k)
-    torch.cuda.synchronize()
-    s = s.cpu()
-    rounds, first, rows = s >> 24, (s >> 12) & 0xFFF, s & 0xFFF
-    print(f"call {call}: rounds hist {torch.bincount(rounds).tolist()}  mean rows {rows.float().mean():.1f}  "
-          f"rows hist {dict(zip(*[t.tolist() for t in torch.unique(rows, return_counts=True)]))}"
-          f"")
+kinds = sys.argv[1:] or ["bench"]
+for kind in kinds:
+    if kind == "bench":
+        W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, T, d, N)
+    else:
+        W_enc, b_enc, b_dec = hostile.weights(kind, N, d, dev, seed=41)
+        x = hostile.activations(T, d, dev, seed=42)
+    for mode in ("int8", "bf16"):
+        ops.set_coarse_mode(mode)
+        prep = ops.prepare_encoder(W_enc)
+        v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, k)
+        torch.cuda.synchronize()
+        s = s.cpu()
+        ok = s >= (1 << 24)
+        rounds, first, rows = s[ok] >> 24, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
+        print(f"{kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
+              f"mean rows {rows.float().mean():.1f} (first round {first.float().mean():.1f})  "
+              f"rows p50/p99/max {int(rows.float().quantile(0.5))}/{int(rows.float().quantile(0.99))}/{int(rows.max())}  "
+              f"not verified: {torch.unique(s[~ok], return_counts=True)}", flush=True)
+        del prep
+    ops.set_coarse_mode("int8")
+    del W_enc
