@@ -97,7 +97,7 @@ int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void 
 int msae_set_coarse_mode(int mode);
 
 /* Width z of the error band of the candidate pass, in standard deviations of its per-(token,
- * feature) rounding noise (default 7; 1 <= z <= 64; environment MSAE_GUARD_Z sets the initial value).
+ * feature) rounding noise (default 7; 0.25 <= z <= 64; environment MSAE_GUARD_Z sets the initial value).
  * A larger z re-scores more rows per token; results of verified tokens do not depend on it. */
 int msae_set_guard_z(float z);
 

@@ -124,7 +124,7 @@ inline float guard_z() {
   if (g_guard_z < 0.f) {
     const char *e = getenv("MSAE_GUARD_Z");
     const float v = e ? (float)atof(e) : 0.f;
-    g_guard_z = (v >= 1.f && v <= 64.f) ? v : 7.f;
+    g_guard_z = (v >= 0.25f && v <= 64.f) ? v : 7.f;
   }
   return g_guard_z;
 }
@@ -940,7 +940,7 @@ extern "C" int msae_set_coarse_mode(int mode) {
 }
 
 extern "C" int msae_set_guard_z(float z) {
-  if (!(z >= 1.f && z <= 64.f)) return MSAE_EINVAL;
+  if (!(z >= 0.25f && z <= 64.f)) return MSAE_EINVAL;
   g_guard_z = z;
   return 0;
 }

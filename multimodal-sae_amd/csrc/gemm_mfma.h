@@ -326,7 +326,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
           if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + wc * C::TN + j * 32 + l31] = v + __builtin_sqrtf(s2);
         } else {
           const float w = tau - v;                     // emit when v + sqrt(s2) > tau
+#ifdef MSAE_ABL_EPI_NOBAND   // tuning only: the round-1 test (results invalid)
+          if (w < 0.f && c_live[j]) {
+#else
           if ((w < 0.f || s2 > w * w) && c_live[j]) {
+#endif
             const float u = v + __builtin_sqrtf(s2);
             const int col = wc * C::TN + j * 32 + l31;
             const unsigned slot = atomicAdd(q_count, 1u);                       // LDS atomic

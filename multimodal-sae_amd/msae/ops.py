@@ -318,18 +318,28 @@ class _SparseEncode(torch.autograd.Function):
     with g masked by relu'(pre) = (value > 0)."""
 
     @staticmethod
-    def forward(ctx, x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi):
+    def forward(ctx, x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi, prepared=None, set_feature=-1,
+                set_value=0.0, zero_feature=-1):
         vals, idxs = [], []
+        edits = set_feature >= 0 or zero_feature >= 0
+        assert not (edits and (k_aux > 0 or k_multi > 0)), "hook edits apply to the plain top-k only"
         if k_aux == 0 and max(k, k_multi) <= 256:
             # no AuxK term: the fused encoder gives the canonical top-max(k, 4k); the top-k is its
-            # prefix (same order), and the dense [T, N] latents are never built
+            # prefix (same order), and the dense [T, N] latents are never built.  `prepared`: operands
+            # of a weight that does not change between calls (inference hooks); None = training step
             kk = max(k, k_multi)
-            v, i, _ = encode_topk_resolved(x, W_enc, b_enc, b_dec, _refresh_train_operands(W_enc), kk)
+            v, i, _ = encode_topk(x, W_enc, b_enc, b_dec,
+                                  prepared if prepared is not None else _refresh_train_operands(W_enc), kk,
+                                  set_feature, set_value, zero_feature)
             vals.append(v[..., :k].contiguous()); idxs.append(i[..., :k].contiguous())
             if k_multi > 0:
                 vals.append(v); idxs.append(i)
         else:
             pre = pre_acts(x, W_enc, b_enc, b_dec)
+            if set_feature >= 0:
+                pre[..., set_feature] = set_value
+            if zero_feature >= 0:
+                pre[..., zero_feature] = 0.0
             v, i = topk(pre, k)
             vals.append(v); idxs.append(i)
             if k_aux > 0:
@@ -340,6 +350,7 @@ class _SparseEncode(torch.autograd.Function):
                 vals.append(v); idxs.append(i)
         ctx.save_for_backward(x, W_enc, b_dec, torch.cat(idxs, -1), torch.cat(vals, -1))
         ctx.splits = [t.shape[-1] for t in vals]
+        ctx.set_feature = set_feature
         ctx.has_b_enc = b_enc is not None
         out = []
         for v, i in zip(vals, idxs):
@@ -354,6 +365,8 @@ class _SparseEncode(torch.autograd.Function):
         g = [grads[2 * j] if grads[2 * j] is not None else
              torch.zeros(val_cat.shape[0], n, device=val_cat.device) for j, n in enumerate(ctx.splits)]
         g_cat = torch.cat(g, -1).float() * (val_cat > 0)           # relu'
+        if ctx.set_feature >= 0:                                   # a latent overwritten by a constant carries no gradient
+            g_cat = g_cat * (idx_cat != ctx.set_feature)
         a = x.float() - b_dec
         need_x, need_W, need_be, need_bd = ctx.needs_input_grad[:4]
         g_x = g_W = g_be = g_bd = None
@@ -366,13 +379,18 @@ class _SparseEncode(torch.autograd.Function):
             da = decode(idx_cat, g_cat, W_enc, None)
             g_x = da.to(x.dtype) if need_x else None
             g_bd = -da.sum(0) if need_bd else None
-        return g_x, g_W, g_be, g_bd, None, None, None, None
+        return g_x, g_W, g_be, g_bd, None, None, None, None, None, None, None, None
 
 
 def sparse_encode(x: Tensor, W_enc: Tensor, b_enc: Tensor, b_dec: Tensor, k: int,
-                  dead_mask: Optional[Tensor] = None, k_aux: int = 0, k_multi: int = 0):
-    """-> [(acts, idx)] for the top-k, (optional) AuxK and (optional) Multi-TopK selections."""
-    out = _SparseEncode.apply(x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi)
+                  dead_mask: Optional[Tensor] = None, k_aux: int = 0, k_multi: int = 0, *,
+                  prepared: Optional[Tensor] = None, set_feature: int = -1, set_value: float = 0.0,
+                  zero_feature: int = -1):
+    """-> [(acts, idx)] for the top-k, (optional) AuxK and (optional) Multi-TopK selections.
+    Differentiable w.r.t. x, W_enc, b_enc, b_dec through the selected latents (the graph of the
+    reference's pre_acts -> [mask] -> topk, sae.py:172-185, patching/utils.py:43-49)."""
+    out = _SparseEncode.apply(x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi, prepared, set_feature,
+                              float(set_value), zero_feature)
     return [(out[2 * j], out[2 * j + 1]) for j in range(len(out) // 2)]
 
 

@@ -172,6 +172,13 @@ class Sae(nn.Module):
         candidate pass does not describe ...) exactly inside the call, on the device; nothing is read
         back, so the method is stream-ordered like every other op.  `status` (return_status=True):
         0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.encoder.weight.requires_grad) and not return_status:
+            # autograd must flow (attribution patching: patching/utils.py:33-58, attribution.py:165):
+            # same kernel, as one autograd node with the sparse backward
+            (acts, idx), = ops.sparse_encode(x, self.encoder.weight, self.encoder.bias, self.b_dec, self.cfg.k,
+                                             prepared=self._prepared_weights(), set_feature=set_feature,
+                                             set_value=set_value, zero_feature=zero_feature)
+            return EncoderOutput(acts, idx)
         acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
                                             self._prepared_weights(), self.cfg.k, set_feature,
                                             float(set_value), zero_feature)

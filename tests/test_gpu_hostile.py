@@ -9,7 +9,7 @@ families a trained SAE (and an adversary) produces and assert
   * no token stays unresolved, and only a few per cent take the exact in-call fallback,
 
 at N >= 16384, T >= 8192.  `test_band_width_matters` shows the suite has teeth: with the band shrunk
-to 1.5 sigma the same comparison finds silently wrong tokens.
+to 0.25 sigma the same comparison finds silently wrong tokens.
 """
 import numpy as np
 import pytest
@@ -113,7 +113,7 @@ def test_width_262144_against_oracle(dev):
 
 
 def test_band_width_matters(dev):
-    """Same comparison with the band shrunk to 1.5 sigma: verified-but-wrong tokens MUST appear (the
+    """Same comparison with the band shrunk to 0.25 sigma: verified-but-wrong tokens MUST appear (the
     suite can see a too-narrow band); back at the default they are gone."""
     from msae import ops
 
@@ -122,7 +122,7 @@ def test_band_width_matters(dev):
     x = hostile.activations(T, d, dev, seed=10)
     prepared = ops.prepare_encoder(W)
     ev, ei = _exact(ops, x, W, b, bd, k)
-    ops.set_guard_z(1.5)
+    ops.set_guard_z(0.25)
     try:
         v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)
     finally:
@@ -130,7 +130,7 @@ def test_band_width_matters(dev):
     wrong_narrow = int(((i != ei).any(-1) & (status == 0)).sum())
     v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)
     wrong_default = int(((i != ei).any(-1) & (status == 0)).sum())
-    print(f"\nverified-but-wrong tokens of {T}: z=1.5 -> {wrong_narrow}, z=7 -> {wrong_default}")
+    print(f"\nverified-but-wrong tokens of {T}: z=0.25 -> {wrong_narrow}, z=7 -> {wrong_default}")
     assert wrong_narrow > 0
     assert wrong_default == 0 and torch.equal(i, ei) and torch.equal(v, ev)
 
