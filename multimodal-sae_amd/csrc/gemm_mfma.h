@@ -37,8 +37,11 @@
 // (value + bias) and z*sigma the width of the error band of the operand type (encode_fused.hip):
 //     z^2 sigma^2(t, n) = P_t Q_n + R_t (Si_n + M_t So_n),  R_t = sx_t^2 z^2/12, M_t = m_t^2 (int8 only)
 //   DENSE  out[t][n] = u                                                      (sample pass)
-//   THRESH append (feature, u) to token t's candidate list when u > tau[t]; the test is done on
-//          squares, (tau - v)^2 < z^2 sigma^2, so only the rare survivors pay a square root
+//   THRESH append (feature, u) to token t's candidate list when u > tau[t].  The hot loop tests the
+//          separable upper bound  v + h_n B_t > tau[t]  (one fma more than a plain compare):
+//            B_t = z sigma of token t against a REFERENCE feature (refs = typical Q, Si, So),
+//            h_n^2 = max(Q_n/Qr, Si_n/Sir, So_n/Sor)  =>  h_n B_t >= z sigma(t, n) for every pair;
+//          survivors are queued in LDS and the exact u of each is computed when the queue is flushed
 #pragma once
 #include <cstdlib>
 
@@ -57,6 +60,7 @@ struct GemmEpilogue {
   // error-band constants (encode_fused.hip): per token (sx, m as float, P, -), per COLUMN of this
   // launch (sw, Q, Si, So).  int8: value = float(acc) * sx[t] * sw[n]; bf16 ignores sx, sw, Si, So.
   const f32x4 *rowc, *colc;
+  const float *refs;             // (Qr, Sir, Sor): the reference feature of the separable bound
   float zz12;                    // z^2 / 12
 };
 
@@ -87,11 +91,11 @@ struct GemmCfg {
   static constexpr int LDS_RING_BYTES = STAGES * STAGE_BYTES;
   // behind the ring: side buffer of epilogue constants, then the THRESH epilogue's candidate queue.
   // Neither overlaps the ring: the next tile's first k-tile is already landing in it meanwhile.
-  // side buffer, one float per thread and slot: tau|bias, sx|sw, m (int, parked early)|Q, P|Si, m|So
+  // side buffer, one float per thread and slot: tau|bias, sx|sw, m (int, parked early)|Q, P|Si, m|So, B|h
   // (row threads | column threads)
-  static constexpr int SIDE_SLOTS = 5;
+  static constexpr int SIDE_SLOTS = 6;
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
-  static constexpr int QCAP = 2560;
+  static constexpr int QCAP = 2304;
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
@@ -266,6 +270,17 @@ __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const 
 // long as the whole k-loop.  So survivors are first queued in LDS (its own region behind the ring;
 // an LDS atomic returns in ~100 cycles) and then flushed, one queue entry per lane: the
 // global atomics of the whole workgroup are in flight together.
+// z^2 sigma^2 of pair (row, col) from the side buffer (same expression as band_sq in encode_fused.hip)
+template <class C>
+__device__ __forceinline__ float gemm_band_sq(const float *side, int row, int col, float zz12) {
+  const float *row_c = side, *col_c = side + C::BM;
+  const float pz = row_c[3 * C::NT + row];
+  if constexpr (!C::I8) return pz * col_c[2 * C::NT + col];
+  const float rs = row_c[C::NT + row], mf = row_c[4 * C::NT + row];
+  const float rz = rs * rs * zz12;
+  return __builtin_fmaf(pz, col_c[2 * C::NT + col], __builtin_fmaf(rz * mf * mf, col_c[4 * C::NT + col], rz * col_c[3 * C::NT + col]));
+}
+
 template <class C, bool DENSE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
@@ -283,65 +298,55 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
   // side[s*NT + tid]: slot s of row tid (tid < BM) or of column tid - BM
   const float *row_c = side, *col_c = side + C::BM;
   // column constants of this lane's NI columns stay in registers across the row loops
-  float c_bias[C::NI], c_sw[C::NI], c_q[C::NI], c_si[C::NI], c_so[C::NI];
+  float c_bias[C::NI], c_sw[C::NI], c_h[C::NI];
   bool c_live[C::NI];
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
     const int col = wc * C::TN + j * 32 + l31;         // column inside the tile
     c_bias[j] = col_c[col];
     c_sw[j] = col_c[C::NT + col];
-    c_q[j] = col_c[2 * C::NT + col];
-    c_si[j] = col_c[3 * C::NT + col];
-    c_so[j] = col_c[4 * C::NT + col];
+    c_h[j] = col_c[5 * C::NT + col];
     const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
     c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
   }
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
+    float tau[16], rs[16], bt[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
-      const int t = m0 + row;
-      const float tau = DENSE ? 0.f : row_c[row];
-      const float pz = row_c[3 * C::NT + row];         // P_t
-      float rs = 0.f, rz = 0.f, rzm = 0.f;
-      if constexpr (C::I8) {
-        rs = row_c[C::NT + row];                       // sx_t
-        const float mf = row_c[4 * C::NT + row];        // m_t (slot 2 holds the NEXT tile's multipliers already)
-        rz = rs * rs * ep.zz12;                        // R_t
-        rzm = rz * mf * mf;                            // R_t M_t
-      }
+      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      tau[e] = DENSE ? 0.f : row_c[row];
+      rs[e] = C::I8 ? row_c[C::NT + row] : 0.f;
+      bt[e] = DENSE ? 0.f : row_c[5 * C::NT + row];
+    }
 #pragma unroll
-      for (int j = 0; j < C::NI; ++j) {
-        float v, s2;
-        if constexpr (C::I8) {
-          v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs * c_sw[j]) + c_bias[j];
-          s2 = __builtin_fmaf(pz, c_q[j], __builtin_fmaf(rzm, c_so[j], rz * c_si[j]));
-        } else {
-          v = acc[i][j][e] + c_bias[j];
-          s2 = pz * c_q[j];
-        }
+    for (int j = 0; j < C::NI; ++j) {
+      const int col = wc * C::TN + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
+        float v;
+        if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * c_sw[j]) + c_bias[j];
+        else v = acc[i][j][e] + c_bias[j];
         if constexpr (DENSE) {
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + wc * C::TN + j * 32 + l31] = v + __builtin_sqrtf(s2);
+          const int t = m0 + row;
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
         } else {
-          const float w = tau - v;                     // emit when v + sqrt(s2) > tau
-#ifdef MSAE_ABL_EPI_NOBAND   // tuning only: the round-1 test (results invalid)
-          if (w < 0.f && c_live[j]) {
-#else
-          if ((w < 0.f || s2 > w * w) && c_live[j]) {
-#endif
-            const float u = v + __builtin_sqrtf(s2);
-            const int col = wc * C::TN + j * 32 + l31;
+          if (__builtin_fmaf(c_h[j], bt[e], v) > tau[e] && c_live[j]) {         // upper bound of u reaches tau
             const unsigned slot = atomicAdd(q_count, 1u);                       // LDS atomic
             if (slot < QCAP) {
-              queue[slot] = ((unsigned long long)__float_as_uint(u) << 32) | (unsigned)(row << 16 | col);
+              queue[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(row << 16 | col);
             } else {                                                              // queue full: slow path
-              const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
-              const int gslot = atomicAdd(ep.cnt + t, 1);
-              if (gslot < ep.cap)
-                ep.cand[(size_t)t * ep.cap + gslot] =
-                    ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+              const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
+              if (u > tau[e]) {
+                const int t = m0 + row;
+                const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+                const int gslot = atomicAdd(ep.cnt + t, 1);
+                if (gslot < ep.cap)
+                  ep.cand[(size_t)t * ep.cap + gslot] =
+                      ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+              }
             }
           }
         }
@@ -354,7 +359,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
-      const float u = __uint_as_float((unsigned)(e >> 32));
+      const float v = __uint_as_float((unsigned)(e >> 32));
+      const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));   // the exact upper value
+      if (!(u > row_c[row])) continue;
       const int t = m0 + row;
       const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
       const int gslot = atomicAdd(ep.cnt + t, 1);
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
   //   threads [0, BM)      : tau (THRESH) and (sx, m, P) of row m0 + tid
   //   threads [BM, BM+BN)  : bias and (sw, Q, Si, So) of column n0 + tid - BM
-  float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
+  float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f, side5 = 0.f;
   int side2 = 1;
   {
     const int tid = tid_;
@@ -414,6 +421,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         side3 = rc[2];
         side4 = 1.f;
         if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
+        if constexpr (!DENSE) {   // B_t: z sigma of this token against the reference feature
+          float b2 = rc[2] * ep.refs[0];
+          if constexpr (C::I8) {
+            const float rz = rc[0] * rc[0] * ep.zz12;
+            b2 = __builtin_fmaf(rz * side4 * side4, ep.refs[2], __builtin_fmaf(rz, ep.refs[1], b2));
+          }
+          side5 = __builtin_sqrtf(b2) * 1.00001f;
+        }
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
@@ -424,6 +439,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       side2 = __float_as_int(cc[1]);
       side3 = cc[2];
       side4 = cc[3];
+      if constexpr (!DENSE) {   // h_n >= sqrt of every ratio to the reference feature (0/0 counts as 0)
+        float h2 = cc[1] / ep.refs[0];
+        if constexpr (C::I8) {
+          h2 = fmaxf(h2, cc[2] / ep.refs[1]);
+          if (cc[3] > 0.f) h2 = fmaxf(h2, cc[3] / ep.refs[2]);
+        }
+        side5 = (cc[1] > 0.f || cc[2] > 0.f || cc[3] > 0.f) ? __builtin_sqrtf(h2) * 1.00001f : 0.f;
+      }
     }
   }
   const bool has_out = C::I8 && op.Ao != nullptr;
@@ -501,6 +524,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   reinterpret_cast<int *>(side)[2 * C::NT + tid_] = side2;
   side[3 * C::NT + tid_] = side3;
   side[4 * C::NT + tid_] = side4;
+  side[5 * C::NT + tid_] = side5;
   gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
   }
 }

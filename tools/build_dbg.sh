@@ -5,15 +5,17 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/../multimodal-sae_amd/csrc"
 OUT="$HERE/bin"
-mkdir -p "$OUT/obj"
+OBJ="$OUT/obj_$$"
+mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function -DMSAE_RESCORE_DEBUG $MSAE_DBG_FLAGS"
+NAME="${MSAE_DBG_NAME:-libmsae_dbg.so}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function ${MSAE_DBG_FLAGS--DMSAE_RESCORE_DEBUG}"
 OBJS=""
 for f in capi decode topk sparsify encode_f32 encode_fused train; do
-  "$HIPCC" $FLAGS -c "$SRC/$f.hip" -o "$OUT/obj/$f.o" &
-  OBJS="$OBJS $OUT/obj/$f.o"
+  "$HIPCC" $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
+  OBJS="$OBJS $OBJ/$f.o"
 done
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT/libmsae_dbg.so"
-rm -rf "$OUT/obj"
-echo "built $OUT/libmsae_dbg.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT/$NAME"
+rm -rf "$OBJ"
+echo "built $OUT/$NAME"

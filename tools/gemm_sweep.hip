@@ -30,7 +30,7 @@ __global__ void max_diff(const float *a, const float *b, size_t n, float *res) {
   atomicMax((int *)res, __float_as_int(m));
 }
 
-struct Ctx { unsigned short *A, *B; float *tau, *dense, *ref, *res; f32x4 *rowc, *colc; int *cnt; unsigned long long *cand; int T, d, N, Ns; };
+struct Ctx { unsigned short *A, *B; float *tau, *dense, *ref, *res; f32x4 *rowc, *colc; float *refs; int *cnt; unsigned long long *cand; int T, d, N, Ns; };
 
 template <class C>
 void run(const char *name, Ctx &c, int reps) {
@@ -40,7 +40,7 @@ void run(const char *name, Ctx &c, int reps) {
   GemmEpilogue ep{};
   float md = -1.f;
   if (!C::I8) {  // correctness on the small problem (first Ns features) against the naive reference
-    ep.dense = c.dense; ep.ld_dense = c.Ns; ep.bias_stride = 1; ep.rowc = c.rowc; ep.colc = c.colc;   // all-zero constants: u = value
+    ep.dense = c.dense; ep.ld_dense = c.Ns; ep.bias_stride = 1; ep.rowc = c.rowc; ep.colc = c.colc; ep.refs = c.refs;   // all-zero constants: u = value
     CK(hipMemset(c.dense, 0, (size_t)c.T * c.Ns * 4));
     int rc = gemm_launch<C, true>(op, c.T, c.T, c.Ns, ep, 0);
     if (rc) { printf("%-28s launch failed rc=%d\n", name, rc); return; }
@@ -50,7 +50,7 @@ void run(const char *name, Ctx &c, int reps) {
   }
   GemmEpilogue et{};
   et.bias_stride = 1; et.tau_vals = c.tau; et.tau_ld = 1; et.tau_col = 0; et.cnt = c.cnt; et.cand = c.cand; et.cap = 16; et.skip_a = et.skip_b = -1;
-  et.rowc = c.rowc; et.colc = c.colc; et.zz12 = 49.f / 12.f;
+  et.rowc = c.rowc; et.colc = c.colc; et.refs = c.refs; et.zz12 = 49.f / 12.f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) gemm_launch<C, false>(op, c.T, c.T, c.N, et, 0);
   CK(hipDeviceSynchronize());
@@ -74,6 +74,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&c.A, (size_t)c.T * c.d * 2)); CK(hipMalloc(&c.B, (size_t)c.N * c.d * 2));
   CK(hipMalloc(&c.tau, c.T * 4)); CK(hipMemset(c.tau, 0, c.T * 4));           // tau <= 0 -> nothing emitted
   CK(hipMalloc(&c.rowc, (size_t)c.T * 16)); CK(hipMemset(c.rowc, 0, (size_t)c.T * 16)); CK(hipMalloc(&c.colc, (size_t)c.N * 16)); CK(hipMemset(c.colc, 0, (size_t)c.N * 16));
+  { float one[4] = {1.f, 1.f, 1.f, 1.f}; CK(hipMalloc(&c.refs, 16)); CK(hipMemcpy(c.refs, one, 16, hipMemcpyHostToDevice)); }
   CK(hipMalloc(&c.cnt, c.T * 4)); CK(hipMemset(c.cnt, 0, c.T * 4)); CK(hipMalloc(&c.cand, (size_t)c.T * 16 * 8));
   CK(hipMalloc(&c.dense, (size_t)c.T * c.Ns * 4)); CK(hipMalloc(&c.ref, (size_t)512 * c.Ns * 4)); CK(hipMalloc(&c.res, 4));
   if (getenv("SWEEP_ZERO")) { CK(hipMemset(c.A, 0, (size_t)c.T * c.d * 2)); CK(hipMemset(c.B, 0, (size_t)c.N * c.d * 2)); printf("ZERO-FILLED operands\n"); }
