@@ -7,7 +7,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../msae/_lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-inline-asm"
 OBJS=""
 for f in capi decode topk sparsify encode_f32 encode_fused train; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" &

@@ -74,7 +74,11 @@ struct GemmOperands {
   const unsigned char *Ao, *Bo;
 };
 
-// FLAGS (tuning only; results invalid when an ABL bit is set):
+// FLAGS:
+//   bit 0 PP           two-group ping-pong k-loop (below); bits 8-11 / 12-15: LDS-DMA pieces an "early"
+//                      wave issues in the even / odd half of a k-tile (default 6 / 4; a "late" wave
+//                      issues the rest, 16 - both, all in its even half)
+//   (tuning only; results invalid when an ABL bit is set)
 //   bit 2 ABL_NOSTAGE  skip the LDS-DMA staging in the loop
 //   bit 3 ABL_NOREAD   read the fragments once and reuse them
 //   bit 4 ABL_NOMFMA   issue no MFMA
@@ -83,6 +87,9 @@ struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, STAGES = STAGES_, WM = WM_, WN = WN_;
   static constexpr bool I8 = I8_;
   static constexpr bool ABL_NOSTAGE = FLAGS_ & 4, ABL_NOREAD = FLAGS_ & 8, ABL_NOMFMA = FLAGS_ & 16;
+  static constexpr bool PP = FLAGS_ & 1;
+  static constexpr int PP_A0 = ((FLAGS_ >> 8) & 15) ? ((FLAGS_ >> 8) & 15) : 6;
+  static constexpr int PP_A1 = ((FLAGS_ >> 8) & 15) ? ((FLAGS_ >> 12) & 15) : 4;
   static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
@@ -102,35 +109,61 @@ struct GemmCfg {
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
   static constexpr int A_PIECES = A_BYTES / 1024;
   static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
+  static constexpr int PP_B0 = 2 * PPW - PP_A0 - PP_A1;   // pieces of a late wave (4 early + 4 late waves share a k-tile)
+  static_assert(!PP || (NWAVES == 8 && PP_B0 >= 0), "ping-pong loop: 8 waves, piece split must fit");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "tile shape");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 1) & 7; }
 
-// Issue this wave's share of one k-tile (byte offset kbyte in each row) into ring slot `slot`.
-template <class C>
-__device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A, size_t ldA,
-                                           const unsigned char *__restrict__ B, size_t ldB, int m0,
-                                           int n0, int Tp, int N, size_t kbyte, unsigned char *lds,
-                                           int slot, int wave, int lane) {
+// LDS-DMA staging.  A piece = 8 tile rows x 128 B = one wave instruction (16 B per lane).  Its global
+// address is a WAVE-UNIFORM base (operand + first row of the piece + k offset: SGPRs) plus a 32-bit
+// per-lane offset (row within the piece x leading dimension + swizzled 16-B chunk) that depends only
+// on the parity of the piece and on the leading dimension -- four VGPRs for the whole kernel instead
+// of one 64-bit address per piece.  (Tiles are always full: Tp % BM == 0 and N % BN == 0.)
+struct GemmStageLane {
+  unsigned off;            // byte offset of this lane inside an EVEN piece (A and B share the leading dimension);
+};                         // an odd piece flips chunk bit 2: swz(row + 8) = swz(row) ^ 4, i.e. off ^ 64
+__device__ __forceinline__ GemmStageLane gemm_stage_lane(int lane, unsigned ld) {
+  const unsigned r_in = lane >> 3, c_in = lane & 7;
+  GemmStageLane l;
+  l.off = r_in * ld + ((c_in ^ ((r_in >> 1) & 7)) << 4);   // ld % 128 == 0: bit 6 belongs to the chunk index
+  return l;
+}
+// pieces [first, first + COUNT) of one k-tile (byte offset kbyte in each row) into ring slot `slot`.
+// Branch-free on purpose: control flow between two LDS-DMA instructions makes the compiler's wait-count
+// pass drain vmcnt before each of them.
+template <class C, int COUNT>
+__device__ __forceinline__ void gemm_stage_pieces(const unsigned char *__restrict__ A,
+                                                  const unsigned char *__restrict__ B, size_t ld, int m0,
+                                                  int n0, size_t kbyte, unsigned char *lds, int slot, int first,
+                                                  const GemmStageLane &sl) {
   unsigned char *base = lds + slot * C::STAGE_BYTES;
-  const int r_in = lane >> 3, c_in = lane & 7;
 #pragma unroll
-  for (int i = 0; i < C::PPW; ++i) {
-    const int piece = wave * C::PPW + i;              // wave-uniform
+  for (int i = 0; i < COUNT; ++i) {
+    const int piece = first + i;                      // wave-uniform
     const bool isA = piece < C::A_PIECES;
     const int pl = isA ? piece : piece - C::A_PIECES;  // piece index inside its operand tile
-    const int r = pl * 8 + r_in;                      // tile row filled by this lane
-    const int c = c_in ^ gemm_swz(r);                 // global chunk landing in LDS slot (r, c_in)
-    int grow = (isA ? m0 : n0) + r;
-    const int gmax = isA ? Tp : N;
-    grow = grow < gmax ? grow : gmax - 1;             // rows past the end are loaded but never used
-    const unsigned char *src = (isA ? A + (size_t)grow * ldA : B + (size_t)grow * ldB) + kbyte + c * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(base + piece * 1024),
-                                     16, 0, 0);
+    const unsigned char *op0 = isA ? A : B;
+    const int r0 = (isA ? m0 : n0) + pl * 8;
+    const unsigned voff = sl.off ^ ((unsigned)(pl & 1) << 6);
+    const unsigned char *sbase = op0 + (size_t)r0 * ld + kbyte;         // wave-uniform: SGPR pair
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(base + piece * 1024);
+    // saddr + 32-bit voffset form, LDS base in M0.  Written as asm because the builtin materialises a
+    // 64-bit VGPR address per piece (hoisted out of the k-loop: ~2 VGPRs per piece).  No builtin LDS-DMA
+    // is left in this kernel, so the compiler never holds a value of its own in M0.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
   }
+}
+// this wave's even share (PPW pieces) of one k-tile
+template <class C>
+__device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A,
+                                           const unsigned char *__restrict__ B, size_t ld, int m0,
+                                           int n0, size_t kbyte, unsigned char *lds, int slot, int wave,
+                                           const GemmStageLane &sl) {
+  gemm_stage_pieces<C, C::PPW>(A, B, ld, m0, n0, kbyte, lds, slot, wave * C::PPW, sl);
 }
 
 __device__ __forceinline__ i32x4 gemm_frag(const unsigned char *tile, int row, int chunk) {
@@ -227,6 +260,40 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   gemm_mfma_step<C>(acc, a0, b0);
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
+}
+
+// ---- two-group ping-pong k-loop (GemmCfg::PP) ------------------------------------------------------------
+// The 8 waves form an EARLY group (waves 0-3) and a LATE group (waves 4-7); waves w and w+4 share a
+// SIMD.  Every wave alternates a MEMORY phase (12 ds_read_b128 = the fragments of half a k-tile, plus
+// its share of the next k-tile's LDS-DMA) with a COMPUTE phase (the 16 MFMAs of that half), one
+// s_barrier after each; the late group runs one phase behind, so on every SIMD one wave's MFMAs cover
+// the other wave's LDS reads / DMA issue / waits instead of both stalling together at one barrier.
+// Ring hazards (2 slots): k-tile kt+1 overwrites the slot of kt-1, whose last reader is the late group's
+// odd-half MEMORY phase -- one barrier before the early group's even-half phase of kt, where the
+// first pieces of kt+1 are issued; the late group issues all of its pieces in ITS even half, so every
+// piece has >= 1.5 phases to land before the barrier that publishes kt+1 (vmcnt(0) in front of it).
+template <class C>
+__device__ __forceinline__ void gemm_half_read(i32x4 (&a)[2][C::MI], i32x4 (&b)[2][C::NI], const unsigned char *sA,
+                                               int wr, int wc, int l31, int kh, int half) {
+  const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
+  const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
+  const unsigned rowB = base + (unsigned)C::A_BYTES + (unsigned)(wc * C::TN + l31) * 128u;
+  const unsigned sw = (unsigned)gemm_swz(l31);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const unsigned off = (((unsigned)((half * 2 + s2) * 2 + kh)) ^ sw) << 4;
+    gemm_read_frags<C>(a[s2], b[s2], rowA + off, rowB + off);
+  }
+}
+template <class C>
+__device__ __forceinline__ void gemm_half_mfma(f32x16 (&acc)[C::MI][C::NI], i32x4 (&a)[2][C::MI], i32x4 (&b)[2][C::NI]) {
+  gemm_mfma_step<C>(acc, a[0], b[0]);
+  gemm_mfma_step<C>(acc, a[1], b[1]);
+}
+__device__ __forceinline__ void gemm_phase_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class C>
@@ -405,8 +472,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
   //   threads [0, BM)      : tau (THRESH) and (sx, m, P) of row m0 + tid
   //   threads [BM, BM+BN)  : bias and (sw, Q, Si, So) of column n0 + tid - BM
-  float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f, side5 = 0.f;
+  float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
   int side2 = 1;
+  float ref0 = 1.f, ref1 = 1.f, ref2 = 1.f;
+  if constexpr (!DENSE) { ref0 = ep.refs[0]; ref1 = ep.refs[1]; ref2 = ep.refs[2]; }   // consumed after the k-loop
   {
     const int tid = tid_;
     if (tid < C::BM) {
@@ -421,14 +490,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         side3 = rc[2];
         side4 = 1.f;
         if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
-        if constexpr (!DENSE) {   // B_t: z sigma of this token against the reference feature
-          float b2 = rc[2] * ep.refs[0];
-          if constexpr (C::I8) {
-            const float rz = rc[0] * rc[0] * ep.zz12;
-            b2 = __builtin_fmaf(rz * side4 * side4, ep.refs[2], __builtin_fmaf(rz, ep.refs[1], b2));
-          }
-          side5 = __builtin_sqrtf(b2) * 1.00001f;
-        }
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
@@ -439,14 +500,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       side2 = __float_as_int(cc[1]);
       side3 = cc[2];
       side4 = cc[3];
-      if constexpr (!DENSE) {   // h_n >= sqrt of every ratio to the reference feature (0/0 counts as 0)
-        float h2 = cc[1] / ep.refs[0];
-        if constexpr (C::I8) {
-          h2 = fmaxf(h2, cc[2] / ep.refs[1]);
-          if (cc[3] > 0.f) h2 = fmaxf(h2, cc[3] / ep.refs[2]);
-        }
-        side5 = (cc[1] > 0.f || cc[2] > 0.f || cc[3] > 0.f) ? __builtin_sqrtf(h2) * 1.00001f : 0.f;
-      }
     }
   }
   const bool has_out = C::I8 && op.Ao != nullptr;
@@ -470,11 +523,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // tile sequence: [outlier tile (int8, optional)] then the nk main k-tiles
   const int lead = has_out ? 1 : 0;
   const int ntiles = op.nk + lead;
+  const GemmStageLane sl_main = gemm_stage_lane(lane, (unsigned)op.ldA);   // ldA == ldB (launcher)
+  const GemmStageLane sl_lead = gemm_stage_lane(lane, 128u);
   auto stage = [&](int tm0, int tn0, int tile, int slot) {
     if (tile < lead)
-      gemm_stage<C>(op.Ao, 128, op.Bo, 128, tm0, tn0, Tp, N, 0, smem, slot, wave, lane);
+      gemm_stage<C>(op.Ao, op.Bo, 128, tm0, tn0, 0, smem, slot, wave, sl_lead);
     else
-      gemm_stage<C>(op.A, op.ldA, op.B, op.ldB, tm0, tn0, Tp, N, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, lane);
+      gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, sl_main);
   };
   if (tile_id == (int)blockIdx.x) stage(m0, n0, 0, 0);   // later tiles: staged by their predecessor
 
@@ -494,28 +549,81 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
     ++seq;
   };
+  auto scale_by_m = [&]() {
+    // |acc| <= 128 * 127 * 127 < 2^23 here and m < 2^23: the full-rate 24-bit multiply is exact
+    // (v_mul_lo_u32 is quarter rate: 128 of them per lane cost ~2 us per tile)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = side_m[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+#pragma unroll
+        for (int j = 0; j < C::NI; ++j) {
+          i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
+          v[e] = __mul24(v[e], m);
+          acc[i][j] = __builtin_bit_cast(f32x16, v);
+        }
+      }
+  };
+  if constexpr (C::PP) {
+    const int grp = wave >> 2, wg = wave & 3;            // early (0) / late (1) group, wave within it
+    constexpr int PA = C::PP_A0 + C::PP_A1;
+    // pieces of k-tile `tile` of output tile (tm0, tn0) this wave issues in the even / odd half
+    auto stage_half = [&](int tm0, int tn0, int tile, int slot, int half) {
+      const bool ld = tile < lead;
+      const unsigned char *pa = ld ? op.Ao : op.A, *pb = ld ? op.Bo : op.B;
+      const size_t ldx = ld ? 128 : op.ldA;
+      const size_t kb = ld ? 0 : (size_t)(tile - lead) * C::ROWB;
+      GemmStageLane sl;
+      sl.off = ld ? sl_lead.off : sl_main.off;
+      if (grp == 0) {
+        if (half == 0) gemm_stage_pieces<C, C::PP_A0>(pa, pb, ldx, tm0, tn0, kb, smem, slot, wg * PA, sl);
+        else gemm_stage_pieces<C, C::PP_A1>(pa, pb, ldx, tm0, tn0, kb, smem, slot, wg * PA + C::PP_A0, sl);
+      } else if (half == 0) {
+        gemm_stage_pieces<C, C::PP_B0>(pa, pb, ldx, tm0, tn0, kb, smem, slot, 4 * PA + wg * C::PP_B0, sl);
+      }
+    };
+    wait_vmcnt<0>();                 // k-tile 0 of this output tile (staged by the predecessor) has landed
+    gemm_phase_barrier();
+    if (grp == 1) gemm_phase_barrier();                  // the late group runs one phase behind
+    i32x4 fa[2][C::MI], fb[2][C::NI];
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // ---- MEMORY phase
+        gemm_half_read<C>(fa, fb, sA, wr, wc, l31, kh, half);
+        if constexpr (!C::ABL_NOSTAGE) {
+          if (kt + 1 < ntiles) stage_half(m0, n0, kt + 1, (seq + 1) & 1, half);
+          else if (has_next) stage_half(m0n, n0n, 0, (seq + 1) & 1, half);
+        }
+        if (has_out && kt == 0 && half == 0 && tid_ < C::BM) side_m[tid_] = side2;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) lgkm_wait_tied<0, C>(fa[s2], fb[s2]);
+        if (half == 1 && grp == 1) wait_vmcnt<0>();      // late group: pieces landed before the publishing barrier
+        gemm_phase_barrier();
+        // ---- COMPUTE phase
+        gemm_half_mfma<C>(acc, fa, fb);
+        if constexpr (C::I8) {
+          if (has_out && kt == 0 && half == 1) scale_by_m();
+        }
+        if (half == 1 && grp == 0) wait_vmcnt<0>();      // early group: same barrier, reached from its compute phase
+        gemm_phase_barrier();
+      }
+      ++seq;
+    }
+    if (grp == 0) gemm_phase_barrier();                  // realign the groups for the epilogue
+  } else {
   int kt0 = 0;
   if constexpr (C::I8) {
     if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
       iteration(0, true);
       kt0 = 1;
-      // |acc| <= 128 * 127 * 127 < 2^23 here and m < 2^23: the full-rate 24-bit multiply is exact
-      // (v_mul_lo_u32 is quarter rate: 128 of them per lane cost ~2 us per tile)
-#pragma unroll
-      for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = side_m[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-#pragma unroll
-          for (int j = 0; j < C::NI; ++j) {
-            i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
-            v[e] = __mul24(v[e], m);
-            acc[i][j] = __builtin_bit_cast(f32x16, v);
-          }
-        }
+      scale_by_m();
     }
   }
   for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
+  }
 
   // park the epilogue constants in LDS (side buffer behind the ring)
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
@@ -524,7 +632,27 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   reinterpret_cast<int *>(side)[2 * C::NT + tid_] = side2;
   side[3 * C::NT + tid_] = side3;
   side[4 * C::NT + tid_] = side4;
-  side[5 * C::NT + tid_] = side5;
+  if constexpr (!DENSE) {
+    // slot 5 of the separable bound, computed only now: the loads it needs had the whole k-loop to land
+    float side5 = 0.f;
+    if (tid_ < C::BM) {          // B_t: z sigma of this token against the reference feature
+      float b2 = side3 * ref0;
+      if constexpr (C::I8) {
+        const float rz = side1 * side1 * ep.zz12;
+        b2 = __builtin_fmaf(rz * side4 * side4, ref2, __builtin_fmaf(rz, ref1, b2));
+      }
+      side5 = __builtin_sqrtf(b2) * 1.00001f;
+    } else if (tid_ < C::BM + C::BN) {   // h_n >= sqrt of every ratio to the reference feature (0/0 counts as 0)
+      const float q = __int_as_float(side2);
+      float h2 = q / ref0;
+      if constexpr (C::I8) {
+        h2 = fmaxf(h2, side3 / ref1);
+        if (side4 > 0.f) h2 = fmaxf(h2, side4 / ref2);
+      }
+      side5 = (q > 0.f || side3 > 0.f || side4 > 0.f) ? __builtin_sqrtf(h2) * 1.00001f : 0.f;
+    }
+    side[5 * C::NT + tid_] = side5;
+  }
   gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
   }
 }
@@ -532,7 +660,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 // Host launcher.  Requires Tp % BM == 0 and N % BN == 0 (checked by the caller's plan).
 template <class C, bool DENSE>
 inline int gemm_launch(const GemmOperands &op, int T, int Tp, int N, const GemmEpilogue &ep, hipStream_t s) {
-  if (Tp % C::BM || N % C::BN || op.nk <= 0) return MSAE_EINVAL;
+  if (Tp % C::BM || N % C::BN || op.nk <= 0 || op.ldA != op.ldB || op.ldA % 128) return MSAE_EINVAL;
   const int nM = Tp / C::BM, nN = N / C::BN;
   auto kern = gemm_kernel<C, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
