@@ -25,6 +25,15 @@
 //   * tile -> workgroup map is XCD-aware: the 32 workgroups resident on one XCD's 32 CUs form an
 //     8 (M) x 4 (N) super-tile sharing 8 A-tiles and 4 B-tiles in that XCD's private L2.
 //
+// Round 2 (profiles/r02_gemm_sweep_*.txt, int8 operands, 64 k-tiles per output tile): full loop 1.67 us
+// per k-tile and workgroup; LDS-DMA staging alone 1.41-1.75 us (46 GB/s per CU out of L2, the same with
+// plain global_load_dwordx4 -> ds_write_b128 staging: 1.72 us, so it is the L2 -> CU delivery of this
+// access pattern, not the DMA instruction); MFMA + fragment reads + barriers alone 1.35-1.40 us.  The
+// two-group ping-pong loop (GemmCfg::PP, kept as a tuning flag) hides the DMA issue behind the partner
+// wave's MFMAs but pays four barriers per k-tile: 1.81-1.92 us.  Register staging: 2.6-3.3 us (32 more
+// live VGPRs, spills).  What paid in round 2: wave-uniform DMA base addresses (saddr form, 1 VGPR) and
+// computing the epilogue's band constants after the k-loop instead of in the prologue (4.7 -> 4.27 ms).
+//
 // Measured on MI355X (tools/gemm_sweep, T=8192 K=4096 N=131072, random data; profiles/):
 //   256x256 tile, 2-slot ring, 8 waves (2x4): bf16 1.20 PFLOP/s (1.39 on zero-filled operands: the
 //   kernel is partly DVFS-bound), int8 2x that; 128x128: 1.0.  Ablations: MFMA+barriers only
