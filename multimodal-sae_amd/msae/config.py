@@ -40,6 +40,36 @@ class CacheConfig:
         return dataclasses.asdict(self)
 
 
+@dataclass
+class AttributionConfig:
+    """sae_auto_interp/config.py:121-138."""
+    model: str = "EleutherAI/pythia-160m"
+    """Name of the model to use (positional)."""
+    data_path: str = "./data/digit.json"
+    """Path to the dataset. Should be a formated json file"""
+    sae_path: Union[str, None] = None
+    """Path to your trained sae, can be either local or on the hub"""
+    selected_sae: str = "layers.24"
+    """Name of the selected sae"""
+    save_dir: str = "./attribution_cache"
+    """Save dir for your feature attribution result"""
+    method: str = "exact"
+    """"exact": the reference's per-feature loop; "batched": all features from one forward + backward"""
+
+    def to_dict(self):
+        return dataclasses.asdict(self)
+
+
+def parse_attribution_config(argv: Optional[Sequence[str]] = None) -> AttributionConfig:
+    p = argparse.ArgumentParser(description="Attribution patching (MI355X HIP path)")
+    for f in dataclasses.fields(AttributionConfig):
+        if f.name == "model":
+            p.add_argument("model", nargs="?", default=f.default, type=str)
+        else:
+            p.add_argument(f"--{f.name}", type=str, default=f.default)
+    return AttributionConfig(**vars(p.parse_args(argv)))
+
+
 _POSITIONAL = ("model", "dataset")
 
 

@@ -14,16 +14,22 @@ from ...utils import ddp_setup, load_filter, load_saes, maybe_load_llava_model, 
 
 
 def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "text"):
-    """Concatenate documents with EOS and cut into `max_seq_len` chunks (the GPT-style chunking the
-    reference uses, sae/data.py:16-100); returns a list of {"input_ids": LongTensor[max_seq_len]}."""
+    """GPT-style chunking as the reference's sae/data.py:16-100 does it: documents joined with EOS
+    (the stream starts with one), cut into chunks of exactly `max_seq_len` ids, the ragged final chunk
+    dropped.  Returns a `datasets.Dataset` in torch format with the single column `input_ids`, so the
+    caller can `.shard(world, rank, contiguous=True)` it exactly like the reference (cache.py:66)."""
+    from datasets import Dataset
+
     eos = tokenizer.eos_token_id
-    buf, out = [], []
+    buf, chunks = [eos], []
     for row in dataset:
         buf.extend(tokenizer(row[text_key], add_special_tokens=False)["input_ids"] + [eos])
         while len(buf) >= max_seq_len:
-            out.append({"input_ids": torch.tensor(buf[:max_seq_len], dtype=torch.long)})
+            chunks.append(buf[:max_seq_len])
             buf = buf[max_seq_len:]
-    return out
+    if not chunks:
+        raise ValueError("Not enough data to create a single complete batch.")   # data.py:80-85
+    return Dataset.from_dict({"input_ids": chunks}).with_format("torch", columns=["input_ids"])
 
 
 def main(cfg: CacheConfig):
@@ -39,9 +45,9 @@ def main(cfg: CacheConfig):
     dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len)
     shard_size = 0
     if ddp:
-        per = (len(dataset) + world - 1) // world          # contiguous shards (cache.py:66)
-        dataset = dataset[rank * per:(rank + 1) * per]
-        shard_size = sum(shard_offsets(len(dataset), model.device)[:rank])
+        dist.barrier()
+        dataset = dataset.shard(world, rank, contiguous=True)       # contiguous chunks (cache.py:66)
+        shard_size = sum(shard_offsets(len(dataset), model.device)[:rank])   # all_gather_into_tensor (cache.py:67-75)
     saes = load_saes(cfg.sae_path, filters=filters, device=model.device)
     cache = FeatureCache(model, tokenizer, saes, batch_size=cfg.batch_size, shard_size=shard_size,
                          filters=filters)

@@ -278,19 +278,134 @@ def train_fixture(Sae, SaeConfig):
     print("wrote g7_train", out["fvu"], out["auxk_loss"], out["multi_topk_fvu"])
 
 
+def attribution_fixture(Sae, SaeConfig):
+    """`Attribution.get_attribution` of the reference itself (features/patching/attribution.py:116-189,
+    hooks of patching/utils.py:21-79) on the tiny LLaVA stand-in of tests/fakes.py with an SAE spliced
+    into `layers.0`.  The constructor (files, PIL images, tokenizer) is bypassed; every line of the
+    scoring loop runs as written."""
+    from functools import partial
+
+    import torch.distributed as dist
+
+    import fakes
+    from sae_auto_interp.features.patching.attribution import Attribution
+    from sae_auto_interp.features.patching.utils import get_logit_diff
+
+    d, N, k, vocab = 64, 1024, 8, 40
+    model = fakes.TinyLlava(vocab=vocab, d=d, n_layers=2, seed=300)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=9)
+    module = "layers.0"
+    inputs = fakes.FakeProcessor(vocab)(text=["<image>"] * 2, images=[fakes.FakeImage(0), fakes.FakeImage(1)])
+    answer_ids = torch.tensor([[5, 11], [17, 2]])
+    attr = Attribution.__new__(Attribution)
+    attr.model, attr.image_processor = model, None
+    attr.sae_dict = {module: sae}
+    attr.prompt_ids = inputs["input_ids"]
+    attr.pixel_values = inputs["pixel_values"].to(torch.float16)
+    attr.image_sizes = inputs["image_sizes"].tolist()
+    attr.attention_mask = inputs["attention_mask"].bool()
+    attr.name_to_module = {module: model.language_model.get_submodule(module)}
+    attr.module_to_name = {v: kk for kk, v in attr.name_to_module.items()}
+    attr.metric = partial(get_logit_diff, answer_token_indices=answer_ids)
+    # which features are active where (to choose informative indices)
+    captured = {}
+    h = attr.name_to_module[module].register_forward_hook(lambda m, i, o: captured.__setitem__("h", o[0]))
+    with torch.no_grad():
+        model(input_ids=attr.prompt_ids, pixel_values=attr.pixel_values)
+    h.remove()
+    with torch.no_grad():
+        top = sae.encode(captured["h"].flatten(0, 1))
+    act_idx = top.top_indices
+    inactive = [i for i in range(N) if i not in set(act_idx.flatten().tolist())][:2]
+    indices = sorted(set(act_idx[4].tolist() + act_idx[7].tolist() + act_idx[9].tolist())) + inactive
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    res = attr.get_attribution(torch.tensor(indices))
+    out = {"d": d, "N": N, "k": k, "vocab": vocab, "wseed": 9, "module": module,
+           "input_ids": attr.prompt_ids.numpy(), "pixel_values": attr.pixel_values.numpy(),
+           "answer_ids": answer_ids.numpy(), "indices": np.array(indices),
+           "attribution": torch.stack(res[module]).numpy(),            # [n_idx, B, S] fp16
+           "clean_top_idx": act_idx.numpy().astype(np.int32), "clean_top_acts": top.top_acts.numpy()}
+    np.savez_compressed(HERE / "g8_attribution.npz", **out)
+    a = out["attribution"].astype(np.float32)
+    print("wrote g8_attribution", a.shape, "max |attr|", np.abs(a).max(), "nonzero entries", int((a != 0).sum()))
+
+
+def steering_fixture(Sae, SaeConfig):
+    """`SteeringController.run` of the reference (features/steering.py:13-128): original generation,
+    then one clamped generation per feature -- the hook fires on the prefill (S != 1: clamp) and on
+    every single-token decode step (S == 1)."""
+    import importlib.util as iu
+
+    import fakes
+
+    spec = iu.spec_from_file_location("sae_auto_interp.features.steering",
+                                      REF / "sae_auto_interp" / "features" / "steering.py")
+    mod = iu.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d, N, k, vocab = 64, 1024, 8, 40
+    model = fakes.TinyLlava(vocab=vocab, d=d, n_layers=2, seed=300)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=9)
+    module, feats, clamp = "layers.0", [77, 300, 901], 50.0
+    ctl = mod.SteeringController(sae=sae, module_name=module, feature_idx=feats, model=model,
+                                 processor=fakes.FakeProcessor(vocab), prompt="describe", k=clamp)
+    res = ctl.run()
+    out = {"d": d, "N": N, "k": k, "vocab": vocab, "wseed": 9, "module": module, "features": np.array(feats),
+           "clamp": clamp, "original": np.array(res[f"{module}_feature{feats[0]}"]["original_resps"]),
+           "clamped": np.array([res[f"{module}_feature{f}"]["clamped_resps"] for f in feats])}
+    np.savez_compressed(HERE / "g10_steering.npz", **out)
+    print("wrote g10_steering", out["original"], out["clamped"])
+
+
+def image_cache_fixture(Sae, SaeConfig, cache_mod):
+    """`FeatureImageCache.run` of the reference (features/cache.py:325-429: `<image>` prompt through the
+    processor, forward of the LLaVA model, BOS position dropped, top-k, Cache.add) on the stand-ins."""
+    import fakes
+
+    d, N, k, vocab = 64, 1024, 8, 40
+    model = fakes.TinyLlava(vocab=vocab, d=d, n_layers=2, seed=300)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=9)
+    module = "layers.1"
+    fic = cache_mod.FeatureImageCache.__new__(cache_mod.FeatureImageCache)
+    fic.llava_model, fic.model, fic.tokenizer = model, model.language_model, None
+    fic.name_to_module = {module: model.language_model.get_submodule(module)}
+    fic.module_to_name = {v: kk for kk, v in fic.name_to_module.items()}
+    fic.submodule_dict = {module: sae}
+    fic.batch_size, fic.width = 2, N
+    fic.cache = cache_mod.Cache(7, None, batch_size=2)
+    fic.processor, fic.prompt = fakes.FakeProcessor(vocab), "<image>"
+    dataset = [{"image": fakes.FakeImage(i)} for i in range(5)]       # drop_last: two batches of two images
+    fic.run(0, dataset)
+    out = {"d": d, "N": N, "k": k, "vocab": vocab, "wseed": 9, "module": module, "n_images": 5, "shard_size": 7,
+           "locations": fic.cache.feature_locations[module].numpy(),
+           "activations": fic.cache.feature_activations[module].numpy()}
+    np.savez_compressed(HERE / "g9_image_cache.npz", **out)
+    print("wrote g9_image_cache", out["locations"].shape, out["locations"][:2].tolist(),
+          "max pos", int(out["locations"][:, 1].max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated fixture functions to (re)generate")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     Sae, SaeConfig, eager_decode, cache_mod = _import_reference()
+    if args.only:
+        for name in args.only.split(","):
+            fn = globals()[name]
+            fn(Sae, SaeConfig, cache_mod) if name in ("cache_fixture", "image_cache_fixture") else fn(Sae, SaeConfig)
+        return
     encode_decode_fixture(Sae, SaeConfig, "g1_c1_d768_n4096", 768, 4096, [32], 64, 1, 0)
     encode_decode_fixture(Sae, SaeConfig, "g2_d4096_n16384", 4096, 16384, [32, 256], 16, 2, 3)
     decode_seam_fixture(eager_decode)
     cache_fixture(Sae, SaeConfig, cache_mod)
     hook_fixture(Sae, SaeConfig)
     train_fixture(Sae, SaeConfig)
+    attribution_fixture(Sae, SaeConfig)
+    steering_fixture(Sae, SaeConfig)
+    image_cache_fixture(Sae, SaeConfig, cache_mod)
     if args.full:
         encode_decode_fixture(Sae, SaeConfig, "g2_c2_d4096_n131072", 4096, 131072, [32, 256], 16, 3, 4)
 
