@@ -5,14 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of T synthetic activations already resident in
-HBM: fused Sae.encode (bf16 MFMA candidate GEMM + exact f32 re-score + TopK) followed by the
+HBM: fused Sae.encode (int8 MFMA candidate GEMM + exact f32 re-score + TopK) followed by the
 k-sparse decode.  Workload = BASELINE.json configs[1]: d_model=4096, width=131072, k=32, bf16
 activations shaped like a residual stream (a few x20 outlier dims), random-init unit-norm weights.
 
-N > 1 (configs[2]): the 131072-feature axis is sharded over the ranks (N/G rows of W_enc each);
-every rank encodes the SAME T tokens against its shard, the per-shard top-k pairs are exchanged with
-one RCCL all-gather (256 B/token/rank) and merged, and the decode is token-sharded with an
-all-gather of the reconstruction.  Total work is fixed as G grows: "scaling": "strong".
+N > 1 (configs[2], the split north_star names) is the HEADLINE of a multi-GPU run: the 131072-feature
+axis is sharded over the ranks (N/G rows of W_enc each); every rank encodes the SAME T tokens against
+its shard, the per-shard top-k_loc pairs are exchanged with one RCCL all-gather (<= 256 B/token/rank)
+and merged, and the decode is token-sharded with an all-gather of the reconstruction.  Total work is
+fixed as G grows: "scaling": "strong", value = T * steps / max-over-ranks time.  The reference's own
+multi-GPU mode -- token-sharded replicas, no data-path collective (launch/cache/cache.py:66) -- is
+measured in the same run and reported under "replicas" (weak scaling).
+
+Optional real inputs (N = 1): --sae_path <dir with cfg.json + sae.safetensors> and/or
+--acts <file.safetensors holding one [T, d] tensor> replace the synthetic SAE / activations.
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,15 +51,17 @@ STAGES = ["prep", "sample_gemm", "threshold_topk", "main_gemm", "select_rescore"
 SHARDED_LEG_TIMEOUT_S = 240   # watchdog of the second (RCCL) leg; the headline line is printed regardless
 
 
-def make_inputs(dev, T, d, N, seed=0, rows=None):
-    """Synthetic SAE + activations.  `rows` = (lo, hi) slice of the feature axis held by this rank.
-    The SAE (weights, biases) is the same on every rank; `seed` only selects the activation batch."""
+def make_inputs(dev, T, d, N, seed=0, rows=None, dec_rows=None):
+    """Synthetic SAE + activations.  `rows` = (lo, hi) slice of the feature axis of W_enc / b_enc held by
+    this rank (`dec_rows` likewise for W_dec; default = the same slice).  The SAE (weights, biases) is
+    the same on every rank; `seed` only selects the activation batch."""
     gw = torch.Generator(device=dev).manual_seed(1234)
     g = torch.Generator(device=dev).manual_seed(4321 + seed)
     lo, hi = rows if rows else (0, N)
+    dlo, dhi = dec_rows if dec_rows else (lo, hi)
     # generate per 8192-row block so every rank draws identical values for its slice
     W_enc = torch.empty(hi - lo, d, device=dev)
-    W_dec = torch.empty(hi - lo, d, device=dev)
+    W_dec = torch.empty(dhi - dlo, d, device=dev)
     blk = 8192
     for b0 in range(0, N, blk):
         gb = torch.Generator(device=dev).manual_seed(977 * (b0 // blk) + 5)
@@ -62,9 +70,11 @@ def make_inputs(dev, T, d, N, seed=0, rows=None):
         s0, s1 = max(b0, lo), min(b0 + blk, hi)
         if s0 < s1:
             we = we / we.norm(dim=1, keepdim=True)
-            wd = wd / wd.norm(dim=1, keepdim=True)
             W_enc[s0 - lo:s1 - lo] = we[s0 - b0:s1 - b0]
-            W_dec[s0 - lo:s1 - lo] = wd[s0 - b0:s1 - b0]
+        s0, s1 = max(b0, dlo), min(b0 + blk, dhi)
+        if s0 < s1:
+            wd = wd / wd.norm(dim=1, keepdim=True)
+            W_dec[s0 - dlo:s1 - dlo] = wd[s0 - b0:s1 - b0]
         del we, wd
     b_enc = (torch.randn(N, generator=gw, device=dev) * 0.02)[lo:hi].contiguous()
     b_dec = torch.randn(d, generator=gw, device=dev) * 0.1
@@ -72,6 +82,24 @@ def make_inputs(dev, T, d, N, seed=0, rows=None):
     for j in range(4):
         x[:, (j * 977 + 13) % d] *= 20.0
     return W_enc, b_enc, W_dec, b_dec, x.to(torch.bfloat16)
+
+
+def load_real_inputs(dev, sae_path, acts_path, T):
+    """--sae_path / --acts: a released checkpoint directory and/or cached activations."""
+    from safetensors.torch import load_file
+
+    out = {}
+    if sae_path:
+        from msae import Sae
+
+        sae = Sae.load_from_disk(sae_path, device=dev)
+        out.update(W_enc=sae.encoder.weight.data, b_enc=sae.encoder.bias.data, W_dec=sae.W_dec.data,
+                   b_dec=sae.b_dec.data, k=sae.cfg.k)
+    if acts_path:
+        t = next(iter(load_file(acts_path).values()))
+        x = t.reshape(-1, t.shape[-1])[:T].to(dev)
+        out["x"] = x if x.dtype in (torch.bfloat16, torch.float16, torch.float32) else x.float()
+    return out
 
 
 def cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, sample_T=256, reps=5):
@@ -112,9 +140,11 @@ def main():
     ap.add_argument("--tokens", type=int, default=8192, help="tokens per step (whole job)")
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-feature-sharded", action="store_true",
-                    help="N > 1: skip the second (feature-sharded, RCCL merge) measurement")
+    ap.add_argument("--no-replicas", action="store_true",
+                    help="N > 1: skip the second (token-sharded replicas, weak scaling) measurement")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--sae_path", default=None, help="N = 1: checkpoint dir (cfg.json + sae.safetensors)")
+    ap.add_argument("--acts", default=None, help="N = 1: safetensors file with one [T, d] activation tensor")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,10 +164,33 @@ def main():
 
     lib = _hip.load()
     T, d, N, k = args.tokens, D_MODEL, WIDTH, args.k
-    # ---- headline: tokens are independent units -> every rank runs the full SAE on ITS OWN batch of
-    # T tokens (the reference's own multi-GPU mode, launch/cache/cache.py:66), no data-path collective
-    W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=rank)
-    engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
+    force = os.environ.get("MSAE_FORCE_COLLECTIVES") == "1"      # exercise the RCCL path on a 1-rank group
+    sharded = ddp and (world > 1 or force)
+    assert N % world == 0, "the feature axis must divide over the ranks"
+    n_loc = N // world
+    lo, hi = rank * n_loc, (rank + 1) * n_loc
+    data = "synthetic"
+    # ---- headline engine.  N = 1: the whole SAE on one GPU.  N > 1: rank g holds rows [g N/G, (g+1) N/G)
+    # of W_enc / b_enc and a replicated W_dec; every rank sees the same T tokens (seed 0)
+    if sharded:
+        W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=0, rows=(lo, hi), dec_rows=(0, N))
+        engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
+                            force_collectives=force)
+    else:
+        W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=rank)
+        if args.sae_path or args.acts:
+            real = load_real_inputs(dev, args.sae_path, args.acts, T)
+            if "W_enc" in real:
+                W_enc, b_enc, W_dec, b_dec, k = real["W_enc"], real["b_enc"], real["W_dec"], real["b_dec"], real["k"]
+                N, d = W_enc.shape
+                n_loc = N
+            if "x" in real:
+                x = real["x"]
+                T = x.shape[0]
+            elif x.shape[1] != d:
+                _, _, _, _, x = make_inputs(dev, T, d, 8192, seed=rank)
+            data = "real: " + ", ".join(f"{n}={v}" for n, v in (("sae", args.sae_path), ("acts", args.acts)) if v)
+        engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
 
     def timed(eng, xin, steps, warmup, profile):
         for _ in range(warmup):
@@ -175,29 +228,46 @@ def main():
             el = float(tmax.item())
         return el, out, stage, dec_ms
 
+    # One JSON line is owed whatever happens in a collective: a wedged RCCL call cannot be caught, so a
+    # watchdog prints what has been measured so far and ends the job.
+    res = {"metric": "tokens/sec through SAE encode+TopK+decode, d=4096 width=131072", "value": None,
+           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+           "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+           "dtype": ("int8" if os.environ.get("MSAE_COARSE", "int8")[0] != "b" else "bf16") +
+                    " MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
+           "data": data}
+    emitted = threading.Event()
+
+    def emit():
+        if rank == 0 and not emitted.is_set():
+            emitted.set()
+            print(json.dumps(res), flush=True)
+
+    def on_stall():
+        res["error"] = f"a collective leg did not finish within {SHARDED_LEG_TIMEOUT_S} s"
+        emit()
+        os._exit(0)
+
+    watchdog = None
+    if sharded:
+        watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, on_stall)
+        watchdog.daemon = True
+        watchdog.start()
+
     elapsed, out, stage, dec_ms = timed(engine, x, args.steps, args.warmup, profile=True)
 
-    res = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * T * args.steps / elapsed
-        n_loc = N
-        res = {
-            "metric": "tokens/sec through SAE encode+TopK+decode, d=4096 width=131072",
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)"
-                     if os.environ.get("MSAE_COARSE", "int8")[0] != "b" else
-                     "bf16 MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: d_model=4096 width=131072 k=%d, T=%d bf16 "
-                                   "activations/step resident in HBM, random-init unit-norm f32 weights"
-                                   % (k, T),
-                       "tokens_per_step": T * world, "k": k,
-                       "parallelism": "single GPU" if world == 1 else
-                       f"dp{world}: token-sharded replicas, {T} tokens/step/GPU, no data-path collective"},
-        }
+        res["ms_per_step"] = elapsed / args.steps * 1e3
+        res["value"] = T * args.steps / elapsed          # all ranks work on the same T tokens when sharded
+        res["config"] = {
+            "workload": "BASELINE configs[1]: d_model=%d width=%d k=%d, T=%d bf16 activations/step resident in HBM, "
+                        "random-init unit-norm f32 weights" % (d, N, k, T),
+            "tokens_per_step": T, "k": k,
+            "parallelism": "single GPU" if not sharded else
+            f"feature-sharded x{world} (BASELINE configs[2]): {n_loc} rows of W_enc per rank, per-shard exact "
+            f"top-{engine.k_loc}, RCCL all-gather + merge, token-sharded decode + all-gather of the reconstruction"}
+        if sharded:
+            res["second_round_tokens"] = engine.second_round_tokens
         if len(stage):
             mean = stage.mean(0)
             t_gemm = float(mean[3]) * 1e-3
@@ -208,69 +278,46 @@ def main():
             kname = "gemm_kernel<int8,THRESH>" if i8 else "gemm_kernel<bf16,THRESH>"
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak,
-                               "ops": "2*T*d*N multiply-adds counted as 2 ops each (int8 MACs on the int8 path)",
-                               "traffic": load_traffic(kname), "launch_ms": float(mean[3])}
+                               "ops": "2*T*d*N_rank multiply-adds counted as 2 ops each (int8 MACs on the int8 path), "
+                                      "rank 0's launch",
+                               "traffic": load_traffic(kname) if world == 1 else None, "launch_ms": float(mean[3])}
             res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
             res["stage_ms"]["decode"] = dec_ms
-            bytes_dec = T * (k * d * 4 + k * 8 + d * 4)
+            tok_dec = T if not sharded else -(-T // world)
+            bytes_dec = tok_dec * (k * d * 4 + k * 8 + d * 4)
             res["decode_hbm"] = {"achieved": bytes_dec / (dec_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": bytes_dec / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             st = out["status"]
             res["fast_path_verified_frac"] = float((st == 0).float().mean().item())
-    # One JSON line is owed whatever happens in the second, collective-heavy leg: if it stalls
-    # (a wedged RCCL call cannot be caught), a watchdog prints the headline result and ends the job.
-    emitted = threading.Event()
 
-    def emit(extra=None):
-        if rank == 0 and not emitted.is_set():
-            emitted.set()
-            if extra is not None:
-                res["feature_sharded"] = extra
-            print(json.dumps(res), flush=True)
-
-    def on_stall():
-        emit({"error": f"feature-sharded leg did not finish within {SHARDED_LEG_TIMEOUT_S} s"})
-        os._exit(0)
-
-    # ---- second result (N > 1): the north-star's feature-sharded engine on ONE replicated batch --
-    # per-shard encode + TopK, RCCL all-gather + merge, token-sharded decode + all-gather (strong scaling)
-    feature = None
-    run_sharded = (ddp and (world > 1 or os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
-                   and not args.no_feature_sharded)
-    if run_sharded:
-        watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, on_stall)
-        watchdog.daemon = True
-        watchdog.start()
+    # ---- second result (N > 1): token-sharded replicas, the reference's own multi-GPU mode (weak scaling).
+    # Every rank holds the WHOLE SAE and encodes its own batch; no data-path collective.  The full SAE also
+    # gives the check of the sharded result: the merged top-k must be bit-identical to a single-GPU encode.
+    if sharded and not args.no_replicas:
         try:
-            n_loc = N // world
-            _, _, _, _, x0 = make_inputs(dev, T, d, 8192, seed=0)       # the same tokens on every rank
-            lo, hi = rank * n_loc, (rank + 1) * n_loc
-            eng_f = ShardedSae(W_enc[lo:hi], b_enc[lo:hi], W_dec, b_dec, k, rank=rank, world=world,
-                               group=dist.group.WORLD,
-                               force_collectives=os.environ.get("MSAE_FORCE_COLLECTIVES") == "1")
-            el_f, out_f, _, _ = timed(eng_f, x0, args.steps, args.warmup, profile=False)
-            # the merged result against this rank's own full-width encode of the same tokens
-            # (every rank holds the whole SAE in the headline mode): bit-identical or it is a bug
-            chk_v, chk_i, _ = ops.encode_topk(x0[:256], W_enc, b_enc, b_dec, ops.prepare_encoder(W_enc), k)
-            same = bool(torch.equal(chk_i, out_f["top_indices"][:256]) and
-                        torch.equal(chk_v, out_f["top_acts"][:256]))
-            feature = {"value": T * args.steps / el_f, "unit": "tokens/s", "ms_per_step": el_f / args.steps * 1e3,
-                       "bit_identical_to_single_gpu_on_256_tokens": same,
-                       "scaling": "strong", "tokens_per_step": T, "k_loc": eng_f.k_loc,
-                       "second_round_tokens": eng_f.second_round_tokens,
-                       "parallelism": f"feature-sharded x{world}: per-shard exact top-k_loc, RCCL all-gather + merge, "
-                                      "token-sharded decode + all-gather of the reconstruction"}
-            del eng_f
+            del engine
+            W_full, b_full, _, _, x_own = make_inputs(dev, T, d, N, seed=1 + rank, rows=(0, N), dec_rows=(0, 1))
+            chk_v, chk_i, _ = ops.encode_topk(x[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
+            same = bool(torch.equal(chk_i, out["top_indices"][:256]) and torch.equal(chk_v, out["top_acts"][:256]))
+            rep = ShardedSae(W_full, b_full, W_dec, b_dec, k)
+            el_r, _, _, _ = timed(rep, x_own, args.steps, args.warmup, profile=False)
+            if rank == 0:
+                res["sharded_bit_identical_to_single_gpu_on_256_tokens"] = same
+                res["replicas"] = {"value": world * T * args.steps / el_r, "unit": "tokens/s",
+                                   "ms_per_step": el_r / args.steps * 1e3, "scaling": "weak",
+                                   "tokens_per_step": world * T,
+                                   "parallelism": f"dp{world}: token-sharded replicas, {T} tokens/step/GPU, "
+                                                  "no data-path collective"}
         except Exception as e:   # the other ranks may now be stuck in a collective: the watchdog ends them
-            feature = {"error": f"{type(e).__name__}: {e}"}
-            emit(feature)
+            res["replicas"] = {"error": f"{type(e).__name__}: {e}"}
+            emit()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.sae_path or args.acts):
         res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
-    emit(feature)
+    emit()
     if ddp:
         dist.barrier()
-        if run_sharded:
+        if watchdog is not None:
             watchdog.cancel()
         dist.destroy_process_group()
 

@@ -343,7 +343,10 @@ class _SparseEncode(torch.autograd.Function):
             v, i = topk(pre, k)
             vals.append(v); idxs.append(i)
             if k_aux > 0:
-                v, i = topk(torch.where(dead_mask[None], pre, -torch.inf), k_aux)  # sae.py:217-220
+                dead_pre = torch.where(dead_mask[None], pre, -torch.inf)            # sae.py:217-220
+                # the LDS-resident selection kernel holds k <= 4096 (d_in <= 8192 for AuxK's k = d_in / 2);
+                # wider residual streams take the torch selection for this auxiliary term
+                v, i = topk(dead_pre, k_aux) if k_aux <= 4096 else torch.topk(dead_pre, k_aux, dim=-1)
                 vals.append(v); idxs.append(i)
             if k_multi > 0:
                 v, i = topk(pre, k_multi)                                           # sae.py:233

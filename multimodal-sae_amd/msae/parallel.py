@@ -60,10 +60,13 @@ class ShardedSae:
     def __init__(self, W_enc_shard: Tensor, b_enc_shard: Tensor, W_dec: Tensor, b_dec: Tensor, k: int,
                  rank: int = 0, world: int = 1, group=None,
                  encode_fn: Optional[Callable] = None, decode_fn: Optional[Callable] = None,
-                 force_collectives: bool = False, k_loc: Optional[int] = None):
+                 force_collectives: bool = False, k_loc: Optional[int] = None,
+                 row_offset: Optional[int] = None):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
+        # global id of this shard's first feature: equal shards unless the caller says otherwise
+        self.row_offset = rank * self.n_loc if row_offset is None else row_offset
         # collectives run whenever there is more than one rank; `force_collectives` also runs them on
         # a 1-rank group so the RCCL code path can be exercised on a single-GPU box
         self.collective = world > 1 or (force_collectives and dist.is_initialized())
@@ -79,32 +82,42 @@ class ShardedSae:
             from . import ops
 
             prepared = ops.prepare_encoder(W_enc_shard)
+            # every token the kernel cannot verify is recomputed exactly inside the call (status 0 / 1 only)
             encode_fn = lambda x, kk: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk)
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
         self._encode, self._decode = encode_fn, decode_fn
 
-    def _gather_merge(self, vals: Tensor, idx: Tensor):
-        """all-gather the [T, kk] (f32, global i32) pairs of every rank, merge to the canonical
-        top-k.  -> (vals [T,k], idx [T,k] int64, flagged [T] bool)."""
-        T, kk = vals.shape
-        packed = torch.stack((vals.contiguous().view(torch.int32),
-                              (idx + self.rank * self.n_loc).to(torch.int32)), 0).contiguous()
-        flat = torch.empty((self.world * 2, T, kk), dtype=torch.int32, device=packed.device)
-        dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
+    def _pack(self, vals: Tensor, idx: Tensor) -> Tensor:
+        """[T, kk] (f32, LOCAL i64) -> int32 [2, T, kk] = (value bits, GLOBAL feature id): what travels."""
+        return torch.stack((vals.contiguous().view(torch.int32),
+                            (idx + self.row_offset).to(torch.int32)), 0).contiguous()
+
+    def _merge_gathered(self, flat: Tensor, T: int, kk: int):
+        """flat int32 [G*2, T, kk] exactly as all_gather_into_tensor lays the ranks' packs out ->
+        (vals [T,k], idx [T,k] int64, flagged [T] bool: a shard's LAST gathered latent ranks inside the
+        merged top-k, so that shard may own further members)."""
+        G = flat.shape[0] // 2
         if flat.is_cuda:
             from . import ops
 
-            return ops.merge_topk_gathered(flat, T, self.world, kk, self.k)   # HIP merge kernel
-        g = flat.view(self.world, 2, T, kk)                     # CPU/gloo: the same merge in torch
+            return ops.merge_topk_gathered(flat, T, G, kk, self.k)   # HIP merge kernel
+        g = flat.view(G, 2, T, kk)                               # CPU/gloo: the same merge in torch
         av, ai = g[:, 0].view(torch.float32).permute(1, 0, 2), g[:, 1].permute(1, 0, 2).to(torch.int64)
         mv, mi = merge_topk(av.reshape(T, -1), ai.reshape(T, -1), self.k)
         if kk < self.k:
-            # a shard whose LAST gathered latent ranks inside the merged top-k may own further members
             kth = canonical_key(mv[:, -1], mi[:, -1])
             flagged = (canonical_key(av[:, :, -1], ai[:, :, -1]) >= kth[:, None]).any(dim=1)
         else:
             flagged = torch.zeros(T, dtype=torch.bool, device=mv.device)
         return mv, mi, flagged
+
+    def _gather_merge(self, vals: Tensor, idx: Tensor):
+        """ONE all-gather of the [T, kk] pairs of every rank, then the canonical merge."""
+        T, kk = vals.shape
+        packed = self._pack(vals, idx)
+        flat = torch.empty((self.world * 2, T, kk), dtype=torch.int32, device=packed.device)
+        dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
+        return self._merge_gathered(flat, T, kk)
 
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
@@ -122,6 +135,24 @@ class ShardedSae:
                 status = status.clone()
                 status[redo] = torch.maximum(status[redo], s2)
         return mv, mi, status
+
+    @staticmethod
+    def encode_emulated(engines, x: Tensor):
+        """The G ranks of a feature-sharded group executed one after the other in ONE process (one GPU):
+        same local encodes, same packs laid out as all_gather_into_tensor would, same merge kernel, same
+        truncation check and second round -- only the transport is a torch.cat.  For tests and per-rank
+        cost studies on a single-GPU box.  -> (vals, idx, number of second-round tokens)."""
+        e0 = engines[0]
+        T = x.shape[0]
+        packs = [e._pack(*e._encode(x, e.k_loc)[:2]) for e in engines]
+        mv, mi, flagged = e0._merge_gathered(torch.cat(packs, 0), T, e0.k_loc)
+        redo = torch.nonzero(flagged).flatten() if e0.k_loc < e0.k else flagged.new_zeros(0, dtype=torch.long)
+        if redo.numel():
+            xr = x[redo].contiguous()
+            packs = [e._pack(*e._encode(xr, e.k)[:2]) for e in engines]
+            mv2, mi2, _ = e0._merge_gathered(torch.cat(packs, 0), int(redo.numel()), e0.k)
+            mv[redo], mi[redo] = mv2, mi2
+        return mv, mi, int(redo.numel())
 
     def decode(self, vals: Tensor, idx: Tensor, gather: bool = True, async_gather: bool = False) -> Tensor:
         """Token-sharded decode.  With `async_gather` the all-gather of the reconstruction is issued

@@ -474,8 +474,43 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
-    fs = res["feature_sharded"]
-    assert "error" not in fs and fs["value"] > 0 and fs["bit_identical_to_single_gpu_on_256_tokens"] is True
+    assert "error" not in res and "feature-sharded" in res["config"]["parallelism"]
+    assert res["sharded_bit_identical_to_single_gpu_on_256_tokens"] is True
+    assert "error" not in res["replicas"] and res["replicas"]["value"] > 0 and res["replicas"]["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_feature_sharded_group_emulated_on_one_gpu(dev, G):
+    """BASELINE configs[2] with G ranks run one after the other on ONE GPU (ShardedSae.encode_emulated):
+    the local fused encodes with the truncated k_loc < k, the packs laid out as the all-gather would, the
+    HIP merge kernel, the truncation check and the second round -- the merged result must equal the
+    single-shard encode bit for bit.  A bias bump concentrates part of the global top-k in shard 0, so
+    the second round really runs."""
+    from msae import ops
+    from msae.parallel import ShardedSae
+
+    d, N, T, k = 1024, 65536, 2048, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 41)
+    b_enc[: N // G // 8] += 0.8
+    g = torch.Generator(device=dev).manual_seed(42)
+    W_dec = torch.randn(N, d, generator=g, device=dev) / d ** 0.5
+    x = _rand_x(dev, T, d, 43)
+    n_loc = N // G
+    engines = [ShardedSae(W_enc[r * n_loc:(r + 1) * n_loc].contiguous(), b_enc[r * n_loc:(r + 1) * n_loc].contiguous(),
+                          W_dec, b_dec, k, rank=r, world=G, k_loc=min(k, 2 * -(-k // G) + 8)) for r in range(G)]
+    assert engines[0].k_loc < k
+    mv, mi, redo = ShardedSae.encode_emulated(engines, x)
+    ev, ei, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, ops.prepare_encoder(W_enc), k)
+    print(f"\nG={G}: k_loc={engines[0].k_loc}, second-round tokens {redo} of {T}")
+    assert redo > 0
+    assert torch.equal(mi, ei) and torch.equal(mv, ev)
+    # token-sharded decode of the merged result == full decode
+    full = ops.decode(ei, ev, W_dec, b_dec)
+    parts = []
+    for r in range(G):
+        lo, hi, _ = __import__("msae.parallel", fromlist=["token_slice"]).token_slice(T, r, G)
+        parts.append(ops.decode(mi[lo:hi].contiguous(), mv[lo:hi].contiguous(), W_dec, b_dec))
+    assert torch.equal(torch.cat(parts), full)
 
 
 @pytest.mark.parametrize("T,G,kl,k", [(100, 8, 16, 32), (33, 2, 32, 32), (17, 4, 24, 32), (5, 8, 64, 256)])
