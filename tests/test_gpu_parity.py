@@ -491,13 +491,13 @@ def test_feature_sharded_group_emulated_on_one_gpu(dev, G):
 
     d, N, T, k = 1024, 65536, 2048, 32
     W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 41)
-    b_enc[: N // G // 8] += 0.8
+    b_enc[: N // G // 8] += 1.5
     g = torch.Generator(device=dev).manual_seed(42)
     W_dec = torch.randn(N, d, generator=g, device=dev) / d ** 0.5
     x = _rand_x(dev, T, d, 43)
     n_loc = N // G
     engines = [ShardedSae(W_enc[r * n_loc:(r + 1) * n_loc].contiguous(), b_enc[r * n_loc:(r + 1) * n_loc].contiguous(),
-                          W_dec, b_dec, k, rank=r, world=G, k_loc=min(k, 2 * -(-k // G) + 8)) for r in range(G)]
+                          W_dec, b_dec, k, rank=r, world=G, k_loc={2: 24, 4: 24, 8: 16}[G]) for r in range(G)]
     assert engines[0].k_loc < k
     mv, mi, redo = ShardedSae.encode_emulated(engines, x)
     ev, ei, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, ops.prepare_encoder(W_enc), k)
