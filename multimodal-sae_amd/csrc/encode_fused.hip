@@ -755,8 +755,26 @@ inline void prof_mark(int i, hipStream_t s) {
 }
 
 // ---- workspace carving -------------------------------------------------------------------------
+// ---- small-T path (steering decode steps, S = 1: features/steering.py:86,105-124) -------------------------
+// T <= 4 tokens cannot feed a 256-row MFMA tile; the pass is a 0.5 GiB weight stream, so it is written as
+// one: every wave walks rows of Wq with 16-B lane loads and v_dot4_i32_i8 against the tokens' activations
+// held in registers.  The activations are quantised to 15 bits as TWO int8 planes (a ~ s (128 hi + lo)),
+// which removes the massive-activation problem without the per-batch outlier machinery (column maxima,
+// outlier tile of Wq): the x-side rounding noise becomes negligible and the band constants are static.
+//   prep_small   a32, two-plane quantisation, rowc = (s, 1, P = z^2 |a|^2 / 12)
+//   gemv_small   u[t][n] = coarse + z sigma, dense [T][N] (512 KB per token)
+//   topk x 2     the SMALL_R + 1 largest u per token (LDS radix-select kernel, 32 slices then their survivors)
+//   rescore_small one WAVE per (token, candidate): the row arrives by coalesced loads into LDS, lane 0 runs the
+//                exact ascending-k f32 chain (the chain is serial by definition: ~8 us for d = 4096)
+//   finalize_small canonical top-k of the exact values; verified iff the (SMALL_R + 1)-th u lies below v_k
+constexpr int SMALL_T_MAX = 4, SMALL_R = 96, SMALL_K_MAX = 64;
+inline bool small_shape_ok(int T, int d, int N, int k) {
+  return T <= SMALL_T_MAX && k <= SMALL_K_MAX && d % 1024 == 0 && d <= 8192 && N > SMALL_R + 1 && i8_shape_ok(N, d);
+}
+
 struct FusedPlan {
-  bool fast, i8;
+  bool fast, i8, small;
+  size_t off_xhi, off_xlo, off_udense, off_skeys, off_sviol, off_sl1v, off_sl1i;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
@@ -776,6 +794,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
+    p.small = p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
     // most rows one token may read before it is handed to the exact path (the needed set is ~k + 10:
     // reaching this means the band is not separating anything); at least k + 4 (first-round minimum)
     p.r_max = k <= 64 ? 8 * k : 3 * k;
@@ -794,11 +813,21 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     }
     p.off_rowc = take((size_t)p.Tp * 16);
     p.off_refs = take(256);
+    if (p.small) {
+      p.off_xhi = take((size_t)T * d);
+      p.off_xlo = take((size_t)T * d);
+      p.off_udense = take((size_t)T * N * 4);
+      p.off_skeys = take((size_t)T * 128 * 8);
+      p.off_sl1v = take((size_t)T * 32 * (SMALL_R + 1) * 4);
+      p.off_sl1i = take((size_t)T * 32 * (SMALL_R + 1) * 4);
+      p.off_sviol = take((size_t)T * 4);
+    }
     p.off_xb = take(p.i8 ? 256 : (size_t)p.Tp * d * 2);
     p.off_a32 = take((size_t)T * d * 4);
     p.off_sample = take((size_t)T * p.S * 4);
-    p.off_tauv = take((size_t)T * p.r * 4);
-    p.off_taui = take((size_t)T * p.r * 4);
+    const size_t tau_n = (size_t)T * (p.r > SMALL_R + 1 ? p.r : SMALL_R + 1);   // small path: top-(SMALL_R + 1) upper values
+    p.off_tauv = take(tau_n * 4);
+    p.off_taui = take(tau_n * 4);
     p.off_cnt = take((size_t)T * 4);
     p.off_cand = take((size_t)T * p.cap * 8);
     p.fb_cap = fallback_capacity(T, N);
@@ -812,6 +841,307 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
   }
   p.bytes = o;
   return p;
+}
+
+
+// exact recompute of the flagged tokens, fb_cap at a time (device-side counts; passes without work exit
+// immediately)
+template <int DT>
+int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int d, int N,
+                       int k, int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
+                       int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
+  int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
+  int *n_flagged = flagged + T;
+  int *fb_counts = flagged + T + 64;
+  float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
+  float *fbv = reinterpret_cast<float *>(ws + pl.off_fbv);
+  int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
+  if (pl.fb_chunks > 1)
+    hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_flagged, pl.fb_cap, pl.fb_chunks, fb_counts);
+  for (int c = 0; c < pl.fb_chunks; ++c) {
+    // one pass covers every token (T <= fb_cap): the flagged count itself is the pass's row count
+    const int *rows = flagged + (size_t)c * pl.fb_cap, *n_rows = pl.fb_chunks > 1 ? fb_counts + c : n_flagged;
+    int rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, rows, n_rows, pl.fb_cap, d, N, 1, fbdense, N, s);
+    if (rc) return rc;
+    if (set_feature >= 0 || zero_feature >= 0)
+      hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_rows,
+                         set_feature, set_value, zero_feature);
+    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, fbv, fbi, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, rows, n_rows, pl.fb_cap, k,
+                       vals, idx, status, g_status_detail);
+  }
+  return 0;
+}
+
+// ---- small-T path kernels ---------------------------------------------------------------------------------
+// one 256-thread workgroup per token: a32, two-plane quantisation q = rint(a / s), q = 128 hi + lo with
+// hi in [-127, 127], lo in [-64, 63], s = max|a| / 16319; rowc[t] = (s, 1, z^2 |a|^2 / 12, 0)
+template <int DT>
+__global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
+                                                         int d, float *__restrict__ a32, signed char *__restrict__ xhi,
+                                                         signed char *__restrict__ xlo, f32x4 *__restrict__ rowc,
+                                                         float zz12, int *__restrict__ zero_a, int n_a,
+                                                         int *__restrict__ zero_b, int n_b) {
+  __shared__ float red[2][4];
+  const int t = blockIdx.x;
+  if (t == 0) {   // per-call counters (model-check flags, flag list + counts) start at zero
+    for (int i = threadIdx.x; i < n_a; i += 256) zero_a[i] = 0;
+    for (int i = threadIdx.x; i < n_b; i += 256) zero_b[i] = 0;
+  }
+  float m = 0.f, ss = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
+    if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+    *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m = fmaxf(m, fabsf(v[e])); ss = __builtin_fmaf(v[e], v[e], ss); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off, 64)); ss += __shfl_xor(ss, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float scale = m > 0.f ? m / 16319.f : 1.f;
+  if (threadIdx.x == 0) rowc[t] = f32x4{scale, 1.f, zz12 * ss, 0.f};
+  const float inv = 1.f / scale;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);
+    unsigned wh = 0, wl = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q = (int)rintf(v[e] * inv);
+      q = q > 16319 ? 16319 : (q < -16319 ? -16319 : q);
+      const int hi = (q + 64) >> 7, lo = q - hi * 128;
+      wh |= ((unsigned)hi & 0xFFu) << (8 * e);
+      wl |= ((unsigned)lo & 0xFFu) << (8 * e);
+    }
+    *reinterpret_cast<unsigned *>(xhi + (size_t)t * d + c) = wh;
+    *reinterpret_cast<unsigned *>(xlo + (size_t)t * d + c) = wl;
+  }
+}
+
+// The weight stream.  A wave owns rows n = w, w + W, ...: per row DSEG loads of 16 B per lane (1 KiB per
+// instruction), 8 dot4 per segment and token, a wave reduction, u = coarse + z sigma -> dense[t][n].
+// HBM-bound: N d bytes once, whatever T <= 4.
+template <int DSEG, int TT>
+__global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__restrict__ wq, const f32x4 *__restrict__ wstat,
+                                                         const float *__restrict__ b_enc, int N, int T,
+                                                         const signed char *__restrict__ xhi,
+                                                         const signed char *__restrict__ xlo,
+                                                         const f32x4 *__restrict__ rowc, float zz12, int skip_a,
+                                                         int skip_b, float *__restrict__ dense) {
+  constexpr int d = DSEG * 1024;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  i32x4 xh[TT][DSEG], xl[TT][DSEG];
+  float sxz[TT], pz[TT], rz[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    const int tt = t < T ? t : T - 1;
+#pragma unroll
+    for (int q = 0; q < DSEG; ++q) {
+      xh[t][q] = *reinterpret_cast<const i32x4 *>(xhi + (size_t)tt * d + q * 1024 + lane * 16);
+      xl[t][q] = *reinterpret_cast<const i32x4 *>(xlo + (size_t)tt * d + q * 1024 + lane * 16);
+    }
+    const f32x4 rc = rowc[tt];
+    sxz[t] = rc[0]; pz[t] = rc[2]; rz[t] = rc[0] * rc[0] * zz12;
+  }
+  constexpr int RB = 16 / DSEG > 0 ? 16 / DSEG : 1;      // rows in flight per wave: 16 KiB of loads outstanding
+  for (int n0 = wave * RB; n0 < N; n0 += n_waves * RB) {
+    i32x4 w[RB][DSEG];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int q = 0; q < DSEG; ++q)
+        w[r][q] = (n0 + r < N) ? *reinterpret_cast<const i32x4 *>(wq + (size_t)(n0 + r) * d + q * 1024 + lane * 16)
+                               : i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+      const f32x4 st = wstat[n];
+      const float bias = b_enc ? b_enc[n] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        int ah = 0, al = 0;
+#pragma unroll
+        for (int q = 0; q < DSEG; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ah = __builtin_amdgcn_sdot4(w[r][q][e], xh[t][q][e], ah, false);
+            al = __builtin_amdgcn_sdot4(w[r][q][e], xl[t][q][e], al, false);
+          }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ah += __shfl_xor(ah, off, 64); al += __shfl_xor(al, off, 64); }
+        if (lane == 0 && t < T) {
+          const float c = (128.f * (float)ah + (float)al) * (sxz[t] * st[0]) + bias;
+          const float zs = __builtin_sqrtf(__builtin_fmaf(pz[t], st[1], rz[t] * st[2]));
+          dense[(size_t)t * N + n] = (n == skip_a || n == skip_b) ? -__builtin_inff() : c + zs;
+        }
+      }
+    }
+  }
+}
+
+// grid (SMALL_R, T), one wave each: row f of W_enc and the token's activations -> LDS by coalesced 16-B lane
+// loads, then lane 0 runs the exact ascending-k fma chain (serial by definition) out of LDS with the next
+// 32 elements' reads in flight behind the current 32 fmas.  exact[t][r] = rank key of relu(p); a pair
+// further than 6 sigma from its coarse value raises viol[t].  uidx2[r] indexes the survivor list of the
+// two-level selection: feature = slice * slice_len + uidx1[survivor].
+__global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restrict__ a32, const float *__restrict__ W_enc,
+                                                           const float *__restrict__ b_enc, int d, int slice_len,
+                                                           const float *__restrict__ uvals, const int32_t *__restrict__ uidx2,
+                                                           const int32_t *__restrict__ uidx1, int ld,
+                                                           const f32x4 *__restrict__ wstat,
+                                                           const f32x4 *__restrict__ rowc, float zz12, float z2,
+                                                           unsigned long long *__restrict__ exact, int *__restrict__ viol) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *row = reinterpret_cast<float *>(smem), *arow = row + d;
+  const int r = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+  const int surv = uidx2[(size_t)t * ld + r];
+  const int f = (surv / ld) * slice_len + uidx1[(size_t)t * 32 * ld + surv];
+  const float upper = uvals[(size_t)t * ld + r];
+  const float *__restrict__ w = W_enc + (size_t)f * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    *reinterpret_cast<f32x4 *>(row + c) = *reinterpret_cast<const f32x4 *>(w + c);
+    *reinterpret_cast<f32x4 *>(arow + c) = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  // both operands come from LDS: scalar loads of the activations would share lgkmcnt with the LDS reads
+  // (different return order -> full drains, measured 20 % slower)
+  float acc = 0.f;
+  f32x4 wa[8], aa[8], wb[8], ab[8];
+  auto fetch = [&](f32x4 (&wv)[8], f32x4 (&av)[8], int kk) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      wv[u] = *reinterpret_cast<const f32x4 *>(row + kk + 4 * u);
+      av[u] = *reinterpret_cast<const f32x4 *>(arow + kk + 4 * u);
+    }
+  };
+  auto consume = [&](const f32x4 (&wv)[8], const f32x4 (&av)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_fmaf(av[u][0], wv[u][0], acc);
+      acc = __builtin_fmaf(av[u][1], wv[u][1], acc);
+      acc = __builtin_fmaf(av[u][2], wv[u][2], acc);
+      acc = __builtin_fmaf(av[u][3], wv[u][3], acc);
+    }
+  };
+  fetch(wa, aa, 0);
+  for (int kk = 0; kk < d; kk += 64) {     // d % 1024 == 0
+    fetch(wb, ab, kk + 32);
+    consume(wa, aa);
+    if (kk + 64 < d) fetch(wa, aa, kk + 64);
+    consume(wb, ab);
+  }
+  const float pre = acc + (b_enc ? b_enc[f] : 0.f);
+  exact[(size_t)t * 128 + r] = rank_key(pre > 0.f ? pre : 0.f, f);
+  if (upper > -__builtin_inff()) {
+    const f32x4 rc = rowc[t], st = wstat[f];
+    const float zs2 = __builtin_fmaf(rc[2], st[1], rc[0] * rc[0] * zz12 * st[2]);
+    const float diff = pre - (upper - __builtin_sqrtf(zs2));
+    if (diff * diff * z2 > GUARD_Z_CHECK * GUARD_Z_CHECK * zs2 * 1.0001f + 1e-30f) atomicOr(viol + t, 1);
+  }
+}
+
+// one wave per token: canonical top-k of the exact values (+ the steering hook's set_feature), verification
+__global__ __launch_bounds__(64) void finalize_small_kernel(const unsigned long long *__restrict__ exact,
+                                                            const float *__restrict__ uvals, int ld, int k,
+                                                            int set_feature, float set_value, const int *__restrict__ viol,
+                                                            float *__restrict__ vals, int32_t *__restrict__ idx,
+                                                            int32_t *__restrict__ status, int *__restrict__ flagged,
+                                                            int *__restrict__ n_flagged) {
+  __shared__ unsigned long long keys[128];
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int has_set = set_feature >= 0 ? 1 : 0;
+  for (int i = lane; i < 128; i += 64) {
+    unsigned long long kv = 0ull;
+    if (i < SMALL_R) kv = exact[(size_t)t * 128 + i];
+    else if (i == SMALL_R && has_set) kv = rank_key(set_value, set_feature);
+    keys[i] = kv;
+  }
+  wave_sort_desc_u64<64>(keys, 128, lane);
+  const float v_k = f32_from_order_key((unsigned)(keys[k - 1] >> 32));
+  const float tau = uvals[(size_t)t * ld + SMALL_R];            // best upper value among the rows NOT re-scored
+  const bool ok = (v_k > tau * 1.000001f) && (v_k > 0.f) && (viol[t] == 0);
+  for (int j = lane; j < k; j += 64) {
+    const unsigned long long key = keys[j];
+    idx[(size_t)t * k + j] = key ? rank_key_index(key) : 0;
+    vals[(size_t)t * k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
+  }
+  if (lane == 0) {
+    if (status) status[t] = ok ? 0 : (2 | (viol[t] ? 64 : 32));
+    if (!ok) flagged[atomicAdd(n_flagged, 1)] = t;
+  }
+}
+
+template <int DT>
+int run_small(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const Prepared &pp,
+              const unsigned char *prepared, int T, int d, int N, int k, int set_feature, float set_value,
+              int zero_feature, float *vals, int32_t *idx, int32_t *status, unsigned char *ws, const FusedPlan &pl,
+              hipStream_t s) {
+  const float z = guard_z(), zz12 = z * z / 12.f;
+  float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
+  signed char *xhi = reinterpret_cast<signed char *>(ws + pl.off_xhi);
+  signed char *xlo = reinterpret_cast<signed char *>(ws + pl.off_xlo);
+  f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
+  float *dense = reinterpret_cast<float *>(ws + pl.off_udense);
+  float *uvals = reinterpret_cast<float *>(ws + pl.off_tauv);     // [T][SMALL_R + 1] (>= T * r floats: r >= 16 ... sized below)
+  int32_t *uidx = reinterpret_cast<int32_t *>(ws + pl.off_taui);
+  unsigned long long *exact = reinterpret_cast<unsigned long long *>(ws + pl.off_skeys);
+  int *viol = reinterpret_cast<int *>(ws + pl.off_sviol);
+  int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
+  int *n_flagged = flagged + T;
+  const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
+  const f32x4 *wstat = reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat);
+  prof_mark(0, s);
+  hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, T,
+                     flagged, T + 64 + pl.fb_chunks);
+  prof_mark(1, s);
+  prof_mark(2, s);
+  prof_mark(3, s);
+  const int grid = 256 * 8;
+  const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
+#define MSAE_GEMV(DSEG, TT)                                                                                        \
+  hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(grid), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, rowc, \
+                     zz12, skip_a, skip_b, dense)
+  const int dseg = d / 1024;
+  if (T == 1) {
+    switch (dseg) { case 1: MSAE_GEMV(1, 1); break; case 2: MSAE_GEMV(2, 1); break; case 4: MSAE_GEMV(4, 1); break;
+                    case 8: MSAE_GEMV(8, 1); break; default: return MSAE_ENOTIMPL; }
+  } else if (T == 2) {
+    switch (dseg) { case 1: MSAE_GEMV(1, 2); break; case 2: MSAE_GEMV(2, 2); break; case 4: MSAE_GEMV(4, 2); break;
+                    case 8: MSAE_GEMV(8, 2); break; default: return MSAE_ENOTIMPL; }
+  } else {
+    switch (dseg) { case 1: MSAE_GEMV(1, 4); break; case 2: MSAE_GEMV(2, 4); break; case 4: MSAE_GEMV(4, 4); break;
+                    default: return MSAE_ENOTIMPL; }
+  }
+#undef MSAE_GEMV
+  // the SMALL_R + 1 largest upper values per token in two levels (one 1024-thread workgroup walking a whole
+  // 512 KB row took 110 us): 32 slices of N / 32 features each keep their best SMALL_R + 1, then one
+  // selection over the 32 x (SMALL_R + 1) survivors; uidx2 indexes the survivor list, uidx1 the slice
+  constexpr int RS1 = SMALL_R + 1, NSL = 32;
+  float *uv1 = reinterpret_cast<float *>(ws + pl.off_sl1v);
+  int32_t *ui1 = reinterpret_cast<int32_t *>(ws + pl.off_sl1i);
+  int rc = msae_topk_launch(dense, T * NSL, N / NSL, RS1, N / NSL, nullptr, uv1, ui1, s);
+  if (rc) return rc;
+  rc = msae_topk_launch(uv1, T, NSL * RS1, RS1, NSL * RS1, nullptr, uvals, uidx, s);
+  if (rc) return rc;
+  prof_mark(4, s);
+  hipLaunchKernelGGL(rescore_small_kernel, dim3(SMALL_R, T), dim3(64), (size_t)d * 8, s, a32, W_enc, b_enc, d, N / NSL, uvals,
+                     uidx, ui1, SMALL_R + 1, wstat, rowc, zz12, z * z, exact, viol);
+  hipLaunchKernelGGL(finalize_small_kernel, dim3(T), dim3(64), 0, s, exact, uvals, SMALL_R + 1, k, set_feature, set_value,
+                     viol, vals, idx, status, flagged, n_flagged);
+  prof_mark(5, s);
+  rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
+                              status, ws, pl, s);
+  if (rc) return rc;
+  prof_mark(6, s);
+  if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
+  return msae_launch_status();
 }
 
 template <int DT>
@@ -828,10 +1158,6 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + pl.off_cand);
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
   int *n_flagged = flagged + T;
-  int *fb_counts = flagged + T + 64;
-  float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
-  float *fbv = reinterpret_cast<float *>(ws + pl.off_fbv);
-  int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
   prof_mark(0, s);
@@ -937,21 +1263,9 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     }
   }
   prof_mark(5, s);
-  // exact recompute of the flagged tokens, fb_cap at a time (device-side counts; passes without work
-  // exit immediately)
-  hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_flagged, pl.fb_cap, pl.fb_chunks, fb_counts);
-  for (int c = 0; c < pl.fb_chunks; ++c) {
-    const int *rows = flagged + (size_t)c * pl.fb_cap, *n_rows = fb_counts + c;
-    rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, rows, n_rows, pl.fb_cap, d, N, 1, fbdense, N, s);
-    if (rc) return rc;
-    if (set_feature >= 0 || zero_feature >= 0)
-      hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_rows,
-                         set_feature, set_value, zero_feature);
-    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, fbv, fbi, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, rows, n_rows, pl.fb_cap, k,
-                       vals, idx, status, g_status_detail);
-  }
+  rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
+                              status, ws, pl, s);
+  if (rc) return rc;
   prof_mark(6, s);
   if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
   return msae_launch_status();
@@ -1085,6 +1399,13 @@ extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, 
   if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || !msae_aligned(W_enc, 16) ||
       (b_dec && !msae_aligned(b_dec, 16)))
     return MSAE_EALIGN;
+  if (pl.small) {
+    switch (x_dtype) {
+      case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
+      case MSAE_BF16: return run_small<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
+      default: return run_small<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
+    }
+  }
   switch (x_dtype) {
     case MSAE_F32: return run_fast<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
     case MSAE_BF16: return run_fast<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);

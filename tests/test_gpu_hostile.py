@@ -95,6 +95,36 @@ def test_trained_like_full_width(dev, coarse, k):
     _compare(ops, x, W, b, bd, k, f"trained_like/{coarse} full width k={k}", max_fallback=0.05)
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 4])
+def test_small_T_path_equals_exact(dev, T):
+    """The S = 1 path (steering decode steps, features/steering.py:86,105-124): T <= 4 tokens take the weight-
+    streaming encoder (two-plane int8 activations, dot4, row-per-wave exact re-score).  Bit-identical to the
+    exact path on trained-like weights at full width, including the hooks' edits, for 64 different inputs."""
+    from msae import ops
+
+    d, N, k = 4096, 131072, 32
+    W, b, bd = hostile.weights("trained_like", N, d, dev, seed=21)
+    prepared = ops.prepare_encoder(W)
+    xs = hostile.activations(64 * T, d, dev, seed=22)
+    n_fallback = 0
+    for c in range(64):
+        x = xs[c * T:(c + 1) * T]
+        kw = [dict(), dict(set_feature=77, set_value=10.0), dict(zero_feature=None)][c % 3]
+        pre = ops.pre_acts(x, W, b, bd)
+        if "zero_feature" in kw:
+            kw["zero_feature"] = int(pre[0].argmax())
+            pre[:, kw["zero_feature"]] = 0.0
+        if "set_feature" in kw:
+            pre[:, 77] = 10.0
+        ev, ei = ops.topk(pre, k)
+        v, i, status = ops.encode_topk(x, W, b, bd, prepared, k, **kw)
+        assert int((status >= 2).sum()) == 0
+        n_fallback += int((status == 1).sum())
+        assert torch.equal(i, ei) and torch.equal(v, ev), (c, kw)
+    print(f"\nT={T}: exact fallback on {n_fallback} of {64 * T} tokens")
+    assert n_fallback <= 0.05 * 64 * T
+
+
 def test_width_262144_against_oracle(dev):
     """BASELINE configs[4] width: fused == exact on every token, exact == CPU oracle on 16 tokens."""
     from msae import ops
