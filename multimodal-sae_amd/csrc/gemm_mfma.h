@@ -29,8 +29,8 @@
 // per k-tile and workgroup; LDS-DMA staging alone 1.41-1.75 us (46 GB/s per CU out of L2, the same with
 // plain global_load_dwordx4 -> ds_write_b128 staging: 1.72 us, so it is the L2 -> CU delivery of this
 // access pattern, not the DMA instruction); MFMA + fragment reads + barriers alone 1.35-1.40 us.  The
-// two-group ping-pong loop (GemmCfg::PP, kept as a tuning flag) hides the DMA issue behind the partner
-// wave's MFMAs but pays four barriers per k-tile: 1.81-1.92 us.  Register staging: 2.6-3.3 us (32 more
+// two-group ping-pong loop (waves 0-3 / 4-7 half a k-tile apart, one barrier per half: commit 5ad2c1e^)
+// hides the DMA issue behind the partner wave's MFMAs but pays four barriers per k-tile: 1.81-1.92 us.  Register staging: 2.6-3.3 us (32 more
 // live VGPRs, spills).  What paid in round 2: wave-uniform DMA base addresses (saddr form, 1 VGPR) and
 // computing the epilogue's band constants after the k-loop instead of in the prologue (4.7 -> 4.27 ms).
 //
@@ -84,9 +84,6 @@ struct GemmOperands {
 };
 
 // FLAGS:
-//   bit 0 PP           two-group ping-pong k-loop (below); bits 8-11 / 12-15: LDS-DMA pieces an "early"
-//                      wave issues in the even / odd half of a k-tile (default 6 / 4; a "late" wave
-//                      issues the rest, 16 - both, all in its even half)
 //   (tuning only; results invalid when an ABL bit is set)
 //   bit 2 ABL_NOSTAGE  skip the LDS-DMA staging in the loop
 //   bit 3 ABL_NOREAD   read the fragments once and reuse them
@@ -96,9 +93,6 @@ struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, STAGES = STAGES_, WM = WM_, WN = WN_;
   static constexpr bool I8 = I8_;
   static constexpr bool ABL_NOSTAGE = FLAGS_ & 4, ABL_NOREAD = FLAGS_ & 8, ABL_NOMFMA = FLAGS_ & 16;
-  static constexpr bool PP = FLAGS_ & 1;
-  static constexpr int PP_A0 = ((FLAGS_ >> 8) & 15) ? ((FLAGS_ >> 8) & 15) : 6;
-  static constexpr int PP_A1 = ((FLAGS_ >> 8) & 15) ? ((FLAGS_ >> 12) & 15) : 4;
   static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
@@ -118,8 +112,6 @@ struct GemmCfg {
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
   static constexpr int A_PIECES = A_BYTES / 1024;
   static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
-  static constexpr int PP_B0 = 2 * PPW - PP_A0 - PP_A1;   // pieces of a late wave (4 early + 4 late waves share a k-tile)
-  static_assert(!PP || (NWAVES == 8 && PP_B0 >= 0), "ping-pong loop: 8 waves, piece split must fit");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "tile shape");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -271,40 +263,6 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   gemm_mfma_step<C>(acc, a1, b1);
 }
 
-// ---- two-group ping-pong k-loop (GemmCfg::PP) ------------------------------------------------------------
-// The 8 waves form an EARLY group (waves 0-3) and a LATE group (waves 4-7); waves w and w+4 share a
-// SIMD.  Every wave alternates a MEMORY phase (12 ds_read_b128 = the fragments of half a k-tile, plus
-// its share of the next k-tile's LDS-DMA) with a COMPUTE phase (the 16 MFMAs of that half), one
-// s_barrier after each; the late group runs one phase behind, so on every SIMD one wave's MFMAs cover
-// the other wave's LDS reads / DMA issue / waits instead of both stalling together at one barrier.
-// Ring hazards (2 slots): k-tile kt+1 overwrites the slot of kt-1, whose last reader is the late group's
-// odd-half MEMORY phase -- one barrier before the early group's even-half phase of kt, where the
-// first pieces of kt+1 are issued; the late group issues all of its pieces in ITS even half, so every
-// piece has >= 1.5 phases to land before the barrier that publishes kt+1 (vmcnt(0) in front of it).
-template <class C>
-__device__ __forceinline__ void gemm_half_read(i32x4 (&a)[2][C::MI], i32x4 (&b)[2][C::NI], const unsigned char *sA,
-                                               int wr, int wc, int l31, int kh, int half) {
-  const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
-  const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
-  const unsigned rowB = base + (unsigned)C::A_BYTES + (unsigned)(wc * C::TN + l31) * 128u;
-  const unsigned sw = (unsigned)gemm_swz(l31);
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const unsigned off = (((unsigned)((half * 2 + s2) * 2 + kh)) ^ sw) << 4;
-    gemm_read_frags<C>(a[s2], b[s2], rowA + off, rowB + off);
-  }
-}
-template <class C>
-__device__ __forceinline__ void gemm_half_mfma(f32x16 (&acc)[C::MI][C::NI], i32x4 (&a)[2][C::MI], i32x4 (&b)[2][C::NI]) {
-  gemm_mfma_step<C>(acc, a[0], b[0]);
-  gemm_mfma_step<C>(acc, a[1], b[1]);
-}
-__device__ __forceinline__ void gemm_phase_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 template <class C>
 __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                              const unsigned char *sB, int wr, int wc, int l31, int kh,
@@ -386,6 +344,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
   }
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#ifdef MSAE_ABL_NOEPI      // tuning builds only (tools/build_dbg.sh): skip the element loop
+  if (!DENSE && ep.cap != -12345) { asm volatile("" ::"v"(acc[0][0][0])); } else
+#endif
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
     float tau[16], rs[16], bt[16];
@@ -431,7 +392,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
   }
   if constexpr (!DENSE) {
     __syncthreads();
+#ifdef MSAE_ABL_NOFLUSH     // tuning builds only: drop the queue instead of flushing it
+    const unsigned nq = 0;
+#else
     const unsigned nq = *q_count < QCAP ? *q_count : QCAP;
+#endif
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
@@ -477,15 +442,17 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     m0n = tm * C::BM, n0n = tn * C::BN;
   }
 
-  // Row / column constants of the epilogue: fetched NOW into two registers per thread, parked in
-  // the LDS side buffer after the k-loop, so the epilogue never waits on global memory.
+  // Row / column constants of the epilogue: fetched NOW into registers, parked in the LDS side buffer
+  // after the k-loop, so the epilogue never waits on global memory.  (Issuing these loads behind the
+  // tile's first barrier instead -- so that the first vmcnt(0) does not wait for them -- measured 5 %
+  // SLOWER: their address arithmetic then sits between the DMA issue and the first MFMAs of the tile.)
   //   threads [0, BM)      : tau (THRESH) and (sx, m, P) of row m0 + tid
   //   threads [BM, BM+BN)  : bias and (sw, Q, Si, So) of column n0 + tid - BM
   float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
   int side2 = 1;
   float ref0 = 1.f, ref1 = 1.f, ref2 = 1.f;
-  if constexpr (!DENSE) { ref0 = ep.refs[0]; ref1 = ep.refs[1]; ref2 = ep.refs[2]; }   // consumed after the k-loop
   {
+    if constexpr (!DENSE) { ref0 = ep.refs[0]; ref1 = ep.refs[1]; ref2 = ep.refs[2]; }   // consumed after the k-loop
     const int tid = tid_;
     if (tid < C::BM) {
       const int t = m0 + tid;
@@ -574,55 +541,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         }
       }
   };
-  if constexpr (C::PP) {
-    const int grp = wave >> 2, wg = wave & 3;            // early (0) / late (1) group, wave within it
-    constexpr int PA = C::PP_A0 + C::PP_A1;
-    // pieces of k-tile `tile` of output tile (tm0, tn0) this wave issues in the even / odd half
-    auto stage_half = [&](int tm0, int tn0, int tile, int slot, int half) {
-      const bool ld = tile < lead;
-      const unsigned char *pa = ld ? op.Ao : op.A, *pb = ld ? op.Bo : op.B;
-      const size_t ldx = ld ? 128 : op.ldA;
-      const size_t kb = ld ? 0 : (size_t)(tile - lead) * C::ROWB;
-      GemmStageLane sl;
-      sl.off = ld ? sl_lead.off : sl_main.off;
-      if (grp == 0) {
-        if (half == 0) gemm_stage_pieces<C, C::PP_A0>(pa, pb, ldx, tm0, tn0, kb, smem, slot, wg * PA, sl);
-        else gemm_stage_pieces<C, C::PP_A1>(pa, pb, ldx, tm0, tn0, kb, smem, slot, wg * PA + C::PP_A0, sl);
-      } else if (half == 0) {
-        gemm_stage_pieces<C, C::PP_B0>(pa, pb, ldx, tm0, tn0, kb, smem, slot, 4 * PA + wg * C::PP_B0, sl);
-      }
-    };
-    wait_vmcnt<0>();                 // k-tile 0 of this output tile (staged by the predecessor) has landed
-    gemm_phase_barrier();
-    if (grp == 1) gemm_phase_barrier();                  // the late group runs one phase behind
-    i32x4 fa[2][C::MI], fb[2][C::NI];
-    for (int kt = 0; kt < ntiles; ++kt) {
-      const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        // ---- MEMORY phase
-        gemm_half_read<C>(fa, fb, sA, wr, wc, l31, kh, half);
-        if constexpr (!C::ABL_NOSTAGE) {
-          if (kt + 1 < ntiles) stage_half(m0, n0, kt + 1, (seq + 1) & 1, half);
-          else if (has_next) stage_half(m0n, n0n, 0, (seq + 1) & 1, half);
-        }
-        if (has_out && kt == 0 && half == 0 && tid_ < C::BM) side_m[tid_] = side2;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) lgkm_wait_tied<0, C>(fa[s2], fb[s2]);
-        if (half == 1 && grp == 1) wait_vmcnt<0>();      // late group: pieces landed before the publishing barrier
-        gemm_phase_barrier();
-        // ---- COMPUTE phase
-        gemm_half_mfma<C>(acc, fa, fb);
-        if constexpr (C::I8) {
-          if (has_out && kt == 0 && half == 1) scale_by_m();
-        }
-        if (half == 1 && grp == 0) wait_vmcnt<0>();      // early group: same barrier, reached from its compute phase
-        gemm_phase_barrier();
-      }
-      ++seq;
-    }
-    if (grp == 0) gemm_phase_barrier();                  // realign the groups for the epilogue
-  } else {
   int kt0 = 0;
   if constexpr (C::I8) {
     if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
@@ -632,7 +550,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
   }
   for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
-  }
 
   // park the epilogue constants in LDS (side buffer behind the ring)
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);

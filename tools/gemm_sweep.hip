@@ -84,19 +84,11 @@ int main(int argc, char **argv) {
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
   const char *only = getenv("SWEEP_ONLY");   // "pp": just the schedule comparison
   RUN(256, 256, 2, 2, 4, false);
-  RUN(256, 256, 2, 2, 4, false, 1);        // ping-pong, pieces 6/4/6
   RUN(256, 256, 2, 2, 4, true);
-  RUN(256, 256, 2, 2, 4, true, 1);
-  RUN(256, 256, 2, 2, 4, true, 0x2801);    // 8/2/6
-  RUN(256, 256, 2, 2, 4, true, 0x4801);    // 8/4/4
-  RUN(256, 256, 2, 2, 4, true, 0x4401);    // 4/4/8
-  RUN(256, 256, 2, 2, 4, true, 0x6A01);    // 10/6/0
-  RUN(256, 256, 2, 2, 4, true, 0x0801);    // 8/0/8
   if (!only) {
     RUN(256, 256, 2, 2, 4, false, 24);     // staging only, 8 waves
     RUN(256, 256, 2, 2, 4, true, 24);      // staging only, int8 byte layout
     RUN(256, 256, 2, 2, 4, true, 4);       // no staging (MFMA + reads + barriers)
-    RUN(256, 256, 2, 2, 4, true, 5);       // ping-pong, no staging
   }
   return 0;
 }
