@@ -1,29 +1,66 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench, rocprof kernel stats.  Everything lands in
-# gpurun_out/ (merged back by gpurun).  Each step has its own timeout and never aborts the rest.
+# One full GPU-box visit of a round: parity tests, smoke, bench (+bf16), rocprof kernel stats, PMC passes,
+# re-score statistics, soak, other shapes, small-T latency, per-rank shard emulation, training step,
+# real-input runner.  Everything lands in gpurun_out/ (merged back by gpurun); each step has its own timeout.
 cd "$(dirname "$0")/.."
 OUT=gpurun_out
+R=${ROUND:-r02}
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== host ==" > $OUT/host.txt
-(nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -8) >> $OUT/host.txt 2>&1
-echo "== pytest -m gpu ==" 
-timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS} > $OUT/pytest_gpu.log 2>&1
+(nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -8) > $OUT/host.txt 2>&1
+if [ -z "$SKIP_TESTS" ]; then
+echo "== pytest -m gpu =="
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
-tail -40 $OUT/pytest_gpu.log
+grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5
+fi
 echo "== smoke =="
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -5 $OUT/smoke.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
 echo "== bench =="
-timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
-echo "== rocprof =="
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/${R}_bench.json
+MSAE_COARSE=bf16 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_bf16.json 2>> $OUT/bench.err; echo "bench bf16 exit $?"
+echo "== rocprof kernel stats =="
 rm -rf $OUT/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
-find $OUT/prof -name "*stats*" | head; 
-for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f; done
-# drop the bulky per-dispatch trace, keep the stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
+for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f | cut -c1-160; done
 find $OUT/prof -name "*kernel_trace*" -size +2M -delete
-echo "== training step (BASELINE configs[3]) =="
-timeout 300 python tools/train_step_bench.py > $OUT/train_step.txt 2>&1; tail -1 $OUT/train_step.txt
-rm -rf $OUT/prof_train
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o tr -- python tools/train_step_bench.py > /dev/null 2> $OUT/rocprof_train.err; echo "rocprof train exit $?"
-find $OUT/prof_train -name "*kernel_trace*" -size +2M -delete
+echo "== PMC passes =="
+timeout 1500 bash tools/gpu_pmc.sh > $OUT/pmc.log 2>&1; tail -8 $OUT/pmc.log
+python tools/pmc_traffic.py $OUT/pmc_summary.json $OUT/pmc_traffic.json > /dev/null 2>&1
+echo "== rescore stats =="
+MSAE_HIP_LIB=tools/bin/libmsae_dbg.so timeout 600 python tools/rescore_stats.py bench trained_like > $OUT/${R}_rescore_stats.txt 2>&1; tail -4 $OUT/${R}_rescore_stats.txt
+echo "== soak =="
+timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
+timeout 900 python tools/soak_fused.py --tokens 131072 --N 131072 --d 4096 --out $OUT/${R}_soak_128k_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
+timeout 900 python tools/soak_fused.py --tokens 131072 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_128k_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
+echo "== shapes / latency / shard emulation / training =="
+timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat $OUT/${R}_other_shapes.txt | grep "T="
+timeout 300 python tools/latency_small_T.py > $OUT/${R}_latency_small_T.txt 2>&1; grep "T=" $OUT/${R}_latency_small_T.txt
+timeout 600 python tools/emulate_shard.py > $OUT/${R}_emulate_shard.txt 2>&1; grep "G=" $OUT/${R}_emulate_shard.txt
+timeout 300 python tools/train_step_bench.py > $OUT/${R}_train_step.txt 2>&1; tail -1 $OUT/${R}_train_step.txt
+echo "== real-input runner (checkpoint dir + activation file written here) =="
+timeout 600 python - > $OUT/${R}_real_inputs.txt 2>&1 <<'PY'
+import json, subprocess, sys, torch
+sys.path[:0] = ["multimodal-sae_amd", "tests"]
+import hostile
+from safetensors.torch import save_file
+from msae import Sae, SaeConfig
+dev = torch.device("cuda:0")
+d, N, k = 4096, 131072, 32
+W, b, bd = hostile.weights("trained_like", N, d, dev, seed=77)
+sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)
+with torch.no_grad():
+    sae.encoder.weight.copy_(W); sae.encoder.bias.copy_(b); sae.b_dec.copy_(bd)
+    sae.W_dec.copy_(W / (W.norm(dim=1, keepdim=True) + 1e-6))
+sae.save_to_disk("/tmp/ckpt/layers.24")
+save_file({"acts": hostile.activations(16384, d, dev, seed=78).cpu()}, "/tmp/acts.safetensors")
+del sae, W
+torch.cuda.empty_cache()
+r = subprocess.run([sys.executable, "bench.py", "--sae_path", "/tmp/ckpt/layers.24", "--acts", "/tmp/acts.safetensors",
+                    "--tokens", "8192", "--steps", "5", "--warmup", "2"], capture_output=True, text=True)
+print("bench --sae_path --acts:", r.stdout.strip()[-1500:], r.stderr[-300:])
+r = subprocess.run([sys.executable, "tools/parity_real.py", "--sae_path", "/tmp/ckpt/layers.24", "--acts", "/tmp/acts.safetensors",
+                    "--out", "gpurun_out/parity_real.json"], capture_output=True, text=True)
+print("parity_real:", r.stdout.strip().splitlines()[-1][:1200], r.stderr[-300:])
+PY
+tail -3 $OUT/${R}_real_inputs.txt | cut -c1-700

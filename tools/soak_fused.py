@@ -30,7 +30,7 @@ REASONS = (("list_overflow", 4), ("tau_le_0", 8), ("fewer_than_k_candidates", 16
            ("model_check", 64))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=1 << 20)
     ap.add_argument("--kind", default="trained_like")
@@ -41,27 +41,49 @@ def main():
     ap.add_argument("--coarse", default="int8")
     ap.add_argument("--z", type=float, default=7.0)
     ap.add_argument("--out", default=str(REPO / "gpurun_out" / "soak.json"))
-    a = ap.parse_args()
+    ap.add_argument("--sae_path", default=None, help="real checkpoint dir (cfg.json + sae.safetensors) instead of --kind")
+    ap.add_argument("--acts", default=None, help="safetensors file with [T, d] activations instead of synthetic ones")
+    a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     ops.set_coarse_mode(a.coarse)
     ops.set_guard_z(a.z)
     ops.set_status_detail(True)
-    W, b, bd = hostile.weights(a.kind, a.N, a.d, dev, seed=41)
+    if a.sae_path:
+        from msae import Sae
+
+        sae = Sae.load_from_disk(a.sae_path, device=dev)
+        W, b, bd = sae.encoder.weight.data, sae.encoder.bias.data, sae.b_dec.data
+        a.N, a.d, a.k, a.kind = W.shape[0], W.shape[1], sae.cfg.k, f"checkpoint {a.sae_path}"
+    else:
+        W, b, bd = hostile.weights(a.kind, a.N, a.d, dev, seed=41)
+    acts = None
+    if a.acts:
+        from safetensors.torch import load_file
+
+        t = next(iter(load_file(a.acts).values()))
+        acts = t.reshape(-1, t.shape[-1])
+        assert acts.shape[1] == a.d, f"activations have d = {acts.shape[1]}, the SAE {a.d}"
+        a.tokens = min(a.tokens, acts.shape[0] // a.batch * a.batch) or acts.shape[0]
+        a.batch = min(a.batch, acts.shape[0])
     prepared = ops.prepare_encoder(W)
     tot = {"tokens": 0, "silent_wrong": 0, "wrong_any": 0, "verified": 0, "exact_fallback": 0, "unresolved": 0}
     reasons = {n: 0 for n, _ in REASONS}
     t_fused = t_exact = 0.0
     chunk = max(256, min(2048, (1 << 30) // (a.N * 4)))
     for s in range((a.tokens + a.batch - 1) // a.batch):
-        x = hostile.activations(a.batch, a.d, dev, seed=10_000 + s)
+        if acts is not None:
+            x = acts[s * a.batch:(s + 1) * a.batch].to(dev)
+            x = x if x.dtype in (torch.bfloat16, torch.float16, torch.float32) else x.float()
+        else:
+            x = hostile.activations(a.batch, a.d, dev, seed=10_000 + s)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         v, i, status = ops.encode_topk(x, W, b, bd, prepared, a.k)
         torch.cuda.synchronize()
         t_fused += time.perf_counter() - t0
         t0 = time.perf_counter()
-        wrong = torch.zeros(a.batch, dtype=torch.bool, device=dev)
-        for t0_ in range(0, a.batch, chunk):
+        wrong = torch.zeros(x.shape[0], dtype=torch.bool, device=dev)
+        for t0_ in range(0, x.shape[0], chunk):
             pre = ops.pre_acts(x[t0_:t0_ + chunk], W, b, bd)
             ev, ei = ops.topk(pre, a.k)
             del pre
@@ -70,7 +92,7 @@ def main():
         torch.cuda.synchronize()
         t_exact += time.perf_counter() - t0
         code = status & 0xFF
-        tot["tokens"] += a.batch
+        tot["tokens"] += x.shape[0]
         tot["silent_wrong"] += int((wrong & (code == 0)).sum())
         tot["wrong_any"] += int(wrong.sum())
         tot["verified"] += int((code == 0).sum())
