@@ -3,10 +3,11 @@ import ctypes, sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/multimodal-sae_amd')
 import bench
 from msae import ops, _hip
+from msae.parallel import default_k_loc
 lib = _hip.load()
 dev = torch.device('cuda:0'); T, d, N, k = 8192, 4096, 131072, 32
 for G in (8, 4, 2, 1):
-    kl = min(k, 2 * -(-k // G) + 8) if G > 1 else k
+    kl = default_k_loc(k, G)
     nl = N // G
     W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, T, d, N, rows=(0, nl))
     prep = ops.prepare_encoder(W_enc)
