@@ -30,7 +30,8 @@
 // plain global_load_dwordx4 -> ds_write_b128 staging: 1.72 us, so it is the L2 -> CU delivery of this
 // access pattern, not the DMA instruction); MFMA + fragment reads + barriers alone 1.35-1.40 us.  The
 // two-group ping-pong loop (waves 0-3 / 4-7 half a k-tile apart, one barrier per half: commit 5ad2c1e^)
-// hides the DMA issue behind the partner wave's MFMAs but pays four barriers per k-tile: 1.81-1.92 us.  Register staging: 2.6-3.3 us (32 more
+// hides the DMA issue behind the partner wave's MFMAs but pays four barriers per k-tile: 1.81-1.92 us.  Issuing part of a wave's DMA pieces behind
+// its own MFMA groups (2..8 pieces after k-steps 0/1/2; profiles/r02_gemm_sweep_dma_interleave.txt): -2 % to +16 %.  Register staging: 2.6-3.3 us (32 more
 // live VGPRs, spills).  What paid in round 2: wave-uniform DMA base addresses (saddr form, 1 VGPR) and
 // computing the epilogue's band constants after the k-loop instead of in the prologue (4.7 -> 4.27 ms).
 //
