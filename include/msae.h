@@ -135,7 +135,7 @@ int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const fl
 /* g_W_dec[n][:] = sum over (a, j) with idx[a][j] == n of acts[a][j] * grad_out[a][:], written to
  * the WHOLE dense [N][d] buffer (the layout autograd expects for Sae.W_dec.grad; rows without a
  * pair are zero; no pre-zeroing needed).  Pairs are grouped by feature with a counting sort and
- * summed in ascending pair order, so the result is bit-reproducible.  d % 4 == 0. */
+ * summed in ascending pair order (segments are sorted whatever their length), so the result is bit-reproducible.  d % 4 == 0. */
 size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N);
 int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
                              int k, int N, int d, float *g_W_dec, void *ws, size_t ws_bytes,

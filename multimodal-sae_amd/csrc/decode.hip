@@ -188,25 +188,64 @@ __global__ __launch_bounds__(256) void wgrad_fill_kernel(const int32_t *__restri
   if ((unsigned)i < (unsigned)N && acts[p] != 0.f) perm[atomicAdd(cursor + i, 1)] = (int)p;
 }
 
+// Ascending sort of a[0..L) by ONE wave with a network whose comparators all point the same way (first
+// step of every merge stage mirrors the block, the rest are half-cleaners), so the slots >= L act as +inf
+// without being stored.  `sync()` orders one step's writes before the next step's reads.
+template <class Sync>
+__device__ __forceinline__ void wave_sort_asc(int *a, int L, int lane, Sync &&sync) {
+  const int np = next_pow2(L);
+  for (int size = 2; size <= np; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const bool flip = stride == (size >> 1);
+      for (int i = lane; i < (np >> 1); i += 64) {
+        const int blk = i / stride, off = i % stride;
+        const int lo = blk * (stride << 1) + off;
+        const int hi = flip ? blk * size + size - 1 - off : lo + stride;
+        if (hi < L) {
+          const int x = a[lo], y = a[hi];
+          if (x > y) { a[lo] = y; a[hi] = x; }
+        }
+      }
+      sync();
+    }
+  }
+}
+
+constexpr int WGRAD_LDS_SEG = 1024;   // pair ids a wave can sort in its LDS slice
+
 // one wave per feature row n; lane owns float4 columns lane, lane+64, ... ; d % 4 == 0
 __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restrict__ acts,
                                                           const float *__restrict__ grad_out,
                                                           const int *__restrict__ offsets,
                                                           int *__restrict__ perm, int k, int N, int d,
                                                           float *__restrict__ g_W) {
+  __shared__ int s_seg[4][WGRAD_LDS_SEG];
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int beg = offsets[n], end = offsets[n + 1];
-  // deterministic order: sort the segment by pair id -- lane 0, in place, insertion sort.  Rows hit
-  // by more than 64 pairs (very dense features) keep the fill order: their sum order may vary.
-  if (lane == 0 && end - beg > 1 && end - beg <= 64) {
-    for (int a = beg + 1; a < end; ++a) {
-      const int key = perm[a];
-      int b = a - 1;
-      while (b >= beg && perm[b] > key) { perm[b + 1] = perm[b]; --b; }
-      perm[b + 1] = key;
+  const int L = end - beg;
+  // deterministic summation order: the segment (filled through an atomic cursor, i.e. in any order) is sorted
+  // by pair id = by token.  <= 64 pairs: lane 0, insertion sort; <= 1024: the wave, in LDS; longer (a feature
+  // active on more than 1024 tokens of the call): the wave, in place, agent-scope fences between the steps.
+  if (L > 1 && L <= 64) {
+    if (lane == 0) {
+      for (int a = beg + 1; a < end; ++a) {
+        const int key = perm[a];
+        int b = a - 1;
+        while (b >= beg && perm[b] > key) { perm[b + 1] = perm[b]; --b; }
+        perm[b + 1] = key;
+      }
     }
+  } else if (L > 64 && L <= WGRAD_LDS_SEG) {
+    int *seg = s_seg[threadIdx.x >> 6];
+    for (int i = lane; i < L; i += 64) seg[i] = perm[beg + i];
+    __builtin_amdgcn_wave_barrier();
+    wave_sort_asc(seg, L, lane, [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); });
+    for (int i = lane; i < L; i += 64) perm[beg + i] = seg[i];
+  } else if (L > WGRAD_LDS_SEG) {
+    volatile int *seg = perm + beg;
+    wave_sort_asc(const_cast<int *>(seg), L, lane, [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); __builtin_amdgcn_wave_barrier(); });
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();

@@ -95,6 +95,32 @@ def test_decode_backward_matches_reference_autograd(dev, golden_dir):
     np.testing.assert_allclose(acts.grad.cpu().numpy(), ga, rtol=1e-4, atol=1e-5)
 
 
+def test_decode_backward_wdec_is_bit_reproducible(dev):
+    """The weight-gradient rows are sums in ascending pair order whatever order the atomic cursor filled the
+    segments in -- also for features hit by more than 64 (LDS sort) and more than 1024 pairs (in-place
+    sort): ten calls give identical bits, and the values match a dense torch accumulation."""
+    from msae import ops
+
+    A, k, N, d = 3000, 4, 64, 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    idx = torch.stack([torch.randperm(N - 3, generator=g, device=dev)[:k] + 3 for _ in range(A)])
+    idx[:, 0] = 0                                   # feature 0: every token (3000 pairs)
+    idx[::6, 1] = 1                                 # feature 1: 500 tokens
+    idx[::50, 2] = 2                                # feature 2: 60 tokens
+    acts = torch.rand(A, k, generator=g, device=dev) + 0.1
+    gout = torch.randn(A, d, generator=g, device=dev)
+    W = torch.zeros(N, d, device=dev)
+    ref = torch.zeros(N, d, device=dev, dtype=torch.float64)
+    ref.index_add_(0, idx.reshape(-1), (acts.reshape(-1, 1).double() * gout.repeat_interleave(k, 0).double()))
+    first = None
+    for _ in range(10):
+        _, gw = ops.decode_bwd(idx, acts, W, gout, False, True)
+        if first is None:
+            first = gw.clone()
+            torch.testing.assert_close(gw.double(), ref, rtol=1e-4, atol=1e-3)
+        assert torch.equal(gw, first)
+
+
 # ---- top-k ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,N,k", [(4, 131072, 32), (3, 131072, 256), (5, 4096, 32), (3, 1000, 7),
                                    (2, 37, 37), (2, 8192, 16), (2, 16384, 2048), (1, 5, 1)])
