@@ -46,10 +46,12 @@ class Cache:
     """Accumulates COO feature records per hooked module (cache.py:23-92)."""
 
     def __init__(self, shard_size: int, filters: Optional[Dict[str, Tensor]] = None,
-                 batch_size: int = 64, spill_dir: Optional[str] = None):
+                 batch_size: int = 64, spill_dir: Optional[str] = None, device_budget_bytes: int = 256 << 20):
         """`spill_dir`: stream every batch's records to disk instead of holding the whole run in host
         RAM (the reference keeps everything in Python lists until save_splits, cache.py:56-57);
-        `save()` reads them back in batch order, so the final tensors are identical."""
+        `save()` reads them back in batch order, so the final tensors are identical.
+        `device_budget_bytes`: records of the fused path wait on the device (worst-case sized buffers, 7 MB
+        per 8192-token batch at k = 32) and cross to the host in one transfer once this much is pending."""
         self.feature_locations = defaultdict(list)
         self.feature_activations = defaultdict(list)
         self.spill_dir = spill_dir
@@ -59,6 +61,8 @@ class Cache:
         self.shard_size = shard_size  # rows held by lower ranks (cache.py:39)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self._bitmaps: Dict[str, Tensor] = {}
+        self.device_budget_bytes = device_budget_bytes
+        self._pending, self._pending_bytes = [], 0
 
     def _bitmap(self, module_path: str, num_latents: int, device) -> Optional[Tensor]:
         if self.filters is None:
@@ -75,9 +79,23 @@ class Cache:
                  module_path: str):
         """Fused equivalent of scatter_ + Cache.add (cache.py:214-217, 42-57) for `[B,S,k]` pairs."""
         row_base = batch_number * self.batch_size + self.shard_size  # cache.py:55
-        loc, act = ops.sparsify(top_acts, top_indices, num_latents, row_base=row_base, thresh=1e-5,
-                                filter_bitmap=self._bitmap(module_path, num_latents, top_acts.device))
-        self._append(module_path, loc.cpu(), act.cpu())
+        loc, act, nnz = ops.sparsify(top_acts, top_indices, num_latents, row_base=row_base, thresh=1e-5,
+                                     filter_bitmap=self._bitmap(module_path, num_latents, top_acts.device), sync=False)
+        # stays on the device, stream-ordered (the reference does a nonzero() + two .cpu() per batch inside the
+        # hook loop): records go to the host in one transfer per `device_budget_bytes` of pending batches
+        self._pending.append((module_path, loc, act, nnz))
+        self._pending_bytes += loc.numel() * 8 + act.numel() * 4
+        if self._pending_bytes >= self.device_budget_bytes:
+            self.flush_pending()
+
+    def flush_pending(self):
+        """Move the batches collected on the device to host memory (ONE host synchronisation)."""
+        if not self._pending:
+            return
+        counts = torch.stack([p[3] for p in self._pending]).cpu().tolist()
+        for (module_path, loc, act, _), n in zip(self._pending, counts):
+            self._append(module_path, loc[:n].cpu(), act[:n].cpu())
+        self._pending, self._pending_bytes = [], 0
 
     def _append(self, module_path: str, loc: Tensor, act: Tensor):
         if self.spill_dir is None:
@@ -106,6 +124,7 @@ class Cache:
         return loc[mask], act[mask]
 
     def save(self):
+        self.flush_pending()
         for module_path, paths in self._spilled.items():      # streamed batches come back in order
             parts = [load_file(p) for p in paths]
             self.feature_locations[module_path] = [p["locations"] for p in parts]

@@ -267,9 +267,14 @@ decode.register_autograd(_decode_backward, setup_context=_decode_setup)
 
 # ---- cache sparsify ---------------------------------------------------------------------------------
 def sparsify(top_acts: Tensor, top_indices: Tensor, num_latents: int, row_base: int = 0,
-             thresh: float = 1e-5, filter_bitmap: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+             thresh: float = 1e-5, filter_bitmap: Optional[Tensor] = None, sync: bool = True):
     """[B, S, k] top-k -> (locations [nnz, 3] int64, activations [nnz] f32) in the reference cache's
-    record order (row, pos, feature ascending); |v| > thresh and optional feature bitmap applied."""
+    record order (row, pos, feature ascending); |v| > thresh and optional feature bitmap applied.
+
+    sync=True reads nnz back (one int64, as `torch.nonzero` does) and returns exactly-sized tensors.
+    sync=False never touches the host: returns (locations [B*S*k, 3], activations [B*S*k], nnz) with the
+    first nnz rows valid and nnz a device int64 scalar -- for loops inside a forward hook that must stay
+    stream-ordered (msae/features/cache.py collects these and reads the counts back once per flush)."""
     dev = _hip.require_device(top_acts, top_indices, filter_bitmap)
     lib = _hip.load()
     assert top_acts.dim() == 3 and top_acts.shape == top_indices.shape
@@ -281,14 +286,14 @@ def sparsify(top_acts: Tensor, top_indices: Tensor, num_latents: int, row_base: 
         st = _hip.stream_of(vals)
         _hip.check(lib.msae_sparsify_count(_hip.ptr(vals), _hip.ptr(idx), B, S, k, thresh, _hip.ptr(fb),
                                            num_latents, _hip.ptr(counts), st), "msae_sparsify_count")
-        nnz = int(counts[-1].item())  # the one host read (torch.nonzero does the same)
+        nnz = int(counts[-1].item()) if sync else B * S * k   # the one host read (torch.nonzero does the same)
         loc = torch.empty(nnz, 3, dtype=torch.int64, device=dev)
         act = torch.empty(nnz, dtype=torch.float32, device=dev)
         if nnz:
             _hip.check(lib.msae_sparsify_write(_hip.ptr(vals), _hip.ptr(idx), B, S, k, thresh,
                                                _hip.ptr(fb), num_latents, row_base, _hip.ptr(counts),
                                                _hip.ptr(loc), _hip.ptr(act), st), "msae_sparsify_write")
-    return loc, act
+    return (loc, act) if sync else (loc, act, counts[-1])
 
 
 def merge_topk_gathered(gathered: Tensor, T: int, G: int, kl: int, k: int):
