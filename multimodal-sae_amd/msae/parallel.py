@@ -7,7 +7,7 @@ Rank g of G owns rows [g*N/G, (g+1)*N/G) of W_enc / b_enc.  Every rank sees the 
 (each rank runs the same LLM forward, or x is broadcast).  Per call:
 
   1. local fused encode + exact TopK over the shard, but only the shard's best
-     k_loc = ceil(k/G) + ceil(3 sqrt(k/G)) latents          -> (vals f32, idx i32 + g*N/G)  [T, k_loc]
+     k_loc = ceil(k/G) + ceil(5 sqrt(k/G)) latents          -> (vals f32, idx i32 + g*N/G)  [T, k_loc]
      (the global top-k puts ~k/G members in each shard, so re-scoring a full local top-k on every
      rank would multiply the HBM-bound re-score work by G)
   2. ONE all-gather of the packed pairs (8 B * k_loc per token per rank) over RCCL/xGMI --
@@ -50,11 +50,12 @@ def merge_topk(vals: Tensor, idx: Tensor, k: int):
 
 def default_k_loc(k: int, world: int) -> int:
     """Latents every shard contributes: the global top-k puts Binomial(k, 1/G) members in a shard, so
-    mean + 3 sigma (~1 % of the tokens then need the second round); all k when there is one shard."""
+    mean + 5 sigma keeps the second round (a whole extra encode call + gather whenever ANY token of the batch
+    is flagged) out of nearly every step; all k when there is one shard."""
     if world <= 1:
         return k
     mean = -(-k // world)
-    return min(k, mean + int(-(-3 * (k / world) ** 0.5 // 1)))
+    return min(k, mean + int(-(-5 * (k / world) ** 0.5 // 1)))
 
 
 def token_slice(T: int, rank: int, world: int):
