@@ -361,23 +361,43 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int col = wc * C::TN + j * 32 + l31;
+      auto value = [&](int e) {
+        if constexpr (C::I8) return (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * c_sw[j]) + c_bias[j];
+        else return acc[i][j][e] + c_bias[j];
+      };
+      auto row_of = [&](int e) { return wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh; };   // row inside the tile
+      if constexpr (DENSE) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;   // row inside the tile
-        float v;
-        if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * c_sw[j]) + c_bias[j];
-        else v = acc[i][j][e] + c_bias[j];
-        if constexpr (DENSE) {
-          const int t = m0 + row;
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-        } else {
-          if (__builtin_fmaf(c_h[j], bt[e], v) > tau[e] && c_live[j]) {         // upper bound of u reaches tau
-            const unsigned slot = atomicAdd(q_count, 1u);                       // LDS atomic
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_of(e), t = m0 + row;
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = value(e) + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
+        }
+      } else {
+        // Survivors are rare (~0.5 % of the outputs) but a per-element branch + LDS atomic costs a ~150-cycle
+        // round trip whenever ANY lane of the wave has one (27 % of the elements): 0.55 ms of the pass.  So
+        // the 16 outputs of this lane's column are tested branch-free -- count, last survivor's value and
+        // position -- and the lane reserves its queue slots with ONE LDS atomic per 16 outputs.
+        unsigned cnt = 0;
+        float hv = 0.f;
+        int he = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = value(e);
+          const bool hit = __builtin_fmaf(c_h[j], bt[e], v) > tau[e];     // upper bound of u reaches tau
+          cnt += hit ? 1u : 0u;
+          hv = hit ? v : hv;
+          he = hit ? e : he;
+        }
+        if (!c_live[j]) cnt = 0;
+        if (cnt) {
+          unsigned slot = atomicAdd(q_count, cnt);                          // LDS atomic
+          auto push = [&](float v, int e) {
+            const int row = row_of(e);
             if (slot < QCAP) {
               queue[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(row << 16 | col);
-            } else {                                                              // queue full: slow path
+            } else {                                                          // queue full: slow path
               const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-              if (u > tau[e]) {
+              if (u > row_c[row]) {
                 const int t = m0 + row;
                 const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
                 const int gslot = atomicAdd(ep.cnt + t, 1);
@@ -385,6 +405,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
                   ep.cand[(size_t)t * ep.cap + gslot] =
                       ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
               }
+            }
+            ++slot;
+          };
+          if (cnt == 1) {
+            push(hv, he);
+          } else {                                                            // several survivors in one column block
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const float v = value(e);
+              if (__builtin_fmaf(c_h[j], bt[e], v) > tau[e]) push(v, e);
             }
           }
         }
