@@ -321,6 +321,8 @@ __global__ __launch_bounds__(1024) void pick_outliers_kernel(const unsigned *__r
     is_out[c] = o ? 1 : 0;
     if (o) odims[atomicAdd(&s_cnt, 1)] = c;   // order is irrelevant: A and B use the same list
   }
+  __syncthreads();
+  if (threadIdx.x == 0) odims[MAX_OUT] = s_cnt;   // the list is compact: the GEMM multiplies only ceil(count / 32) k-steps of the outlier tile
 }
 
 // one workgroup per token row (rows >= T of the padded tile are zero): per-token scales, int8 rows and
@@ -806,7 +808,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
       p.off_colc = take((size_t)N * 16);
       p.off_colc_s = take((size_t)p.S * 16);
       p.off_colmax = take((size_t)d * 4);
-      p.off_odims = take((size_t)MAX_OUT * 4);
+      p.off_odims = take((size_t)(MAX_OUT + 1) * 4);
       p.off_isout = take((size_t)d);
       p.off_wqo = take((size_t)N * MAX_OUT);
       p.off_wqos = take((size_t)p.S * MAX_OUT);
@@ -1194,6 +1196,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     op_main.nk = d / 128;
     op_main.Ao = reinterpret_cast<const unsigned char *>(xqo);
     op_main.Bo = reinterpret_cast<const unsigned char *>(wqo);
+    op_main.n_out = odims + MAX_OUT;
     op_samp = op_main;
     op_samp.B = reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);

@@ -82,6 +82,7 @@ struct GemmOperands {
   // int8 only: optional leading outlier tile (one k-tile, rows 128 B apart); the accumulators are
   // multiplied by the token's integer multiplier m (GemmEpilogue::rowc[t][1]) after it
   const unsigned char *Ao, *Bo;
+  const int *n_out;              // device: number of outlier dims actually present (the tile is compact from column 0)
 };
 
 // FLAGS:
@@ -262,6 +263,21 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   gemm_mfma_step<C>(acc, a0, b0);
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
+}
+
+// the outlier k-tile: only its first `nks` k-steps hold data (32 outlier dims per k-step), the rest is zero
+template <class C>
+__device__ __forceinline__ void gemm_compute_lead(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
+                                                  const unsigned char *sB, int wr, int wc, int l31, int kh, int nks) {
+  for (int ks = 0; ks < nks; ++ks) {
+    const int chunk = ks * 2 + kh;
+    i32x4 a[C::MI], b[C::NI];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) a[i] = gemm_frag(sA, wr * C::TM + i * 32 + l31, chunk);
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) b[j] = gemm_frag(sB, wc * C::TN + j * 32 + l31, chunk);
+    gemm_mfma_step<C>(acc, a, b);
+  }
 }
 
 template <class C>
@@ -510,6 +526,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
   }
   const bool has_out = C::I8 && op.Ao != nullptr;
+  int lead_ks = 4;
+  if (has_out && op.n_out != nullptr) lead_ks = (*op.n_out + 31) >> 5;    // wave-uniform scalar load
 
   f32x16 acc[C::MI][C::NI];
 #pragma unroll
@@ -553,7 +571,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     }
     const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
-    gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+    if (park_m) gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
+    else gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
     ++seq;
   };
   auto scale_by_m = [&]() {
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
       iteration(0, true);
       kt0 = 1;
-      scale_by_m();
+      if (lead_ks > 0) scale_by_m();   // no outlier dim in this batch: the accumulators are still zero
     }
   }
   for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
