@@ -117,6 +117,9 @@ inline int coarse_mode() {
 }
 
 int g_status_detail = 0;   // msae_set_status_detail
+#ifdef MSAE_GEMM_TIMELINE
+unsigned long long *g_timeline = nullptr;
+#endif
 
 // ---- width of the error band: u = coarse + z*sigma (MSAE_GUARD_Z / msae_set_guard_z; default 7) ----------
 float g_guard_z = -1.f;
@@ -1219,6 +1222,9 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
     ep.dense = sample; ep.ld_dense = pl.S;
     ep.rowc = rowc; ep.colc = colc_s; ep.refs = refs; ep.zz12 = zz12;
+#ifdef MSAE_GEMM_TIMELINE
+    ep.timeline = nullptr;
+#endif
     const int grc = pl.i8 ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
     if (grc) return grc;
@@ -1238,6 +1244,11 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
     ep.rowc = rowc; ep.colc = colc; ep.refs = refs; ep.zz12 = zz12;
+#ifdef MSAE_GEMM_TIMELINE
+    if (!g_timeline) (void)hipMalloc(&g_timeline, 64 * 8 * 8);
+    (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
+    ep.timeline = g_timeline;
+#endif
     const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s)
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
     if (grc) return grc;
@@ -1289,6 +1300,13 @@ extern "C" int msae_set_guard_z(float z) {
   g_guard_z = z;
   return 0;
 }
+
+#ifdef MSAE_GEMM_TIMELINE
+extern "C" int msae_debug_timeline(unsigned long long *host_out) {   // tuning builds only (tools/gemm_timeline.py)
+  if (!g_timeline) return MSAE_EINVAL;
+  return (int)hipMemcpy(host_out, g_timeline, 64 * 8 * 8, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int msae_set_status_detail(int on) {
   g_status_detail = on ? 1 : 0;

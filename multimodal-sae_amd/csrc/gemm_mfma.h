@@ -72,7 +72,16 @@ struct GemmEpilogue {
   const f32x4 *rowc, *colc;
   const float *refs;             // (Qr, Sir, Sor): the reference feature of the separable bound
   float zz12;                    // z^2 / 12
+#ifdef MSAE_GEMM_TIMELINE        // tuning builds: s_memtime stamps of workgroup 0 / wave 0, 8 per output tile
+  unsigned long long *timeline;
+#endif
 };
+#ifdef MSAE_GEMM_TIMELINE
+#define MSAE_TL(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && ep.timeline && tl_tile < 64) \
+    ep.timeline[tl_tile * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MSAE_TL(slot) do { } while (0)
+#endif
 
 // Operands of one launch.  A rows are tokens, B rows are features; ld* in BYTES.
 struct GemmOperands {
@@ -335,7 +344,7 @@ __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int co
 template <class C, bool DENSE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
-                                              unsigned char *smem, const float *side) {
+                                              unsigned char *smem, const float *side, int tl_tile = 0) {
   const int l31 = lane & 31, kh = lane >> 5;
   constexpr int QCAP = C::QCAP;
   unsigned *q_count = reinterpret_cast<unsigned *>(smem + C::LDS_RING_BYTES + C::SIDE_BYTES);
@@ -346,6 +355,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     if (threadIdx.x == 0) *q_count = 0u;
     __syncthreads();
   }
+  MSAE_TL(7);
   // side[s*NT + tid]: slot s of row tid (tid < BM) or of column tid - BM
   const float *row_c = side, *col_c = side + C::BM;
   // column constants of this lane's NI columns stay in registers across the row loops
@@ -437,6 +447,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
       }
     }
   }
+  MSAE_TL(4);
   if constexpr (!DENSE) {
     __syncthreads();
 #ifdef MSAE_ABL_NOFLUSH     // tuning builds only: drop the queue instead of flushing it
@@ -458,6 +469,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
             ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
     }
   }
+  MSAE_TL(5);
 }
 
 template <class C, bool DENSE>
@@ -470,7 +482,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // iteration of a tile already stages the first k-tile of the next one, whose latency is then
   // hidden behind the epilogue.
   int seq = 0;                                   // flat k-tile counter; ring slot = seq & 1
+  [[maybe_unused]] int tl_tile = -1;
   for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
+  ++tl_tile;
+  MSAE_TL(0);
   // the thread id is made opaque per tile: otherwise every lane-dependent address of the
   // prologue and the epilogue is hoisted out of this loop and lives across the k-loop (spills)
   int tid_ = threadIdx.x;
@@ -566,6 +581,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
+    if (kt == 0) MSAE_TL(1);
+    if (kt == 1) MSAE_TL(2);
     if constexpr (!C::ABL_NOSTAGE) {
       if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
@@ -601,6 +618,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   }
   for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
 
+  MSAE_TL(3);
   // park the epilogue constants in LDS (side buffer behind the ring)
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
   side[tid_] = side0;
@@ -629,7 +647,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
     side[5 * C::NT + tid_] = side5;
   }
-  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side);
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side, tl_tile);
+  MSAE_TL(6);
   }
 }
 
