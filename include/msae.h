@@ -119,6 +119,12 @@ int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,
                      int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
                      int32_t *status, void *ws, size_t ws_bytes, void *stream);
+/* The same call writing 64-bit indices (EncoderOutput.top_indices is int64 in the reference: Tensor.topk,
+ * sae.py:179-181); saves the widening pass on the latency path (one decode step of steering). */
+int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                         const float *b_dec, const void *prepared, int T, int d, int N, int k,
+                         int set_feature, float set_value, int zero_feature, float *vals, int64_t *idx,
+                         int32_t *status, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- k-sparse decoder -------------------------------------------------------------------- */
 
@@ -127,6 +133,10 @@ int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float
  * `status` (int32[1], optional) is given, flagged there (kernels.py:276 device_assert). */
 int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec, const float *b_dec,
                     int A, int k, int N, int d, float *out, int32_t *status, void *stream);
+/* The same with 64-bit indices: the dtype Tensor.topk returns and the reference hands to decoder_impl
+ * (sae.py:179-181,187-191) -- no narrowing copy between the encoder and the decoder. */
+int msae_decode_i64_f32(const int64_t *idx, const float *acts, const float *W_dec, const float *b_dec,
+                        int A, int k, int N, int d, float *out, int32_t *status, void *stream);
 
 /* g_acts[A][k] = grad_out[A][:] . W_dec[idx[A][j]][:]   (dense-dense-sparse-out matmul) */
 int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const float *W_dec, int A,

@@ -85,6 +85,16 @@ __device__ __forceinline__ int rank_key_index(unsigned long long k) {
   return 0x7FFFFFFF - (int)(unsigned)(k & 0xFFFFFFFFull);
 }
 
+// optional outputs of the row top-k launch (exact fallback of the fused encoder): 64-bit indices beside or
+// instead of the 32-bit ones, output rows through a map (row i of the input -> token row_map[i]), and the
+// status word of a token recomputed this way (1, or 1 | reason << 8 with `detail`)
+struct TopkExtra {
+  int64_t *idx64 = nullptr;
+  const int *row_map = nullptr;
+  int32_t *status = nullptr;
+  int detail = 0;
+};
+
 // Bitonic sort of n (power of two) 64-bit keys in LDS, DESCENDING; all threads of the block call.
 __device__ __forceinline__ void bitonic_sort_desc_u64(unsigned long long *s, int n) {
   for (int size = 2; size <= n; size <<= 1) {

@@ -17,13 +17,14 @@ constexpr int DEC_THREADS = 256;
 constexpr int DEC_UNROLL = 8;
 
 // grid: (A, ceil(d / 1024))
+template <typename IT>
 __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_v4_kernel(
-    const int32_t *__restrict__ idx, const float *__restrict__ acts,
+    const IT *__restrict__ idx, const float *__restrict__ acts,
     const float *__restrict__ W_dec, const float *__restrict__ b_dec, float *__restrict__ out,
     int k, int N, int d, int32_t *status) {
   const int a = blockIdx.x;
   const int col = (blockIdx.y * DEC_THREADS + threadIdx.x) * 4;
-  const int32_t *ip = idx + (size_t)a * k;
+  const IT *ip = idx + (size_t)a * k;
   const float *vp = acts + (size_t)a * k;
   if (col >= d) return;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -33,9 +34,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_v4_kernel(
     float v[DEC_UNROLL];
 #pragma unroll
     for (int u = 0; u < DEC_UNROLL; ++u) {
-      int i = ip[j + u];
+      const IT iw = ip[j + u];
+      int i = (int)iw;
       v[u] = vp[j + u];
-      const bool bad = (unsigned)i >= (unsigned)N;
+      const bool bad = iw < 0 || iw >= (IT)N;
       if (bad) {
         v[u] = 0.f;
         i = 0;
@@ -54,9 +56,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_v4_kernel(
     }
   }
   for (; j < k; ++j) {
-    int i = ip[j];
+    const IT iw = ip[j];
+    int i = (int)iw;
     float v = vp[j];
-    if ((unsigned)i >= (unsigned)N) {
+    if (iw < 0 || iw >= (IT)N) {
       v = 0.f;
       i = 0;
       if (status && threadIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 1);
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_v4_kernel(
 }
 
 // any d / alignment: one column per lane.  grid: (A, ceil(d / 256))
+template <typename IT>
 __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_scalar_kernel(
-    const int32_t *__restrict__ idx, const float *__restrict__ acts,
+    const IT *__restrict__ idx, const float *__restrict__ acts,
     const float *__restrict__ W_dec, const float *__restrict__ b_dec, float *__restrict__ out,
     int k, int N, int d, int32_t *status) {
   const int a = blockIdx.x;
@@ -86,9 +90,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_scalar_kernel(
   if (col >= d) return;
   float acc = 0.f;
   for (int j = 0; j < k; ++j) {
-    int i = idx[(size_t)a * k + j];
+    const IT iw = idx[(size_t)a * k + j];
+    int i = (int)iw;
     float v = acts[(size_t)a * k + j];
-    if ((unsigned)i >= (unsigned)N) {
+    if (iw < 0 || iw >= (IT)N) {
       v = 0.f;
       i = 0;
       if (status && threadIdx.x == 0 && blockIdx.y == 0) atomicOr(status, 1);
@@ -281,9 +286,9 @@ __global__ void wgrad_zero_kernel(int *p, int n) {
 
 }  // namespace
 
-extern "C" int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec,
-                               const float *b_dec, int A, int k, int N, int d, float *out,
-                               int32_t *status, void *stream) {
+template <typename IT>
+static int decode_launch(const IT *idx, const float *acts, const float *W_dec, const float *b_dec, int A, int k,
+                         int N, int d, float *out, int32_t *status, void *stream) {
   if (A < 0 || k <= 0 || N <= 0 || d <= 0) return MSAE_EINVAL;
   if (A == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -291,14 +296,27 @@ extern "C" int msae_decode_f32(const int32_t *idx, const float *acts, const floa
                    (!b_dec || msae_aligned(b_dec, 16));
   if (vec) {
     dim3 grid(A, (d + DEC_THREADS * 4 - 1) / (DEC_THREADS * 4));
-    hipLaunchKernelGGL(decode_fwd_v4_kernel, grid, dim3(DEC_THREADS), 0, s, idx, acts, W_dec, b_dec,
+    hipLaunchKernelGGL(decode_fwd_v4_kernel<IT>, grid, dim3(DEC_THREADS), 0, s, idx, acts, W_dec, b_dec,
                        out, k, N, d, status);
   } else {
     dim3 grid(A, (d + DEC_THREADS - 1) / DEC_THREADS);
-    hipLaunchKernelGGL(decode_fwd_scalar_kernel, grid, dim3(DEC_THREADS), 0, s, idx, acts, W_dec,
+    hipLaunchKernelGGL(decode_fwd_scalar_kernel<IT>, grid, dim3(DEC_THREADS), 0, s, idx, acts, W_dec,
                        b_dec, out, k, N, d, status);
   }
   return msae_launch_status();
+}
+
+extern "C" int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec,
+                               const float *b_dec, int A, int k, int N, int d, float *out,
+                               int32_t *status, void *stream) {
+  return decode_launch<int32_t>(idx, acts, W_dec, b_dec, A, k, N, d, out, status, stream);
+}
+
+// same with the index width of Tensor.topk (int64): what the reference hands to decoder_impl
+extern "C" int msae_decode_i64_f32(const int64_t *idx, const float *acts, const float *W_dec,
+                                   const float *b_dec, int A, int k, int N, int d, float *out,
+                                   int32_t *status, void *stream) {
+  return decode_launch<int64_t>(idx, acts, W_dec, b_dec, A, k, N, d, out, status, stream);
 }
 
 extern "C" int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out,

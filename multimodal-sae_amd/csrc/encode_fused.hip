@@ -49,7 +49,7 @@ int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const f
                          const float *b_dec, const int *rows, const int *n_rows, int T, int d, int N,
                          int relu, float *out, int ld_out, hipStream_t s);
 int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
-                     float *vals, int32_t *idx, hipStream_t s);
+                     float *vals, int32_t *idx, hipStream_t s, const TopkExtra &ex = TopkExtra());
 bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float *out, int out_ld,
                            int out_col, hipStream_t s);
 
@@ -502,7 +502,7 @@ struct RescoreArgs {
   int set_feature; float set_value; int zero_feature;
   const f32x4 *rowc, *colc;           // error-band constants per token / per feature
   float zz12, z2; int i8;
-  float *vals; int32_t *idx; int32_t *status;
+  float *vals; int32_t *idx; int64_t *idx64; int32_t *status;   // idx / idx64: either may be null
   int *flagged; int *n_flagged; int fb_cap;
 };
 
@@ -680,7 +680,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
 
   for (int j = lane; j < p.k; j += NT) {
     const unsigned long long key = res[j];
-    p.idx[(size_t)t * p.k + j] = key ? rank_key_index(key) : 0;
+    const int fi = key ? rank_key_index(key) : 0;
+    if (p.idx) p.idx[(size_t)t * p.k + j] = fi;
+    if (p.idx64) p.idx64[(size_t)t * p.k + j] = fi;
     p.vals[(size_t)t * p.k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
   }
   if (lane == 0) {
@@ -730,21 +732,8 @@ __global__ void fallback_counts_kernel(const int *n_flagged, int fb_cap, int chu
   }
 }
 
-// exact results of the flagged tokens overwrite the fast-path results
-__global__ void scatter_fallback_kernel(const float *fb_vals, const int32_t *fb_idx, const int *flagged,
-                                        const int *n_flagged, int fb_cap, int k, float *vals, int32_t *idx,
-                                        int32_t *status, int detail) {
-  const int nf = min(*n_flagged, fb_cap);
-  for (int i = blockIdx.x; i < nf; i += gridDim.x) {
-    const int t = flagged[i];
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-      vals[(size_t)t * k + j] = fb_vals[(size_t)i * k + j];
-      idx[(size_t)t * k + j] = fb_idx[(size_t)i * k + j];
-    }
-    // status detail (msae_set_status_detail): keep why the fast path gave up, bits 8.. = the reason bits
-    if (threadIdx.x == 0 && status) status[t] = detail ? (1 | ((status[t] & ~3) << 8)) : 1;
-  }
-}
+// index output of one call: 32-bit (msae_encode_topk), 64-bit (msae_encode_topk_i64), never both null
+struct IdxOut { int32_t *i32; int64_t *i64; };
 
 // ---- stage profiling (bench.py roofline): HIP events recorded on the launch stream ------------------
 constexpr int PROF_MARKS = 7;  // boundaries of: prep | sample gemm | tau topk | main gemm | rescore | fallback
@@ -766,24 +755,34 @@ inline void prof_mark(int i, hipStream_t s) {
 // held in registers.  The activations are quantised to 15 bits as TWO int8 planes (a ~ s (128 hi + lo)),
 // which removes the massive-activation problem without the per-batch outlier machinery (column maxima,
 // outlier tile of Wq): the x-side rounding noise becomes negligible and the band constants are static.
-//   prep_small   a32, two-plane quantisation, rowc = (s, 1, P = z^2 |a|^2 / 12)
-//   gemv_small   u[t][n] = coarse + z sigma, dense [T][N] (512 KB per token)
-//   topk x 2     the SMALL_R + 1 largest u per token (LDS radix-select kernel, 32 slices then their survivors)
-//   rescore_small one WAVE per (token, candidate): the row arrives by coalesced loads into LDS, lane 0 runs the
-//                exact ascending-k f32 chain (the chain is serial by definition: ~8 us for d = 4096)
-//   finalize_small canonical top-k of the exact values; verified iff the (SMALL_R + 1)-th u lies below v_k
-constexpr int SMALL_T_MAX = 4, SMALL_R = 96, SMALL_K_MAX = 64;
+//   prep_small    a32, two-plane quantisation, rowc = (s, 1, P = z^2 |a|^2 / 12)
+//   gemv_small    u = coarse + z sigma of every row; each workgroup keeps the upper values of ITS rows (<= 128)
+//                 in LDS and emits its SMALL_EMIT best as (u, feature) keys plus its next value as a bound
+//   select_small  one workgroup per token: a threshold (bisection on the value) with SMALL_R .. SMALL_RMAX of the
+//                 SMALL_GRID x SMALL_EMIT survivors at or above it; those are the candidates, and
+//                 tau = max(survivors below it, every workgroup's bound) bounds all other features
+//   rescore_small one WAVE per (token, candidate): row and activations in registers (lane l holds elements
+//                 256 c + 4 l ..), the exact ascending-k chain walks the lanes (4 fma + a one-lane wave
+//                 rotate per step, ~6 cycles per element instead of ~15 for a one-lane chain out of LDS);
+//                 the LAST wave of a token to finish sorts the exact values and writes the outputs: verified
+//                 iff v_k lies above tau
+constexpr int SMALL_T_MAX = 4, SMALL_R = 96, SMALL_RMAX = 127, SMALL_K_MAX = 64;   // candidates per token: R .. RMAX
+constexpr int SMALL_GRID = 2048;                       // gemv workgroups of 4 waves (8 per CU)
+constexpr int SMALL_EMIT = 3;                          // survivors per workgroup and token
+constexpr int SMALL_WG_ROWS = 128;                     // most rows of one workgroup (32 per wave)
+constexpr int SMALL_SURV = SMALL_GRID * SMALL_EMIT;    // 6144 keys per token
+static_assert(SMALL_RMAX < SMALL_SURV && SMALL_RMAX + 1 <= 128, "candidate list: 127 exact values + the hook's set_feature");
 inline bool small_shape_ok(int T, int d, int N, int k) {
-  return T <= SMALL_T_MAX && k <= SMALL_K_MAX && d % 1024 == 0 && d <= 8192 && N > SMALL_R + 1 && i8_shape_ok(N, d);
+  return T <= SMALL_T_MAX && k <= SMALL_K_MAX && d % 1024 == 0 && d <= 8192 && N >= 4096 &&
+         N <= SMALL_GRID * SMALL_WG_ROWS && i8_shape_ok(N, d);
 }
 
 struct FusedPlan {
   bool fast, i8, small;
-  size_t off_xhi, off_xlo, off_udense, off_skeys, off_sviol, off_sl1v, off_sl1i;
+  size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
-  size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_fbv,
-      off_fbi, off_dense, bytes;
+  size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_dense, bytes;
 };
 
 inline FusedPlan make_plan(int T, int d, int N, int k) {
@@ -821,16 +820,17 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     if (p.small) {
       p.off_xhi = take((size_t)T * d);
       p.off_xlo = take((size_t)T * d);
-      p.off_udense = take((size_t)T * N * 4);
       p.off_skeys = take((size_t)T * 128 * 8);
-      p.off_sl1v = take((size_t)T * 32 * (SMALL_R + 1) * 4);
-      p.off_sl1i = take((size_t)T * 32 * (SMALL_R + 1) * 4);
-      p.off_sviol = take((size_t)T * 4);
+      p.off_surv = take((size_t)T * SMALL_SURV * 8);
+      p.off_sbound = take((size_t)T * SMALL_GRID * 4);
+      p.off_scand = take((size_t)T * 128 * 8);
+      p.off_stau = take((size_t)T * 4);
+      p.off_sviol = take((size_t)T * 2 * 4);            // model-check flags [T] | finished-wave counters [T]
     }
     p.off_xb = take(p.i8 ? 256 : (size_t)p.Tp * d * 2);
     p.off_a32 = take((size_t)T * d * 4);
     p.off_sample = take((size_t)T * p.S * 4);
-    const size_t tau_n = (size_t)T * (p.r > SMALL_R + 1 ? p.r : SMALL_R + 1);   // small path: top-(SMALL_R + 1) upper values
+    const size_t tau_n = (size_t)T * p.r;
     p.off_tauv = take(tau_n * 4);
     p.off_taui = take(tau_n * 4);
     p.off_cnt = take((size_t)T * 4);
@@ -839,8 +839,6 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
     p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);   // token list [T] | count | per-pass counts
     p.off_fbdense = take((size_t)p.fb_cap * N * 4);
-    p.off_fbv = take((size_t)p.fb_cap * k * 4);
-    p.off_fbi = take((size_t)p.fb_cap * k * 4);
   } else {
     p.off_dense = take((size_t)T * N * 4);
   }
@@ -853,14 +851,12 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
 // immediately)
 template <int DT>
 int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int d, int N,
-                       int k, int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
+                       int k, int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
                        int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
   int *n_flagged = flagged + T;
   int *fb_counts = flagged + T + 64;
   float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
-  float *fbv = reinterpret_cast<float *>(ws + pl.off_fbv);
-  int32_t *fbi = reinterpret_cast<int32_t *>(ws + pl.off_fbi);
   if (pl.fb_chunks > 1)
     hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_flagged, pl.fb_cap, pl.fb_chunks, fb_counts);
   for (int c = 0; c < pl.fb_chunks; ++c) {
@@ -871,10 +867,11 @@ int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, co
     if (set_feature >= 0 || zero_feature >= 0)
       hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_rows,
                          set_feature, set_value, zero_feature);
-    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, fbv, fbi, s);
+    // the exact results go straight to the flagged tokens' rows of the outputs (row map = the flag list)
+    TopkExtra ex;
+    ex.idx64 = idx.i64; ex.row_map = rows; ex.status = status; ex.detail = g_status_detail;
+    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, vals, idx.i32, s, ex);
     if (rc) return rc;
-    hipLaunchKernelGGL(scatter_fallback_kernel, dim3(128), dim3(64), 0, s, fbv, fbi, rows, n_rows, pl.fb_cap, k,
-                       vals, idx, status, g_status_detail);
   }
   return 0;
 }
@@ -927,19 +924,23 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict_
   }
 }
 
-// The weight stream.  A wave owns rows n = w, w + W, ...: per row DSEG loads of 16 B per lane (1 KiB per
-// instruction), 8 dot4 per segment and token, a wave reduction, u = coarse + z sigma -> dense[t][n].
-// HBM-bound: N d bytes once, whatever T <= 4.
+// The weight stream.  A wave owns rows n = w, w + W, ... (W waves): per row DSEG loads of 16 B per lane (1 KiB per
+// instruction), 8 dot4 per segment and token, a wave reduction, u = coarse + z sigma.  HBM-bound: N d bytes
+// once, whatever T <= 4.  The workgroup's upper values go to LDS as rank keys; at the end wave t picks
+// token t's SMALL_EMIT + 1 largest (four max-reductions) -> surv[t][wg][0..EMIT), bound[t][wg].
 template <int DSEG, int TT>
 __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__restrict__ wq, const f32x4 *__restrict__ wstat,
                                                          const float *__restrict__ b_enc, int N, int T,
                                                          const signed char *__restrict__ xhi,
                                                          const signed char *__restrict__ xlo,
                                                          const f32x4 *__restrict__ rowc, float zz12, int skip_a,
-                                                         int skip_b, float *__restrict__ dense) {
+                                                         int skip_b, unsigned long long *__restrict__ surv,
+                                                         unsigned *__restrict__ bound) {
   constexpr int d = DSEG * 1024;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  __shared__ unsigned long long wgk[TT][SMALL_WG_ROWS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  for (int i = threadIdx.x; i < TT * SMALL_WG_ROWS; i += 256) (&wgk[0][0])[i] = 0ull;
   i32x4 xh[TT][DSEG], xl[TT][DSEG];
   float sxz[TT], pz[TT], rz[TT];
 #pragma unroll
@@ -953,21 +954,25 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
     const f32x4 rc = rowc[tt];
     sxz[t] = rc[0]; pz[t] = rc[2]; rz[t] = rc[0] * rc[0] * zz12;
   }
+  __syncthreads();
   constexpr int RB = 16 / DSEG > 0 ? 16 / DSEG : 1;      // rows in flight per wave: 16 KiB of loads outstanding
-  for (int n0 = wave * RB; n0 < N; n0 += n_waves * RB) {
+  int slot = wv * (SMALL_WG_ROWS / 4);                     // this wave's next key slot (<= 32 rows per wave)
+  // rows wave, wave + W, wave + 2 W, ...: every workgroup sees a thin, index-strided slice of the features
+  for (int n0 = wave; n0 < N; n0 += n_waves * RB) {
     i32x4 w[RB][DSEG];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
       for (int q = 0; q < DSEG; ++q)
-        w[r][q] = (n0 + r < N) ? *reinterpret_cast<const i32x4 *>(wq + (size_t)(n0 + r) * d + q * 1024 + lane * 16)
-                               : i32x4{0, 0, 0, 0};
+        w[r][q] = (n0 + r * n_waves < N)
+                      ? *reinterpret_cast<const i32x4 *>(wq + (size_t)(n0 + r * n_waves) * d + q * 1024 + lane * 16)
+                      : i32x4{0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int n = n0 + r;
-      if (n >= N) break;
-      const f32x4 st = wstat[n];
-      const float bias = b_enc ? b_enc[n] : 0.f;
+      const int n = n0 + r * n_waves;
+      const bool live = n < N;                          // wave-uniform
+      const f32x4 st = wstat[live ? n : 0];
+      const float bias = b_enc ? b_enc[live ? n : 0] : 0.f;
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         int ah = 0, al = 0;
@@ -980,139 +985,236 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
           }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { ah += __shfl_xor(ah, off, 64); al += __shfl_xor(al, off, 64); }
-        if (lane == 0 && t < T) {
+        if (lane == 0 && t < T && live) {
           const float c = (128.f * (float)ah + (float)al) * (sxz[t] * st[0]) + bias;
           const float zs = __builtin_sqrtf(__builtin_fmaf(pz[t], st[1], rz[t] * st[2]));
-          dense[(size_t)t * N + n] = (n == skip_a || n == skip_b) ? -__builtin_inff() : c + zs;
+          wgk[t][slot + r] = rank_key((n == skip_a || n == skip_b) ? -__builtin_inff() : c + zs, n);
         }
       }
     }
-  }
-}
-
-// grid (SMALL_R, T), one wave each: row f of W_enc and the token's activations -> LDS by coalesced 16-B lane
-// loads, then lane 0 runs the exact ascending-k fma chain (serial by definition) out of LDS with the next
-// 32 elements' reads in flight behind the current 32 fmas.  exact[t][r] = rank key of relu(p); a pair
-// further than 6 sigma from its coarse value raises viol[t].  uidx2[r] indexes the survivor list of the
-// two-level selection: feature = slice * slice_len + uidx1[survivor].
-__global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restrict__ a32, const float *__restrict__ W_enc,
-                                                           const float *__restrict__ b_enc, int d, int slice_len,
-                                                           const float *__restrict__ uvals, const int32_t *__restrict__ uidx2,
-                                                           const int32_t *__restrict__ uidx1, int ld,
-                                                           const f32x4 *__restrict__ wstat,
-                                                           const f32x4 *__restrict__ rowc, float zz12, float z2,
-                                                           unsigned long long *__restrict__ exact, int *__restrict__ viol) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *row = reinterpret_cast<float *>(smem), *arow = row + d;
-  const int r = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
-  const int surv = uidx2[(size_t)t * ld + r];
-  const int f = (surv / ld) * slice_len + uidx1[(size_t)t * 32 * ld + surv];
-  const float upper = uvals[(size_t)t * ld + r];
-  const float *__restrict__ w = W_enc + (size_t)f * d;
-  for (int c = lane * 4; c < d; c += 256) {
-    *reinterpret_cast<f32x4 *>(row + c) = *reinterpret_cast<const f32x4 *>(w + c);
-    *reinterpret_cast<f32x4 *>(arow + c) = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);
+    slot += RB;
   }
   __syncthreads();
-  if (lane != 0) return;
-  // both operands come from LDS: scalar loads of the activations would share lgkmcnt with the LDS reads
-  // (different return order -> full drains, measured 20 % slower)
-  float acc = 0.f;
-  f32x4 wa[8], aa[8], wb[8], ab[8];
-  auto fetch = [&](f32x4 (&wv)[8], f32x4 (&av)[8], int kk) {
+  if (wv >= TT || wv >= T) return;
+  unsigned long long k0 = wgk[wv][lane], k1 = wgk[wv][lane + 64], best[SMALL_EMIT + 1];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      wv[u] = *reinterpret_cast<const f32x4 *>(row + kk + 4 * u);
-      av[u] = *reinterpret_cast<const f32x4 *>(arow + kk + 4 * u);
-    }
-  };
-  auto consume = [&](const f32x4 (&wv)[8], const f32x4 (&av)[8]) {
+  for (int e = 0; e <= SMALL_EMIT; ++e) {
+    unsigned long long m = k0 > k1 ? k0 : k1;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      acc = __builtin_fmaf(av[u][0], wv[u][0], acc);
-      acc = __builtin_fmaf(av[u][1], wv[u][1], acc);
-      acc = __builtin_fmaf(av[u][2], wv[u][2], acc);
-      acc = __builtin_fmaf(av[u][3], wv[u][3], acc);
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(m, off, 64);
+      m = o > m ? o : m;
     }
-  };
-  fetch(wa, aa, 0);
-  for (int kk = 0; kk < d; kk += 64) {     // d % 1024 == 0
-    fetch(wb, ab, kk + 32);
-    consume(wa, aa);
-    if (kk + 64 < d) fetch(wa, aa, kk + 64);
-    consume(wb, ab);
+    best[e] = m;                              // keys are unique (feature in the low word) unless 0 = empty
+    if (k0 == m) k0 = 0ull; else if (k1 == m) k1 = 0ull;
   }
-  const float pre = acc + (b_enc ? b_enc[f] : 0.f);
-  exact[(size_t)t * 128 + r] = rank_key(pre > 0.f ? pre : 0.f, f);
-  if (upper > -__builtin_inff()) {
-    const f32x4 rc = rowc[t], st = wstat[f];
-    const float zs2 = __builtin_fmaf(rc[2], st[1], rc[0] * rc[0] * zz12 * st[2]);
-    const float diff = pre - (upper - __builtin_sqrtf(zs2));
-    if (diff * diff * z2 > GUARD_Z_CHECK * GUARD_Z_CHECK * zs2 * 1.0001f + 1e-30f) atomicOr(viol + t, 1);
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < SMALL_EMIT; ++e) surv[((size_t)wv * SMALL_GRID + blockIdx.x) * SMALL_EMIT + e] = best[e];
+    bound[(size_t)wv * SMALL_GRID + blockIdx.x] = (unsigned)(best[SMALL_EMIT] >> 32);
   }
 }
 
-// one wave per token: canonical top-k of the exact values (+ the steering hook's set_feature), verification
-__global__ __launch_bounds__(64) void finalize_small_kernel(const unsigned long long *__restrict__ exact,
-                                                            const float *__restrict__ uvals, int ld, int k,
-                                                            int set_feature, float set_value, const int *__restrict__ viol,
-                                                            float *__restrict__ vals, int32_t *__restrict__ idx,
-                                                            int32_t *__restrict__ status, int *__restrict__ flagged,
-                                                            int *__restrict__ n_flagged) {
-  __shared__ unsigned long long keys[128];
-  const int t = blockIdx.x, lane = threadIdx.x;
+// one 1024-thread workgroup per token, six survivors per thread in registers.  A bisection on the 32-bit
+// order key of the upper value finds a threshold with SMALL_R .. SMALL_RMAX survivors at or above it (one
+// ballot count + one barrier per step, ~16 steps); those are the candidates (any order), and tau = the largest
+// upper value any OTHER feature can have = max(survivors below the threshold, the workgroups' bounds).
+// Ties that make the window unreachable leave fewer candidates: still sound, tau says so.
+__global__ __launch_bounds__(1024) void select_small_kernel(const unsigned long long *__restrict__ surv,
+                                                            const unsigned *__restrict__ bound,
+                                                            unsigned long long *__restrict__ cand,
+                                                            float *__restrict__ tau) {
+  constexpr int PER = SMALL_SURV / 1024;
+  static_assert(SMALL_SURV % 1024 == 0 && SMALL_GRID % 1024 == 0, "survivors per thread");
+  __shared__ int cnt[33];
+  __shared__ unsigned long long c_keys[128];
+  __shared__ unsigned s_tau;
+  __shared__ int s_n;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  unsigned long long k[PER];
+  unsigned v[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    k[e] = surv[(size_t)t * SMALL_SURV + e * 1024 + tid];
+    v[e] = (unsigned)(k[e] >> 32);
+  }
+  unsigned below = 0u;                                   // largest value that will NOT be a candidate
+#pragma unroll
+  for (int e = 0; e < SMALL_GRID / 1024; ++e) {
+    const unsigned b = bound[(size_t)t * SMALL_GRID + e * 1024 + tid];
+    below = b > below ? b : below;
+  }
+  if (tid < 33) cnt[tid] = 0;
+  if (tid < 128) c_keys[tid] = 0ull;
+  if (tid == 0) { s_tau = 0u; s_n = 0; }
+  __syncthreads();
+  unsigned lo = 0u, hi = 0xFFFFFFFFu, theta = 0xFFFFFFFFu;    // f(lo) > SMALL_RMAX, f(hi) < SMALL_R
+  for (int step = 0; hi - lo > 1u; ++step) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[e] >= mid));
+    if (lane == 0) atomicAdd(&cnt[step], c);
+    __syncthreads();
+    const int tot = cnt[step];
+    if (tot > SMALL_RMAX) lo = mid;
+    else if (tot < SMALL_R) hi = mid;
+    else { theta = mid; break; }
+  }
+  if (theta == 0xFFFFFFFFu) theta = hi;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    if (v[e] >= theta && k[e] != 0ull) {
+      const int slot = atomicAdd(&s_n, 1);
+      if (slot < 128) c_keys[slot] = k[e];
+    } else {
+      below = v[e] > below ? v[e] : below;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(below, off, 64); below = o > below ? o : below; }
+  if (lane == 0) atomicMax(&s_tau, below);
+  __syncthreads();
+  if (tid < 128) cand[(size_t)t * 128 + tid] = c_keys[tid];
+  if (tid == 0) {
+    const unsigned ninf = f32_order_key(-__builtin_inff());
+    tau[t] = f32_from_order_key(s_tau > ninf ? s_tau : ninf);
+  }
+}
+
+// canonical top-k of a token's exact values (+ the steering hook's set_feature), verification, outputs:
+// run by the last rescoring wave of the token
+__device__ __forceinline__ void finalize_small(unsigned long long *keys, const unsigned long long *exact, float tau,
+                                               int t, int k, int set_feature, float set_value, int viol,
+                                               float *vals, IdxOut idx, int32_t *status, int *flagged,
+                                               int *n_flagged, int lane) {
   const int has_set = set_feature >= 0 ? 1 : 0;
   for (int i = lane; i < 128; i += 64) {
     unsigned long long kv = 0ull;
-    if (i < SMALL_R) kv = exact[(size_t)t * 128 + i];
-    else if (i == SMALL_R && has_set) kv = rank_key(set_value, set_feature);
+    if (i < SMALL_RMAX) kv = exact[(size_t)t * 128 + i];
+    else if (has_set) kv = rank_key(set_value, set_feature);
     keys[i] = kv;
   }
   wave_sort_desc_u64<64>(keys, 128, lane);
   const float v_k = f32_from_order_key((unsigned)(keys[k - 1] >> 32));
-  const float tau = uvals[(size_t)t * ld + SMALL_R];            // best upper value among the rows NOT re-scored
-  const bool ok = (v_k > tau * 1.000001f) && (v_k > 0.f) && (viol[t] == 0);
+  const bool ok = (v_k > tau * 1.000001f) && (v_k > 0.f) && (viol == 0);
   for (int j = lane; j < k; j += 64) {
     const unsigned long long key = keys[j];
-    idx[(size_t)t * k + j] = key ? rank_key_index(key) : 0;
+    const int fi = key ? rank_key_index(key) : 0;
+    if (idx.i32) idx.i32[(size_t)t * k + j] = fi;
+    if (idx.i64) idx.i64[(size_t)t * k + j] = fi;
     vals[(size_t)t * k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
   }
   if (lane == 0) {
-    if (status) status[t] = ok ? 0 : (2 | (viol[t] ? 64 : 32));
+    if (status) status[t] = ok ? 0 : (2 | (viol ? 64 : 32));
     if (!ok) flagged[atomicAdd(n_flagged, 1)] = t;
   }
+}
+
+// grid (SMALL_RMAX, T), one wave each.  Row f of W_enc and the token's activations are loaded straight into
+// registers by coalesced 16-B lane loads: lane l holds elements 256 c + 4 l .. + 3 of chunk c.  The exact chain
+// is serial by definition; it visits the lanes in order: every lane executes "4 fma, rotate the accumulator
+// one lane up" 64 times per chunk, and the lane whose turn it is holds the true partial sum (the others compute
+// garbage that is rotated out of the way).  exact[t][r] = rank key of relu(p); a pair further than 6 sigma from
+// its coarse value raises viol[t].  The last wave of token t to arrive (device-scope counter) finalises t.
+template <int DSEG>
+__global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restrict__ a32, const float *__restrict__ W_enc,
+                                                           const float *__restrict__ b_enc, int k,
+                                                           const unsigned long long *__restrict__ cand,
+                                                           const float *__restrict__ tau,
+                                                           const f32x4 *__restrict__ wstat,
+                                                           const f32x4 *__restrict__ rowc, float zz12, float z2,
+                                                           int set_feature, float set_value,
+                                                           unsigned long long *__restrict__ exact, int *__restrict__ viol,
+                                                           int *__restrict__ done, float *__restrict__ vals, IdxOut idx,
+                                                           int32_t *__restrict__ status, int *__restrict__ flagged,
+                                                           int *__restrict__ n_flagged) {
+  constexpr int d = DSEG * 1024, CH = DSEG * 4, GC = CH < 16 ? CH : 16;   // chunks of 256 elements, <= 16 in registers
+  __shared__ unsigned long long keys[128];
+  __shared__ int s_last;
+  const int r = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+  const unsigned long long ck = cand[(size_t)t * 128 + r];
+  if (ck != 0ull) {                                    // wave-uniform
+    const int f = rank_key_index(ck);
+    const float upper = f32_from_order_key((unsigned)(ck >> 32));
+    const float *__restrict__ w = W_enc + (size_t)f * d + lane * 4;
+    const float *__restrict__ a = a32 + (size_t)t * d + lane * 4;
+    float acc = 0.f;
+    for (int g = 0; g < CH; g += GC) {
+      f32x4 wv[GC], av[GC];
+#pragma unroll
+      for (int c = 0; c < GC; ++c) {
+        wv[c] = *reinterpret_cast<const f32x4 *>(w + (g + c) * 256);
+        av[c] = *reinterpret_cast<const f32x4 *>(a + (g + c) * 256);
+      }
+#pragma unroll
+      for (int c = 0; c < GC; ++c) {
+        const f32x4 w4 = wv[c], a4 = av[c];
+#pragma unroll 8
+        for (int st = 0; st < 64; ++st) {
+          acc = __builtin_fmaf(a4[0], w4[0], acc);
+          acc = __builtin_fmaf(a4[1], w4[1], acc);
+          acc = __builtin_fmaf(a4[2], w4[2], acc);
+          acc = __builtin_fmaf(a4[3], w4[3], acc);
+          // wave_ror:1 -- lane l takes lane l - 1's value, lane 0 lane 63's
+          acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x13C, 0xF, 0xF, false));
+        }
+      }
+    }
+    if (lane == 0) {                                   // after whole chunks the true sum is back in lane 0
+      const float pre = acc + (b_enc ? b_enc[f] : 0.f);
+      exact[(size_t)t * 128 + r] = rank_key(pre > 0.f ? pre : 0.f, f);
+      if (upper > -__builtin_inff()) {
+        const f32x4 rc = rowc[t], st = wstat[f];
+        const float zs2 = __builtin_fmaf(rc[2], st[1], rc[0] * rc[0] * zz12 * st[2]);
+        const float diff = pre - (upper - __builtin_sqrtf(zs2));
+        if (diff * diff * z2 > GUARD_Z_CHECK * GUARD_Z_CHECK * zs2 * 1.0001f + 1e-30f) atomicOr(viol + t, 1);
+      }
+    }
+  } else if (lane == 0) {
+    exact[(size_t)t * 128 + r] = 0ull;
+  }
+  // release our result, count this wave in; the last one acquires everybody's
+  if (lane == 0)
+    s_last = __hip_atomic_fetch_add(done + t, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every lane reads the other waves' results below
+  const int vi = __hip_atomic_load(viol + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  finalize_small(keys, exact, tau[t], t, k, set_feature, set_value, vi, vals, idx, status, flagged, n_flagged, lane);
 }
 
 template <int DT>
 int run_small(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const Prepared &pp,
               const unsigned char *prepared, int T, int d, int N, int k, int set_feature, float set_value,
-              int zero_feature, float *vals, int32_t *idx, int32_t *status, unsigned char *ws, const FusedPlan &pl,
+              int zero_feature, float *vals, IdxOut idx, int32_t *status, unsigned char *ws, const FusedPlan &pl,
               hipStream_t s) {
   const float z = guard_z(), zz12 = z * z / 12.f;
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
   signed char *xhi = reinterpret_cast<signed char *>(ws + pl.off_xhi);
   signed char *xlo = reinterpret_cast<signed char *>(ws + pl.off_xlo);
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
-  float *dense = reinterpret_cast<float *>(ws + pl.off_udense);
-  float *uvals = reinterpret_cast<float *>(ws + pl.off_tauv);     // [T][SMALL_R + 1] (>= T * r floats: r >= 16 ... sized below)
-  int32_t *uidx = reinterpret_cast<int32_t *>(ws + pl.off_taui);
+  unsigned long long *surv = reinterpret_cast<unsigned long long *>(ws + pl.off_surv);
+  unsigned *bound = reinterpret_cast<unsigned *>(ws + pl.off_sbound);
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + pl.off_scand);
+  float *tau = reinterpret_cast<float *>(ws + pl.off_stau);
   unsigned long long *exact = reinterpret_cast<unsigned long long *>(ws + pl.off_skeys);
   int *viol = reinterpret_cast<int *>(ws + pl.off_sviol);
+  int *done = viol + T;
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
   int *n_flagged = flagged + T;
   const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
   const f32x4 *wstat = reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat);
   prof_mark(0, s);
-  hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, T,
+  hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, 2 * T,
                      flagged, T + 64 + pl.fb_chunks);
   prof_mark(1, s);
   prof_mark(2, s);
   prof_mark(3, s);
-  const int grid = 256 * 8;
   const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
 #define MSAE_GEMV(DSEG, TT)                                                                                        \
-  hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(grid), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, rowc, \
-                     zz12, skip_a, skip_b, dense)
+  hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(SMALL_GRID), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, \
+                     rowc, zz12, skip_a, skip_b, surv, bound)
   const int dseg = d / 1024;
   if (T == 1) {
     switch (dseg) { case 1: MSAE_GEMV(1, 1); break; case 2: MSAE_GEMV(2, 1); break; case 4: MSAE_GEMV(4, 1); break;
@@ -1125,24 +1227,17 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
                     default: return MSAE_ENOTIMPL; }
   }
 #undef MSAE_GEMV
-  // the SMALL_R + 1 largest upper values per token in two levels (one 1024-thread workgroup walking a whole
-  // 512 KB row took 110 us): 32 slices of N / 32 features each keep their best SMALL_R + 1, then one
-  // selection over the 32 x (SMALL_R + 1) survivors; uidx2 indexes the survivor list, uidx1 the slice
-  constexpr int RS1 = SMALL_R + 1, NSL = 32;
-  float *uv1 = reinterpret_cast<float *>(ws + pl.off_sl1v);
-  int32_t *ui1 = reinterpret_cast<int32_t *>(ws + pl.off_sl1i);
-  int rc = msae_topk_launch(dense, T * NSL, N / NSL, RS1, N / NSL, nullptr, uv1, ui1, s);
-  if (rc) return rc;
-  rc = msae_topk_launch(uv1, T, NSL * RS1, RS1, NSL * RS1, nullptr, uvals, uidx, s);
-  if (rc) return rc;
+  hipLaunchKernelGGL(select_small_kernel, dim3(T), dim3(1024), 0, s, surv, bound, cand, tau);
   prof_mark(4, s);
-  hipLaunchKernelGGL(rescore_small_kernel, dim3(SMALL_R, T), dim3(64), (size_t)d * 8, s, a32, W_enc, b_enc, d, N / NSL, uvals,
-                     uidx, ui1, SMALL_R + 1, wstat, rowc, zz12, z * z, exact, viol);
-  hipLaunchKernelGGL(finalize_small_kernel, dim3(T), dim3(64), 0, s, exact, uvals, SMALL_R + 1, k, set_feature, set_value,
-                     viol, vals, idx, status, flagged, n_flagged);
+#define MSAE_RESCORE(DSEG)                                                                                         \
+  hipLaunchKernelGGL(rescore_small_kernel<DSEG>, dim3(SMALL_RMAX, T), dim3(64), 0, s, a32, W_enc, b_enc, k, cand, tau, wstat, \
+                     rowc, zz12, z * z, set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
+  switch (dseg) { case 1: MSAE_RESCORE(1); break; case 2: MSAE_RESCORE(2); break; case 4: MSAE_RESCORE(4); break;
+                  case 8: MSAE_RESCORE(8); break; default: return MSAE_ENOTIMPL; }
+#undef MSAE_RESCORE
   prof_mark(5, s);
-  rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
-                              status, ws, pl, s);
+  int rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
+                                  status, ws, pl, s);
   if (rc) return rc;
   prof_mark(6, s);
   if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
@@ -1152,7 +1247,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
 template <int DT>
 int run_fast(const void *x, const float *W_enc, const float *b_enc, const float *b_dec,
              const Prepared &pp, const unsigned char *prepared, int T, int d, int N, int k,
-             int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
+             int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
              int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
   unsigned short *xb = reinterpret_cast<unsigned short *>(ws + pl.off_xb);
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
@@ -1262,7 +1357,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
     ra.rowc = rowc; ra.colc = colc; ra.zz12 = zz12; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
-    ra.vals = vals; ra.idx = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
+    ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
@@ -1389,11 +1484,10 @@ extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k) {
   return make_plan(T, d, N, k).bytes;
 }
 
-extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
-                                const float *b_dec, const void *prepared, int T, int d, int N, int k,
-                                int set_feature, float set_value, int zero_feature, float *vals,
-                                int32_t *idx, int32_t *status, void *ws, size_t ws_bytes,
-                                void *stream) {
+static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                            const float *b_dec, const void *prepared, int T, int d, int N, int k,
+                            int set_feature, float set_value, int zero_feature, float *vals,
+                            IdxOut idx, int32_t *status, void *ws, size_t ws_bytes, void *stream) {
   if (T < 0 || d <= 0 || N <= 0 || k <= 0 || k > N || k > 4096) return MSAE_EINVAL;
   if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
   if (set_feature >= N || zero_feature >= N) return MSAE_EINVAL;
@@ -1412,7 +1506,9 @@ extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, 
     if (set_feature >= 0 || zero_feature >= 0)
       hipLaunchKernelGGL(edit_dense_kernel, dim3((T + 255) / 256), dim3(256), 0, s, dense, N, T,
                          (const int *)nullptr, set_feature, set_value, zero_feature);
-    rc = msae_topk_launch(dense, T, N, k, N, nullptr, vals, idx, s);
+    TopkExtra ex;
+    ex.idx64 = idx.i64;
+    rc = msae_topk_launch(dense, T, N, k, N, nullptr, vals, idx.i32, s, ex);
     if (rc) return rc;
     if (status) hipLaunchKernelGGL(zero_i32_kernel, dim3(64), dim3(256), 0, s, status, (size_t)T);
     return msae_launch_status();
@@ -1434,4 +1530,24 @@ extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, 
     case MSAE_BF16: return run_fast<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
     default: return run_fast<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
   }
+}
+
+extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                                const float *b_dec, const void *prepared, int T, int d, int N, int k,
+                                int set_feature, float set_value, int zero_feature, float *vals,
+                                int32_t *idx, int32_t *status, void *ws, size_t ws_bytes,
+                                void *stream) {
+  if (!idx) return MSAE_EINVAL;
+  return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
+                          zero_feature, vals, IdxOut{idx, nullptr}, status, ws, ws_bytes, stream);
+}
+
+extern "C" int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                                    const float *b_dec, const void *prepared, int T, int d, int N, int k,
+                                    int set_feature, float set_value, int zero_feature, float *vals,
+                                    int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
+                                    void *stream) {
+  if (!idx) return MSAE_EINVAL;
+  return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
+                          zero_feature, vals, IdxOut{nullptr, idx}, status, ws, ws_bytes, stream);
 }

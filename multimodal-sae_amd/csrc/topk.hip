@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
                                                                int T, int N, int k, int ld,
                                                                const int *__restrict__ n_rows,
                                                                float *__restrict__ vals,
-                                                               int32_t *__restrict__ idx) {
+                                                               int32_t *__restrict__ idx, TopkExtra ex) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (n_rows) T = min(T, *n_rows);         // device-side row count (exact fallback)
   TkShared &sh = *reinterpret_cast<TkShared *>(smem_raw);
@@ -208,12 +208,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
 
   // ---- canonical order ---------------------------------------------------------------------
   bitonic_sort_desc_u64(keys, kp);
+  const int orow = ex.row_map ? ex.row_map[rowi] : rowi;
   for (int j = threadIdx.x; j < k; j += TK_THREADS) {
     const unsigned long long kk = keys[j];
     const int ix = rank_key_index(kk);
-    idx[(size_t)rowi * k + j] = ix;
-    vals[(size_t)rowi * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
+    if (idx) idx[(size_t)orow * k + j] = ix;
+    if (ex.idx64) ex.idx64[(size_t)orow * k + j] = ix;
+    vals[(size_t)orow * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
   }
+  // a token the fused encoder could not verify, recomputed here: status 1 (msae_set_status_detail keeps why)
+  if (ex.status && threadIdx.x == 0) ex.status[orow] = ex.detail ? (1 | ((ex.status[orow] & ~3) << 8)) : 1;
   __syncthreads();   // sh / keys are reused by the next row
   }
 }
@@ -314,7 +318,7 @@ extern "C" size_t msae_topk_ws_bytes(int T, int N, int k) {
 
 // ld = row pitch in elements (>= N); exposed to the other translation units of the library.
 int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
-                     float *vals, int32_t *idx, hipStream_t s) {
+                     float *vals, int32_t *idx, hipStream_t s, const TopkExtra &ex) {
   if (T < 0 || N <= 0 || k <= 0 || k > N || k > 4096 || ld < N) return MSAE_EINVAL;
   if (T == 0) return 0;
   const size_t smem = sizeof(TkShared) + (size_t)next_pow2(k) * sizeof(unsigned long long);
@@ -322,10 +326,10 @@ int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const in
   const int grid = (n_rows && T > 128) ? 128 : T;   // device-side count: workgroups loop over the rows
   if (vec)
     hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(grid), dim3(TK_THREADS), smem, s, latents, T, N, k, ld,
-                       n_rows, vals, idx);
+                       n_rows, vals, idx, ex);
   else
     hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(grid), dim3(TK_THREADS), smem, s, latents, T, N, k,
-                       ld, n_rows, vals, idx);
+                       ld, n_rows, vals, idx, ex);
   return msae_launch_status();
 }
 
@@ -346,7 +350,7 @@ bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float
 extern "C" int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_t *idx,
                              void *ws, size_t ws_bytes, void *stream) {
   (void)ws; (void)ws_bytes;
-  return msae_topk_launch(latents, T, N, k, N, nullptr, vals, idx, (hipStream_t)stream);
+  return msae_topk_launch(latents, T, N, k, N, nullptr, vals, idx, (hipStream_t)stream, TopkExtra());
 }
 
 extern "C" int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, int k, float *vals,

@@ -35,8 +35,13 @@ PROTOTYPES = {
     "msae_encode_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    "msae_encode_topk_i64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "msae_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
+    "msae_decode_i64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p]),
     "msae_decode_bwd_acts_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p]),
     "msae_decode_bwd_wdec_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

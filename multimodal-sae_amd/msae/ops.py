@@ -154,20 +154,21 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     N, d = W.shape
     assert xa.shape[-1] == d, f"x last dim {xa.shape[-1]} != d_in {d}"
     T = xa.numel() // d
+    # the kernels write every element of all three outputs (int64 indices directly: no widening pass)
     vals = torch.empty(*xa.shape[:-1], k, dtype=torch.float32, device=dev)
-    idx = torch.empty(*xa.shape[:-1], k, dtype=torch.int32, device=dev)
-    status = torch.zeros(xa.shape[:-1], dtype=torch.int32, device=dev)
+    idx = torch.empty(*xa.shape[:-1], k, dtype=torch.int64, device=dev)
+    status = torch.empty(xa.shape[:-1], dtype=torch.int32, device=dev)
     if T == 0:
-        return vals, idx.to(torch.int64), status
+        return vals, idx, status
     nws = lib.msae_encode_topk_ws_bytes(T, d, N, k)
     ws = _workspace(dev, nws)
     with torch.cuda.device(dev):
-        _hip.check(lib.msae_encode_topk(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
-                                        _hip.ptr(be), _hip.ptr(bd), _hip.ptr(prepared), T, d, N, k,
-                                        set_feature, set_value, zero_feature, _hip.ptr(vals),
-                                        _hip.ptr(idx), _hip.ptr(status), _hip.ptr(ws), ws.numel(),
-                                        _hip.stream_of(xa)), "msae_encode_topk")
-    return vals, idx.to(torch.int64), status
+        _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
+                                            _hip.ptr(be), _hip.ptr(bd), _hip.ptr(prepared), T, d, N, k,
+                                            set_feature, set_value, zero_feature, _hip.ptr(vals),
+                                            _hip.ptr(idx), _hip.ptr(status), _hip.ptr(ws), ws.numel(),
+                                            _hip.stream_of(xa)), "msae_encode_topk_i64")
+    return vals, idx, status
 
 
 @encode_topk.register_fake
@@ -197,14 +198,18 @@ def decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, b_dec: Optional
     dev = _hip.require_device(top_indices, top_acts, W_dec, b_dec)
     lib = _hip.load()
     assert top_indices.shape == top_acts.shape, "indices / acts shape mismatch"  # kernels.py:193
-    idx, acts, W, bd = _idx32(top_indices), _f32c(top_acts), _f32c(W_dec), _f32c(b_dec)
+    acts, W, bd = _f32c(top_acts), _f32c(W_dec), _f32c(b_dec)
+    if top_indices.dtype == torch.int64:      # Tensor.topk's index type: read as it is, no narrowing copy
+        idx, fn, name = top_indices.detach().contiguous(), lib.msae_decode_i64_f32, "msae_decode_i64_f32"
+    else:
+        idx, fn, name = _idx32(top_indices), lib.msae_decode_f32, "msae_decode_f32"
     N, d = W.shape
     k = idx.shape[-1]
     A = idx.numel() // k
     out = torch.empty(*idx.shape[:-1], d, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _hip.check(lib.msae_decode_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(W), _hip.ptr(bd), A, k, N,
-                                       d, _hip.ptr(out), None, _hip.stream_of(acts)), "msae_decode_f32")
+        _hip.check(fn(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(W), _hip.ptr(bd), A, k, N, d, _hip.ptr(out), None,
+                      _hip.stream_of(acts)), "%s" % name)
     return out
 
 

@@ -250,6 +250,40 @@ def test_fused_encode_bit_exact_vs_oracle(dev, coarse, T, d, N, k):
     assert_bit_equal(v.cpu().numpy(), ref_v, "fused vals")
 
 
+@pytest.mark.parametrize("T,d,N,k", [(1, 1024, 8192, 32), (3, 4096, 16384, 32), (300, 1024, 8192, 64), (40, 200, 1000, 8)])
+def test_encode_and_decode_entry_points_of_both_index_widths_agree(dev, T, d, N, k):
+    """msae_encode_topk (int32 indices) and msae_encode_topk_i64 (what torch.ops.msae.encode_topk calls), and
+    msae_decode_f32 / msae_decode_i64_f32, straight through the C ABI: small-T path, MFMA path, exact path."""
+    from msae import _hip, ops
+
+    lib = _hip.load()
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 15)
+    x = _rand_x(dev, T, d, 16)
+    prepared = ops.prepare_encoder(W_enc)
+    v64, i64, st64 = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)
+    assert i64.dtype == torch.int64
+    v32 = torch.empty(T, k, dtype=torch.float32, device=dev)
+    i32 = torch.full((T, k), -1, dtype=torch.int32, device=dev)
+    st32 = torch.full((T,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.msae_encode_topk_ws_bytes(T, d, N, k) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    rc = lib.msae_encode_topk(_hip.ptr(x), _hip.DTYPE_CODE[x.dtype], _hip.ptr(W_enc), _hip.ptr(b_enc), _hip.ptr(b_dec),
+                              _hip.ptr(prepared), T, d, N, k, -1, 0.0, -1, _hip.ptr(v32), _hip.ptr(i32), _hip.ptr(st32),
+                              ws.data_ptr() + off, ws.numel() - off, _hip.stream_of(x))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.equal(i32.long(), i64) and torch.equal(v32, v64) and torch.equal(st32, st64)
+    W_dec = torch.randn(N, d, device=dev)
+    out64 = ops.decode(i64, v64, W_dec, b_dec)
+    out32 = ops.decode(i32, v64, W_dec, b_dec)
+    assert torch.equal(out64, out32)
+    bad = i64.clone()
+    bad[0, 0] = N + (1 << 33)           # outside [0, N) also beyond 32 bits: skipped, like the int32 entry does
+    ref = i32.clone()
+    ref[0, 0] = -1
+    assert torch.equal(ops.decode(bad, v64, W_dec, b_dec), ops.decode(ref, v64, W_dec, b_dec))
+
+
 def test_fused_encode_full_width_matches_exact_path(dev, coarse):
     """BASELINE config 2 shape: d=4096, N=131072, k=32 (and k=256).  Fused path == exact HIP path
     bit for bit on every token; exact HIP path == oracle on a subset of tokens."""

@@ -18,7 +18,8 @@ for T in (1, 8, 64, 128, 256, 1024, 2880):
         torch.cuda.synchronize(); res[name] = (time.perf_counter() - t0) / 10 * 1e3
     v, i, s = ops.encode_topk(xs, W_enc, b_enc, b_dec, prep, k)
     ev, ei = ops.topk(ops.pre_acts(xs, W_enc, b_enc, b_dec), k) if T <= 256 else (v, i)
-    t0 = time.perf_counter(); 
+    for _ in range(3): r = ops.decode(i, v, W_dec, b_dec)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): r = ops.decode(i, v, W_dec, b_dec)
     torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 10 * 1e3
     print(f"T={T:5d}  fused {res['fused']:.3f} ms  exact {res.get('exact', float('nan')):.3f} ms  decode {td:.3f} ms  "
