@@ -41,6 +41,7 @@
 // Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the token
 // verifies, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_mfma.h"
@@ -493,6 +494,9 @@ constexpr int G_BM = GemmBf16::BM;
 #ifndef MSAE_RESCORE_U
 #define MSAE_RESCORE_U 16
 #endif
+#ifndef MSAE_RESCORE_LPR      // lanes that share a row of W_enc in the re-scoring stream: 1, or 4 (64-B pieces per
+#define MSAE_RESCORE_LPR 1    // row and instruction, 16 rows per pass: measured 1.61 ms against 1.17 -- not the default)
+#endif
 static_assert(MSAE_RESCORE_U * 4 == 64, "one re-scoring batch must be the 64 floats fast_shape_ok() guarantees");
 struct RescoreArgs {
   const float *a32; const float *W_enc, *b_enc;
@@ -621,49 +625,71 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   for (;;) {
     ++rounds;
     int my_viol = 0;
-    for (int c0 = done; c0 < target; c0 += NT) {
-      const int c = c0 + lane;
-      const bool active = c < target;
-      const unsigned long long key = active ? keys[c] : keys[c0];
-      const int f = rank_key_index(key);
-      const float upper = f32_from_order_key((unsigned)(key >> 32));
-      const f32x4 cc = p.colc[f];
-      const float *__restrict__ w = W_enc + (size_t)f * p.d;
-      float acc = 0.f;
-      // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
-      // other is in flight, so the lane never drains its loads (bytes in flight per CU are what
-      // bounds this kernel: ~7 waves/CU x 45 lanes x RS_U..2*RS_U x 16 B against ~64 KB needed)
-      constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U;   // floats per batch
-      f32x4 wa[RS_U], wb[RS_U];
-      auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
+    // LPR = 1: lane c streams row c (16 B per lane and instruction).  LPR = 4 (tuning builds): four lanes share a
+    // row, lane q loading bytes [16 q, 16 q + 16) of every 64-B piece -- four times fewer cache lines per
+    // instruction, but only 16 rows per pass, i.e. three row-streaming latencies per round instead of one.  The
+    // chain stays one serial ascending-k sequence: sub-step q multiplies the group's lane-q piece (every lane
+    // executes it on its own registers; only lane q's is the true partial sum) and a quad rotate hands the
+    // accumulator on.  The activations are wave-uniform scalar operands either way.
+    auto run_pass = [&](auto lpr_tag) {
+      constexpr int LPR = decltype(lpr_tag)::value;
+      constexpr int RPP = NT / LPR;                  // rows per pass
+      constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U * LPR;   // floats of a row per batch
+      const int rq = lane / LPR, q = lane % LPR;
+      for (int c0 = done; c0 < target; c0 += RPP) {
+        const int c = c0 + rq;
+        const bool active = c < target;
+        const unsigned long long key = active ? keys[c] : keys[c0];
+        const int f = rank_key_index(key);
+        const float upper = f32_from_order_key((unsigned)(key >> 32));
+        const f32x4 cc = p.colc[f];
+        const float *__restrict__ w = W_enc + (size_t)f * p.d + 4 * q;
+        float acc = 0.f;
+        // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
+        // other is in flight, so the lane never drains its loads
+        f32x4 wa[RS_U], wb[RS_U];
+        auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
 #pragma unroll
-        for (int u = 0; u < RS_U; ++u) dst[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
-      };
-      auto consume = [&](const f32x4 (&src)[RS_U], int kk) {
+          for (int u = 0; u < RS_U; ++u) dst[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * LPR * u);
+        };
+        auto consume = [&](const f32x4 (&src)[RS_U], int kk) {
 #pragma unroll
-        for (int u = 0; u < RS_U; ++u) {
-          acc = __builtin_fmaf(a[kk + 4 * u + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
-          acc = __builtin_fmaf(a[kk + 4 * u + 1], src[u][1], acc);
-          acc = __builtin_fmaf(a[kk + 4 * u + 2], src[u][2], acc);
-          acc = __builtin_fmaf(a[kk + 4 * u + 3], src[u][3], acc);
+          for (int u = 0; u < RS_U; ++u) {
+#pragma unroll
+            for (int qq = 0; qq < LPR; ++qq) {
+              const int k0 = kk + 4 * LPR * u + 4 * qq;
+              acc = __builtin_fmaf(a[k0 + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
+              acc = __builtin_fmaf(a[k0 + 1], src[u][1], acc);
+              acc = __builtin_fmaf(a[k0 + 2], src[u][2], acc);
+              acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
+              if constexpr (LPR == 4)   // quad_perm:[3,0,1,2] -- lane i takes lane i - 1's value, lane 0 lane 3's
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xF, 0xF, false));
+            }
+          }
+        };
+        fetch(wa, 0);
+        for (int kk = 0; kk < p.d; kk += 2 * RS_B) {     // d % RS_B == 0 (fast_shape_ok / the caller's choice of LPR)
+          const bool has_b = kk + RS_B < p.d;
+          if (has_b) fetch(wb, kk + RS_B);
+          consume(wa, kk);
+          if (kk + 2 * RS_B < p.d) fetch(wa, kk + 2 * RS_B);
+          if (has_b) consume(wb, kk + RS_B);
         }
-      };
-      fetch(wa, 0);
-      for (int kk = 0; kk < p.d; kk += 2 * RS_B) {     // d % RS_B == 0 on this path (fast_shape_ok)
-        const bool has_b = kk + RS_B < p.d;
-        if (has_b) fetch(wb, kk + RS_B);
-        consume(wa, kk);
-        if (kk + 2 * RS_B < p.d) fetch(wa, kk + 2 * RS_B);
-        if (has_b) consume(wb, kk + RS_B);
+        const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
+        if (active && q == 0) {                          // whole pieces done: the sum is back in the group's lane 0
+          res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
+          // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
+          const float zs2 = band_sq(rc, cc, p.zz12, i8);
+          const float diff = pre - (upper - __builtin_sqrtf(zs2));
+          if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
+        }
       }
-      const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
-      if (active) {
-        res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
-        // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
-        const float zs2 = band_sq(rc, cc, p.zz12, i8);
-        const float diff = pre - (upper - __builtin_sqrtf(zs2));
-        if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
-      }
+    };
+    if constexpr (MSAE_RESCORE_LPR == 4) {
+      if (p.d % (4 * MSAE_RESCORE_U * 4) == 0) run_pass(std::integral_constant<int, 4>());
+      else run_pass(std::integral_constant<int, 1>());
+    } else {
+      run_pass(std::integral_constant<int, 1>());
     }
     done = target;
     viol = viol || (__syncthreads_or(my_viol) != 0);
