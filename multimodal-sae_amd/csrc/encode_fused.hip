@@ -491,6 +491,14 @@ using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
 constexpr int G_BM = GemmBf16::BM;
 
 // ---- candidate select + exact re-score ----------------------------------------------------------
+// The S = 1 weight stream reads every 1-KiB row piece exactly once per call: non-temporal loads (0.141 -> 0.131 ms
+// at T = 1).  NOT for the re-scoring rows: a lane fetches a 128-B line in eight 16-B loads and lives on the
+// cache holding it in between (non-temporal there: 1.18 -> 3.34 ms, profiles/r02_ab_nontemporal.txt).
+#ifdef MSAE_GEMV_PLAIN_LOADS
+#define MSAE_STREAM_LOAD(p) (*(p))
+#else
+#define MSAE_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 #ifndef MSAE_RESCORE_U
 #define MSAE_RESCORE_U 16
 #endif
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
 #pragma unroll
       for (int q = 0; q < DSEG; ++q)
         w[r][q] = (n0 + r * n_waves < N)
-                      ? *reinterpret_cast<const i32x4 *>(wq + (size_t)(n0 + r * n_waves) * d + q * 1024 + lane * 16)
+                      ? MSAE_STREAM_LOAD(reinterpret_cast<const i32x4 *>(wq + (size_t)(n0 + r * n_waves) * d + q * 1024 + lane * 16))
                       : i32x4{0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
