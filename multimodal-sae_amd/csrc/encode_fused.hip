@@ -271,16 +271,23 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
 // x side (every call).  Massive-activation dims would dictate the per-token scale and wipe out
 // the resolution of all other dims, so they are split off: colmax -> outlier dim list ->
 // per-token quantisation with the outliers in their own 128-wide k-tile at scale m[t]*sx[t].
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ a32, int T, int d,
-                                                     unsigned *__restrict__ colmax_bits) {
+// int8 pass: prep_x and colmax in one sweep -- a thread owns four columns (b_dec in registers) and walks its
+// rows: a32 = x - b_dec is written once and never read back for the maxima.
+template <int DT>
+__global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
+                                                          int T, int d, float *__restrict__ a32,
+                                                          unsigned *__restrict__ colmax_bits) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= d) return;
   const int rows_per = (T + gridDim.y - 1) / gridDim.y;
   const int t0 = blockIdx.y * rows_per, t1 = min(T, t0 + rows_per);
+  const f32x4 bd = b_dec ? *reinterpret_cast<const f32x4 *>(b_dec + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int t = t0; t < t1; ++t) {
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);
+    f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
+    if (b_dec) v = v - bd;
+    *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
     m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
     m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
   }
@@ -1297,8 +1304,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   prof_mark(0, s);
   hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)T + 64 + pl.fb_chunks,
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
-  hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.i8 ? T : pl.Tp, d,
-                     pl.i8 ? (unsigned short *)nullptr : xb, a32);
+  if (!pl.i8)
+    hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
   GemmOperands op_main{}, op_samp{};
   const float z = guard_z(), zz12 = z * z / 12.f;
@@ -1317,7 +1324,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
-    hipLaunchKernelGGL(colmax_kernel, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, a32, T, d, colmax);
+    hipLaunchKernelGGL(prep_colmax_kernel<DT>, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+                       colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     hipLaunchKernelGGL(quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, a32, T, d, odims, is_out, xq, xqo, rowc, zz12);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
