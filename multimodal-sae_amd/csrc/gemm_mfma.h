@@ -117,7 +117,8 @@ struct GemmCfg {
   static constexpr int SIDE_SLOTS = 6;
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 2304;
-  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
+  static constexpr int PF_SINK_BYTES = 256;      // where the L2-warming loads of the k-loop land (never read)
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8 + PF_SINK_BYTES;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
@@ -176,6 +177,19 @@ __device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A,
                                            int n0, size_t kbyte, unsigned char *lds, int slot, int wave,
                                            const GemmStageLane &sl) {
   gemm_stage_pieces<C, C::PPW>(A, B, ld, m0, n0, kbyte, lds, slot, wave * C::PPW, sl);
+}
+
+// L2 warming (tuning builds, -DMSAE_GEMM_WARM; measured 4.41 ms against 4.22 without: NOT the default -- the
+// k-loop is not waiting on L2 misses).  The 32 workgroups of an XCD walk an 8 x 4 super-tile in step, so every operand line of a k-tile
+// is requested by 4 (A) or 8 (B) CUs at almost the same time -- and ALL of them wait for the one miss.  Each CU
+// therefore touches its 1/4 of the A tile's lines and 1/8 of the B tile's lines two k-tiles ahead (96 lines:
+// waves 0-3 sixteen A rows each, waves 4-7 eight B rows each), with one 4-byte LDS-DMA load per wave into a
+// sink nobody reads: no VGPR, nothing to wait for -- the k-loop's vmcnt leaves this youngest load outstanding.
+__device__ __forceinline__ void gemm_warm_l2(const unsigned char *sbase, unsigned voff, unsigned sink) {
+#ifdef MSAE_GEMM_WARM
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(sink) : "memory", "m0");
+#endif
 }
 
 __device__ __forceinline__ i32x4 gemm_frag(const unsigned char *tile, int row, int chunk) {
@@ -571,11 +585,28 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     else
       gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, sl_main);
   };
-  if (tile_id == (int)blockIdx.x) stage(m0, n0, 0, 0);   // later tiles: staged by their predecessor
+  // L2 warming two k-tiles ahead (gemm_warm_l2): this wave's rows of the shared operand tiles
+  const bool pf_a = wave < 4;
+  const int pf_wi = (m0 / C::BM) & 7, pf_wj = (n0 / C::BN) & 3;         // position inside the XCD's 8 x 4 super-tile
+  const int pf_row = pf_a ? pf_wj * 64 + wave * 16 : pf_wi * 32 + (wave - 4) * 8;   // first row inside the tile
+  const unsigned pf_voff = (unsigned)(lane & (pf_a ? 15 : 7)) * (unsigned)op.ldA;
+  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + C::LDS_BYTES - C::PF_SINK_BYTES);
+  auto warm = [&](int tm0, int tn0, int kmain) {         // main k-tile index (>= 0) of the tile at (tm0, tn0)
+    const unsigned char *base = pf_a ? op.A + (size_t)(tm0 + pf_row) * op.ldA : op.B + (size_t)(tn0 + pf_row) * op.ldB;
+    gemm_warm_l2(base + (size_t)kmain * C::ROWB, pf_voff, pf_sink);
+  };
+  if (tile_id == (int)blockIdx.x) {   // later tiles: staged by their predecessor
+    stage(m0, n0, 0, 0);
+    warm(m0, n0, 1 < op.nk ? 1 : 0);  // keeps "the youngest load is a warming load" true from the first wait on
+  }
 
   int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
   auto iteration = [&](int kt, bool park_m = false) {
+#ifndef MSAE_GEMM_WARM
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
+#else
+    wait_vmcnt<1>();               // ... all but the youngest load: the L2-warming one issued behind them
+#endif
     if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
       if (tid_ < C::BM) side_m[tid_] = side2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -586,6 +617,12 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     if constexpr (!C::ABL_NOSTAGE) {
       if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
+      {   // one warming load per wave and iteration, always (the wait above counts on it)
+        const int k2 = kt + 2 - lead;                    // main k-tile two ahead: this tile's, else the next tile's
+        const bool cur = k2 < op.nk, nxt = !cur && has_next;      // (selects, no control flow: see gemm_stage_pieces)
+        const int kn = k2 - op.nk < op.nk ? k2 - op.nk : 0;
+        warm(nxt ? m0n : m0, nxt ? n0n : n0, cur ? k2 : (nxt ? kn : op.nk - 1));
+      }
     }
     const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
     if (park_m) gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
