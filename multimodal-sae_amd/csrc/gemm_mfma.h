@@ -76,11 +76,20 @@ struct GemmEpilogue {
   unsigned long long *timeline;
 #endif
 };
-#ifdef MSAE_GEMM_TIMELINE
+#if defined(MSAE_GEMM_TIMELINE) && MSAE_GEMM_TIMELINE != 2
 #define MSAE_TL(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && ep.timeline && tl_tile < 64) \
     ep.timeline[tl_tile * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MSAE_TL(slot) do { } while (0)
+#endif
+#if defined(MSAE_GEMM_TIMELINE) && MSAE_GEMM_TIMELINE == 2   // inside k-tile 8 of every output tile (wave MSAE_TLK_WAVE)
+#ifndef MSAE_TLK_WAVE
+#define MSAE_TLK_WAVE 0
+#endif
+#define MSAE_TLK(cond, slot) do { if ((cond) && blockIdx.x == 0 && threadIdx.x == 64 * MSAE_TLK_WAVE && ep.timeline && tl_tile < 64) \
+    ep.timeline[tl_tile * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MSAE_TLK(cond, slot) do { } while (0)
 #endif
 
 // Operands of one launch.  A rows are tokens, B rows are features; ld* in BYTES.
@@ -262,9 +271,11 @@ __device__ __forceinline__ void gemm_read_frags(i32x4 (&a)[C::MI], i32x4 (&b)[C:
   a[2] = lds_read_b128<2 * 4096>(addrA); a[3] = lds_read_b128<3 * 4096>(addrA);
   b[0] = lds_read_b128<0 * 4096>(addrB); b[1] = lds_read_b128<1 * 4096>(addrB);
 }
-template <class C>
+// `mid` runs between k-steps 1 and 2 (the reads of k-steps 2 and 3 are in flight across it): the waves that
+// issue the next k-tile's LDS-DMA there instead of before their first MFMA (gemm_kernel: stagger)
+template <class C, class F>
 __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
-                                                 int wr, int wc, int l31, int kh) {
+                                                 int wr, int wc, int l31, int kh, F &&mid) {
   static_assert(C::KS == 4, "four k-steps per tile");
   const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
   const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
@@ -282,10 +293,16 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   lgkm_wait_tied<6, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
   gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
+  mid();
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
+}
+template <class C>
+__device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
+                                                 int wr, int wc, int l31, int kh) {
+  gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [] {});
 }
 
 // the outlier k-tile: only its first `nks` k-steps hold data (32 outlier dims per k-step), the rest is zero
@@ -602,6 +619,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 
   int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
   auto iteration = [&](int kt, bool park_m = false) {
+    MSAE_TLK(kt == 8, 0);
+    MSAE_TLK(kt == 9, 5);
 #ifndef MSAE_GEMM_WARM
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
 #else
@@ -611,12 +630,27 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (tid_ < C::BM) side_m[tid_] = side2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    MSAE_TLK(kt == 8, 1);
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
+    MSAE_TLK(kt == 8, 2);
     if (kt == 0) MSAE_TL(1);
     if (kt == 1) MSAE_TL(2);
-    if constexpr (!C::ABL_NOSTAGE) {
+    auto stage_next = [&]() {
       if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
+    };
+#ifdef MSAE_GEMM_STAGGER
+    // Waves w and w + 4 share a SIMD.  If both issue their eight LDS-DMA pieces right behind the barrier (~700
+    // cycles of issue each) the SIMD's MFMA pipe idles for that long in every k-tile; so the upper four waves
+    // start with MFMAs on the data already in LDS and issue their pieces between k-steps 1 and 2, while their
+    // partners -- done issuing -- keep the pipe busy.  ONE copy of the MFMA code: the two roles differ only in
+    // which of the two stage_next() call sites is taken.
+    const bool late = (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m;
+#else
+    constexpr bool late = false;
+#endif
+    if constexpr (!C::ABL_NOSTAGE) {
+      if (!late) stage_next();
       {   // one warming load per wave and iteration, always (the wait above counts on it)
         const int k2 = kt + 2 - lead;                    // main k-tile two ahead: this tile's, else the next tile's
         const bool cur = k2 < op.nk, nxt = !cur && has_next;      // (selects, no control flow: see gemm_stage_pieces)
@@ -624,9 +658,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         warm(nxt ? m0n : m0, nxt ? n0n : n0, cur ? k2 : (nxt ? kn : op.nk - 1));
       }
     }
+    MSAE_TLK(kt == 8, 3);
     const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
     if (park_m) gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
+    else if constexpr (!C::ABL_NOREAD && !C::ABL_NOMFMA && !C::ABL_NOSTAGE)
+      gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [&] { if (late) stage_next(); });
     else gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
+    MSAE_TLK(kt == 8, 4);
     ++seq;
   };
   auto scale_by_m = [&]() {

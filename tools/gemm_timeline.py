@@ -20,6 +20,13 @@ buf = (ctypes.c_ulonglong * 512)()
 lib.msae_debug_timeline.restype = ctypes.c_int
 assert lib.msae_debug_timeline(buf) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(64, 8)
+if "--k" in sys.argv:   # build with -DMSAE_GEMM_TIMELINE=2 [-DMSAE_TLK_WAVE=w]: stamps inside k-tile 8 of each output tile
+    seg = np.diff(t[2:62, :6], axis=1)
+    for n, v in zip(["wait vmcnt (own DMA pieces)", "wait barrier", "issue next k-tile's DMA", "ds_read + MFMA", "to next iteration"],
+                    np.median(seg, axis=0)):
+        print(f"  {n:30s} {v:8.0f}")
+    print(f"  k-tile period                  {np.median(t[2:62, 5] - t[2:62, 0]):8.0f}")
+    sys.exit(0)
 names = ["prologue->barrier0", "k-tile 0 (outlier)", "k-tiles 1..", "park + 2 barriers", "element loop", "flush", "loop back"]
 order = [0, 1, 2, 3, 7, 4, 5, 6]                 # stamp 7 (epilogue barriers passed) sits between 3 and 4
 seg = np.diff(t[:, order], axis=1)[2:62]       # skip the first / last tiles
