@@ -10,10 +10,14 @@ k-sparse decode.  Workload = BASELINE.json configs[1]: d_model=4096, width=13107
 activations shaped like a residual stream (a few x20 outlier dims), random-init unit-norm weights.
 
 N > 1 (configs[2], the split north_star names) is the HEADLINE of a multi-GPU run: the 131072-feature
-axis is sharded over the ranks (N/G rows of W_enc each); every rank encodes the SAME T tokens against
-its shard, the per-shard top-k_loc pairs are exchanged with one RCCL all-gather (<= 256 B/token/rank)
-and merged, and the decode is token-sharded with an all-gather of the reconstruction.  Total work is
-fixed as G grows: "scaling": "strong", value = T * steps / max-over-ranks time.  The reference's own
+axis is sharded over the ranks (N/G rows of W_enc each); every rank runs the candidate pass over the SAME
+T tokens against its shard.  Two exchange schemes are timed in the same run ("shard_modes") and the faster
+bit-identical one is the headline: (a) per-shard EXACT top-k_loc pairs, one RCCL all-gather, merge with a
+truncation re-check; (b) per-shard top-C candidates by upper bound, one RCCL all-to-all, exact re-score on the
+token's owner against the replicated f32 W_enc (the HBM-bound re-score then runs once per token instead of
+once per token and rank), all-gather of the results.  The decode is token-sharded with an all-gather of the
+reconstruction.  Total work is fixed as G grows: "scaling": "strong", value = T * steps / max-over-ranks
+time; the first 256 tokens are compared with a single-GPU encode.  The reference's own
 multi-GPU mode -- token-sharded replicas, no data-path collective (launch/cache/cache.py:66) -- is
 measured in the same run and reported under "replicas" (weak scaling).
 
@@ -172,10 +176,17 @@ def main():
     data = "synthetic"
     # ---- headline engine.  N = 1: the whole SAE on one GPU.  N > 1: rank g holds rows [g N/G, (g+1) N/G)
     # of W_enc / b_enc and a replicated W_dec; every rank sees the same T tokens (seed 0)
+    engine_cand = None
     if sharded:
-        W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=0, rows=(lo, hi), dec_rows=(0, N))
+        # every rank keeps the whole f32 W_enc (2 GiB of 288 GB): the candidate-exchange mode re-scores a token's
+        # candidates on the token's owner, and the check below encodes 256 tokens on one GPU
+        W_full, b_full, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=0, rows=(0, N), dec_rows=(0, N))
+        W_enc, b_enc = W_full[lo:hi], b_full[lo:hi]
         engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
                             force_collectives=force)
+        if os.environ.get("MSAE_SHARD_MODE", "both") != "topk":
+            engine_cand = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
+                                     force_collectives=force, mode="candidates", W_enc_full=W_full, b_enc_full=b_full)
     else:
         W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=rank)
         if args.sae_path or args.acts:
@@ -255,6 +266,29 @@ def main():
         watchdog.start()
 
     elapsed, out, stage, dec_ms = timed(engine, x, args.steps, args.warmup, profile=True)
+    mode_desc = "per-shard exact top-%d, RCCL all-gather + merge" % engine.k_loc
+    shard_modes = {}
+    if sharded:
+        # both exchange schemes are timed; the headline is the faster one whose first 256 tokens are bit-identical to
+        # a single-GPU encode of the same tokens (the per-shard top-k scheme ran first: if the second leg wedges, the
+        # watchdog still reports it)
+        chk_v, chk_i, _ = ops.encode_topk(x[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
+        same = lambda o: bool(torch.equal(chk_i, o["top_indices"][:256]) and torch.equal(chk_v, o["top_acts"][:256]))
+        ok_topk = same(out)
+        shard_modes["per_shard_topk"] = {"ms_per_step": elapsed / args.steps * 1e3, "bit_identical_256": ok_topk,
+                                         "k_loc": engine.k_loc, "second_round_tokens": engine.second_round_tokens}
+        res["sharded_bit_identical_to_single_gpu_on_256_tokens"] = ok_topk
+        res["ms_per_step"], res["value"] = elapsed / args.steps * 1e3, T * args.steps / elapsed   # for the watchdog
+        if engine_cand is not None:
+            el_c, out_c, stage_c, dec_c = timed(engine_cand, x, args.steps, args.warmup, profile=True)
+            ok_c = same(out_c)
+            shard_modes["candidate_exchange"] = {"ms_per_step": el_c / args.steps * 1e3, "bit_identical_256": ok_c,
+                                                 "candidates_per_shard": engine_cand.n_cand}
+            if ok_c and (el_c < elapsed or not ok_topk):
+                elapsed, out, stage, dec_ms, engine = el_c, out_c, stage_c, dec_c, engine_cand
+                res["sharded_bit_identical_to_single_gpu_on_256_tokens"] = ok_c
+                mode_desc = ("per-shard top-%d candidates by upper bound, RCCL all-to-all, exact re-score on the token's "
+                             "owner against the replicated W_enc, all-gather of the results" % engine_cand.n_cand)
 
     if rank == 0:
         res["ms_per_step"] = elapsed / args.steps * 1e3
@@ -264,9 +298,10 @@ def main():
                         "random-init unit-norm f32 weights" % (d, N, k, T),
             "tokens_per_step": T, "k": k,
             "parallelism": "single GPU" if not sharded else
-            f"feature-sharded x{world} (BASELINE configs[2]): {n_loc} rows of W_enc per rank, per-shard exact "
-            f"top-{engine.k_loc}, RCCL all-gather + merge, token-sharded decode + all-gather of the reconstruction"}
+            f"feature-sharded x{world} (BASELINE configs[2]): {n_loc} rows of W_enc per rank, {mode_desc}, "
+            f"token-sharded decode + all-gather of the reconstruction"}
         if sharded:
+            res["shard_modes"] = shard_modes
             res["second_round_tokens"] = engine.second_round_tokens
         if len(stage):
             mean = stage.mean(0)
@@ -295,14 +330,11 @@ def main():
     # gives the check of the sharded result: the merged top-k must be bit-identical to a single-GPU encode.
     if sharded and not args.no_replicas:
         try:
-            del engine
-            W_full, b_full, _, _, x_own = make_inputs(dev, T, d, N, seed=1 + rank, rows=(0, N), dec_rows=(0, 1))
-            chk_v, chk_i, _ = ops.encode_topk(x[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
-            same = bool(torch.equal(chk_i, out["top_indices"][:256]) and torch.equal(chk_v, out["top_acts"][:256]))
+            del engine, engine_cand
+            _, _, _, _, x_own = make_inputs(dev, T, d, 8192, seed=1 + rank)        # this rank's own batch
             rep = ShardedSae(W_full, b_full, W_dec, b_dec, k)
             el_r, _, _, _ = timed(rep, x_own, args.steps, args.warmup, profile=False)
             if rank == 0:
-                res["sharded_bit_identical_to_single_gpu_on_256_tokens"] = same
                 res["replicas"] = {"value": world * T * args.steps / el_r, "unit": "tokens/s",
                                    "ms_per_step": el_r / args.steps * 1e3, "scaling": "weak",
                                    "tokens_per_step": world * T,

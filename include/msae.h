@@ -126,6 +126,32 @@ int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const f
                          int set_feature, float set_value, int zero_feature, float *vals, int64_t *idx,
                          int32_t *status, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- feature-sharded group (BASELINE configs[2]: "per-shard TopK + RCCL merge over xGMI") ------
+ * The encoder's feature axis is split over G ranks; every rank sees the same T tokens.  Re-scoring a local top-k
+ * exactly on every rank would multiply the HBM-bound re-score work by G, so the shards exchange CANDIDATES:
+ *   msae_shard_candidates    rank g, all T tokens: candidate pass over its N/G features, then per token the C best
+ *                            by upper value u as one record of msae_shard_record_bytes(C) bytes:
+ *                            uint64 key[C] (order key of u << 32 | 0x7FFFFFFF - GLOBAL feature id, 0 = empty),
+ *                            float z_sigma[C], float tau (largest u any OTHER feature of the shard can have; +inf when
+ *                            the shard cannot bound it), float 0.  ws as for msae_encode_topk(T, d, N/G, k).
+ *   (all-to-all / all-gather of the records: rank r needs the records of its tokens from every shard)
+ *   msae_rescore_candidates  rank r, its T tokens (T_valid of them real): records[G][T] -> exact top-k against the
+ *                            FULL W_enc / b_enc (replicated, 2 GiB of 288 GB), same verification rule as
+ *                            msae_encode_topk (every feature with u >= v_k re-scored, v_k above every shard's tau,
+ *                            model check), unverifiable tokens recomputed exactly in the call.  Bit-identical to the
+ *                            single-GPU msae_encode_topk.  set_feature / zero_feature are global ids (both calls). */
+size_t msae_shard_record_bytes(int C);
+int msae_shard_candidates(const void *x, int x_dtype, const float *b_enc_shard, const float *b_dec,
+                          const void *prepared_shard, int T, int d, int N_shard, int k, int row_offset, int C,
+                          int set_feature, int zero_feature, void *records, void *ws, size_t ws_bytes,
+                          void *stream);
+size_t msae_rescore_candidates_ws_bytes(int T, int d, int N, int k, int G, int C);
+int msae_rescore_candidates(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                            const float *b_dec, int T, int T_valid, int d, int N, int k, int G, int C,
+                            const void *records, int set_feature, float set_value, int zero_feature,
+                            float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
+                            void *stream);
+
 /* ---- k-sparse decoder -------------------------------------------------------------------- */
 
 /* out[A][d] = sum_j acts[A][j] * W_dec[idx[A][j]][:] + b_dec  (j-ordered f32 fma chain, entries

@@ -523,7 +523,15 @@ struct RescoreArgs {
   float zz12, z2; int i8;
   float *vals; int32_t *idx; int64_t *idx64; int32_t *status;   // idx / idx64: either may be null
   int *flagged; int *n_flagged; int fb_cap;
+  // EXT (feature-sharded group, msae_rescore_candidates): the candidate lists come as the shards' records
+  // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
+  const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
 };
+
+// One shard's record of a token (msae_shard_candidates): C keys (order key of the upper value u | 0x7FFFFFFF -
+// GLOBAL feature, 0 = empty), C times z sigma of that (token, feature) pair, tau = the largest u any feature of
+// the shard NOT in the record can have (+inf: the shard could not bound it -> the token is recomputed exactly).
+__host__ __device__ inline int shard_record_bytes(int C) { return C * 12 + 8; }
 
 // Wave-wide bitonic sort (descending) of n = power-of-two u64 keys in LDS by ONE 64-lane wave.
 template <int NT>
@@ -571,26 +579,67 @@ __device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, f
 //     all candidates with u >= v_k are re-scored  and  v_k > tau  (non-candidates have u <= tau)
 // and no re-scored pair contradicted the error model (|p - coarse| <= 6 sigma).  Tokens that fail (or
 // overflowed their list / have tau <= 0 / more than r_max rows to read) go to the exact path.
-template <int NW>   // waves per token: 1 for k <= 64, 4 for larger k (longer lists, more rows per round)
+// EXT: the list is the union of the shards' records; keys[] then carries the list POSITION in its low word
+// (feature and z sigma are looked up by position: ef[], ezs[]).
+template <int NW, bool EXT = false>   // waves per token: 1 for k <= 64, 4 for larger k (longer lists, more rows per round)
 __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
   const int nrp = next_pow2(p.r_max + 1);
   unsigned long long *res = keys + p.cap;
+  [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
+  [[maybe_unused]] int *ef = reinterpret_cast<int *>(ezs + p.cap);        // EXT only: [cap] global feature by position
   constexpr int NT = 64 * NW;
   __shared__ float s_cc[NT], s_zs[NT], s_pick[2];
+  __shared__ int s_n;
+  __shared__ unsigned s_tau;
   const int lane = threadIdx.x;   // thread index within the token's workgroup
   const int t = blockIdx.x;
-  const int cnt = p.cnt[t];
-  const int n = cnt < p.cap ? cnt : p.cap;
-  const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+  if constexpr (EXT) { if (t >= p.ext_valid) return; }
+  int cnt, n;
+  float tau;
   const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
-  const f32x4 rc = p.rowc[t];
+  f32x4 rc = {0.f, 0.f, 0.f, 0.f};
   const bool i8 = p.i8 != 0;
-
-  const int np = next_pow2(n > 2 ? n : 2);
-  for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  int np;
+  if constexpr (EXT) {
+    const int M = p.ext_G * p.ext_C;
+    np = next_pow2(M > 2 ? M : 2);
+    if (lane == 0) { s_n = 0; s_tau = 0u; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = lane; i < np; i += NT) {
+      unsigned long long kv = 0ull;
+      if (i < M) {
+        const int g = i / p.ext_C, j = i - g * p.ext_C;
+        const unsigned char *rec = p.ext + ((size_t)g * p.ext_T + t) * p.ext_stride;
+        const unsigned long long key = reinterpret_cast<const unsigned long long *>(rec)[j];
+        if (key != 0ull) {
+          kv = (key & 0xFFFFFFFF00000000ull) | (unsigned)(0x7FFFFFFF - i);
+          ef[i] = rank_key_index(key);
+          ezs[i] = reinterpret_cast<const float *>(rec + (size_t)p.ext_C * 8)[j];
+          ++mine;
+        }
+      }
+      keys[i] = kv;
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    if (lane < p.ext_G) {           // tau = the largest bound of the shards (order keys: +inf dominates, NaN never enters)
+      const unsigned char *rec = p.ext + ((size_t)lane * p.ext_T + t) * p.ext_stride;
+      atomicMax(&s_tau, f32_order_key(*reinterpret_cast<const float *>(rec + (size_t)p.ext_C * 12)));
+    }
+    __syncthreads();
+    n = cnt = s_n;
+    tau = f32_from_order_key(s_tau);
+  } else {
+    cnt = p.cnt[t];
+    n = cnt < p.cap ? cnt : p.cap;
+    tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+    rc = p.rowc[t];
+    np = next_pow2(n > 2 ? n : 2);
+    for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  }
   for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
   wave_sort_desc_u64<NT>(keys, np, lane);   // upper value desc (index asc on ties)
   const int has_set = p.set_feature >= 0 ? 1 : 0;
@@ -604,7 +653,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     float my_cc = -__builtin_inff(), my_zs = 0.f;
     if (lane < mt) {
       const unsigned long long key = keys[lane];
-      my_zs = __builtin_sqrtf(band_sq(rc, p.colc[rank_key_index(key)], p.zz12, i8));
+      if constexpr (EXT) my_zs = ezs[rank_key_index(key)];
+      else my_zs = __builtin_sqrtf(band_sq(rc, p.colc[rank_key_index(key)], p.zz12, i8));
       my_cc = f32_from_order_key((unsigned)(key >> 32)) - my_zs;
     }
     s_cc[lane] = my_cc;
@@ -655,9 +705,12 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         const int c = c0 + rq;
         const bool active = c < target;
         const unsigned long long key = active ? keys[c] : keys[c0];
-        const int f = rank_key_index(key);
+        int f = rank_key_index(key);
+        float ext_zs = 0.f;
+        f32x4 cc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EXT) { ext_zs = ezs[f]; f = ef[f]; }     // list position -> (z sigma, global feature)
+        else cc = p.colc[f];
         const float upper = f32_from_order_key((unsigned)(key >> 32));
-        const f32x4 cc = p.colc[f];
         const float *__restrict__ w = W_enc + (size_t)f * p.d + 4 * q;
         float acc = 0.f;
         // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
@@ -694,7 +747,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         if (active && q == 0) {                          // whole pieces done: the sum is back in the group's lane 0
           res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
           // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
-          const float zs2 = band_sq(rc, cc, p.zz12, i8);
+          const float zs2 = EXT ? ext_zs * ext_zs : band_sq(rc, cc, p.zz12, i8);
           const float diff = pre - (upper - __builtin_sqrtf(zs2));
           if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
         }
@@ -743,6 +796,89 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   }
 }
 
+// Feature-sharded group, sender side: the C best candidates of THIS shard per token by upper value, as the
+// record shard_record_bytes() describes (global feature ids).  One wave per token.
+struct PackArgs {
+  const int *cnt; const unsigned long long *cand; int cap;
+  const float *tau_vals; int tau_ld, tau_col;
+  const f32x4 *rowc, *colc; float zz12; int i8;
+  int C, row_offset, stride;
+  unsigned char *recs;
+};
+template <int PK>   // key slots per lane: the list (<= cap <= 64 PK keys) lives in registers
+__global__ __launch_bounds__(64) void pack_candidates_kernel(PackArgs p) {
+  // The C largest of ~512 keys are a selection, not a sort: the keys sit in registers (PK per lane) and a bisection
+  // on the 64-bit key -- unique: the feature id is its low word -- finds the C-th largest with one ballot count
+  // per key slot and step; the survivors are compacted with ballot prefix counts (any order: the owner sorts).
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int cnt = p.cnt[t];
+  const int n = cnt < p.cap ? cnt : p.cap;
+  const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+  const bool bounded = cnt <= p.cap && tau > 0.f;        // list complete and a real threshold behind it
+  const int nj = bounded ? (n + 63) >> 6 : 0;            // key slots in use (wave-uniform)
+  unsigned long long kreg[PK];
+#pragma unroll
+  for (int j = 0; j < PK; ++j) {
+    const int i = j * 64 + lane;
+    kreg[j] = (j < nj && i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  }
+  unsigned long long lo = 0ull, hi = ~0ull;              // count(key >= lo) >= C  (or everything is taken), count(>= hi) < C
+  if (n > p.C) {
+    while (hi - lo > 1ull) {
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int jb = 0; jb < PK; jb += 8) {               // one branch per eight key slots (empty slots hold 0 < mid)
+        if (jb < nj) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kreg[j] >= mid));
+        }
+      }
+      if (c >= p.C) lo = mid; else hi = mid;
+    }
+  } else {
+    lo = 1ull;                                           // every (non-empty) key
+  }
+  unsigned char *rec = p.recs + (size_t)t * p.stride;
+  unsigned long long *okeys = reinterpret_cast<unsigned long long *>(rec);
+  float *ozs = reinterpret_cast<float *>(rec + (size_t)p.C * 8);
+  const f32x4 rc = p.rowc[t];
+  int base = 0;
+  unsigned long long below = 0ull;                       // largest key NOT taken
+#pragma unroll
+  for (int j = 0; j < PK; ++j) {
+    if (j < nj) {
+      const unsigned long long key = kreg[j];
+      const bool take = key >= lo && key != 0ull;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+      if (take) {
+        const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const int f = rank_key_index(key);
+        okeys[pos] = (key & 0xFFFFFFFF00000000ull) | (unsigned)(0x7FFFFFFF - (f + p.row_offset));
+        ozs[pos] = __builtin_sqrtf(band_sq(rc, p.colc[f], p.zz12, p.i8 != 0));
+      } else {
+        below = key > below ? key : below;
+      }
+      base += __builtin_popcountll(m);
+    }
+  }
+  for (int jj = base + lane; jj < p.C; jj += 64) { okeys[jj] = 0ull; ozs[jj] = 0.f; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(below, off, 64);
+    below = o > below ? o : below;
+  }
+  if (lane == 0) {
+    // what the shard's other features can reach: the best candidate left behind, else the threshold every
+    // non-candidate stayed below; +inf when the shard cannot tell (overflowed list, degenerate token)
+    float b = __builtin_inff();
+    if (bounded) b = below != 0ull ? f32_from_order_key((unsigned)(below >> 32)) : tau;
+    float *tail = reinterpret_cast<float *>(rec + (size_t)p.C * 12);
+    tail[0] = b;
+    tail[1] = 0.f;
+  }
+}
+
 // three scratch ranges in one launch (candidate counters, flag list, column maxima)
 __global__ void zero3_i32_kernel(int *p0, size_t n0, int *p1, size_t n1, int *p2, size_t n2) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n0; i += (size_t)gridDim.x * 256) p0[i] = 0;
@@ -775,6 +911,8 @@ __global__ void fallback_counts_kernel(const int *n_flagged, int fb_cap, int chu
 
 // index output of one call: 32-bit (msae_encode_topk), 64-bit (msae_encode_topk_i64), never both null
 struct IdxOut { int32_t *i32; int64_t *i64; };
+// msae_shard_candidates: where this shard's records go
+struct ShardOut { unsigned char *recs; int C; int row_offset; };
 
 // ---- stage profiling (bench.py roofline): HIP events recorded on the launch stream ------------------
 constexpr int PROF_MARKS = 7;  // boundaries of: prep | sample gemm | tau topk | main gemm | rescore | fallback
@@ -1289,7 +1427,8 @@ template <int DT>
 int run_fast(const void *x, const float *W_enc, const float *b_enc, const float *b_dec,
              const Prepared &pp, const unsigned char *prepared, int T, int d, int N, int k,
              int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
-             int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
+             int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s,
+             const ShardOut *shard = nullptr) {
   unsigned short *xb = reinterpret_cast<unsigned short *>(ws + pl.off_xb);
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
   float *sample = reinterpret_cast<float *>(ws + pl.off_sample);
@@ -1391,6 +1530,21 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     if (grc) return grc;
   }
   prof_mark(4, s);
+  if (shard) {   // feature-sharded group: this shard's best candidates travel, the owner of the token re-scores
+    PackArgs pa{};
+    pa.cnt = cnt; pa.cand = cand; pa.cap = pl.cap;
+    pa.tau_vals = tauv; pa.tau_ld = pl.r; pa.tau_col = pl.r - 1;
+    pa.rowc = rowc; pa.colc = colc; pa.zz12 = zz12; pa.i8 = pl.i8 ? 1 : 0;
+    pa.C = shard->C; pa.row_offset = shard->row_offset; pa.stride = shard_record_bytes(shard->C);
+    pa.recs = shard->recs;
+    if (pl.cap <= 64 * 32) hipLaunchKernelGGL(pack_candidates_kernel<32>, dim3(T), dim3(64), 0, s, pa);
+    else if (pl.cap <= 64 * 64) hipLaunchKernelGGL(pack_candidates_kernel<64>, dim3(T), dim3(64), 0, s, pa);
+    else return MSAE_ENOTIMPL;
+    prof_mark(5, s);
+    prof_mark(6, s);
+    if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
+    return msae_launch_status();
+  }
   {
     RescoreArgs ra{};
     ra.a32 = a32; ra.W_enc = W_enc; ra.b_enc = b_enc;
@@ -1592,4 +1746,125 @@ extern "C" int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_e
   if (!idx) return MSAE_EINVAL;
   return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
                           zero_feature, vals, IdxOut{nullptr, idx}, status, ws, ws_bytes, stream);
+}
+
+// ---- feature-sharded group: per-shard candidates, owner-side exact re-score ----------------------------
+namespace {
+struct ExtPlan { size_t off_a32, off_flag, off_fbdense, bytes; int fb_cap, fb_chunks, cap, r_max; };
+inline ExtPlan make_plan_ext(int T, int d, int N, int k, int M) {
+  ExtPlan p{};
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += msae_align_up(b, 256); return at; };
+  p.cap = next_pow2(M > 2 ? M : 2);
+  p.r_max = k <= 64 ? 8 * k : 3 * k;
+  if (p.r_max < k + 4) p.r_max = k + 4;
+  if (p.r_max > p.cap) p.r_max = p.cap;
+  p.off_a32 = take((size_t)T * d * 4);
+  p.fb_cap = fallback_capacity(T, N);
+  p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
+  p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);
+  p.off_fbdense = take((size_t)p.fb_cap * N * 4);
+  p.bytes = o;
+  return p;
+}
+
+template <int DT>
+int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int T_valid,
+                    int d, int N, int k, int G, int C, const unsigned char *recs, int set_feature, float set_value,
+                    int zero_feature, float *vals, int64_t *idx, int32_t *status, unsigned char *ws,
+                    const ExtPlan &xp, hipStream_t s) {
+  float *a32 = reinterpret_cast<float *>(ws + xp.off_a32);
+  int *flagged = reinterpret_cast<int *>(ws + xp.off_flag);
+  int *n_flagged = flagged + T;
+  const float z = guard_z();
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(8), dim3(256), 0, s, flagged, (size_t)T + 64 + xp.fb_chunks);
+  hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T_valid, T_valid, d,
+                     (unsigned short *)nullptr, a32);
+  RescoreArgs ra{};
+  ra.a32 = a32; ra.W_enc = W_enc; ra.b_enc = b_enc;
+  ra.cap = xp.cap;
+  ra.T = T_valid; ra.d = d; ra.N = N; ra.k = k; ra.r_max = xp.r_max;
+  ra.zz12 = z * z / 12.f; ra.z2 = z * z; ra.i8 = 0;
+  ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
+  ra.vals = vals; ra.idx = nullptr; ra.idx64 = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
+  ra.fb_cap = T;
+  ra.ext = recs; ra.ext_G = G; ra.ext_C = C; ra.ext_T = T; ra.ext_stride = shard_record_bytes(C); ra.ext_valid = T_valid;
+  const int nrp = next_pow2(xp.r_max + 1);
+  const size_t smem = ((size_t)xp.cap + nrp) * 8 + (size_t)xp.cap * 8 + 64;
+  if (k <= 64) {
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<1, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((select_rescore_kernel<1, true>), dim3(T_valid), dim3(64), smem, s, ra, (const float *)a32, W_enc);
+  } else {
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<4, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((select_rescore_kernel<4, true>), dim3(T_valid), dim3(256), smem, s, ra, (const float *)a32, W_enc);
+  }
+  FusedPlan pl{};                       // the exact fallback reads only these fields
+  pl.off_flag = xp.off_flag; pl.off_fbdense = xp.off_fbdense; pl.fb_cap = xp.fb_cap; pl.fb_chunks = xp.fb_chunks;
+  int rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals,
+                                  IdxOut{nullptr, idx}, status, ws, pl, s);
+  if (rc) return rc;
+  return msae_launch_status();
+}
+}  // namespace
+
+extern "C" size_t msae_shard_record_bytes(int C) { return C > 0 ? (size_t)shard_record_bytes(C) : 0; }
+
+extern "C" int msae_shard_candidates(const void *x, int x_dtype, const float *b_enc, const float *b_dec,
+                                     const void *prepared, int T, int d, int N, int k, int row_offset, int C,
+                                     int set_feature, int zero_feature, void *records, void *ws, size_t ws_bytes,
+                                     void *stream) {
+  if (T < 0 || d <= 0 || N <= 0 || k <= 0 || C <= 0 || row_offset < 0 || !records) return MSAE_EINVAL;
+  if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
+  if (T == 0) return 0;
+  FusedPlan pl = make_plan(T, d, N, k);
+  if (!pl.fast || !prepared || C > pl.cap) return MSAE_ENOTIMPL;   // shapes without the candidate pass: use msae_encode_topk per shard
+  pl.small = false;
+  if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
+  if (!msae_aligned(ws, 256) || !msae_aligned(records, 8)) return MSAE_EALIGN;
+  if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || (b_dec && !msae_aligned(b_dec, 16))) return MSAE_EALIGN;
+  const Prepared pp = make_prepared(N, d);
+  const unsigned char *pb = static_cast<const unsigned char *>(prepared);
+  unsigned char *wsb = static_cast<unsigned char *>(ws);
+  hipStream_t s = (hipStream_t)stream;
+  const ShardOut so{static_cast<unsigned char *>(records), C, row_offset};
+  // the hooks' features are global ids: only the owning shard leaves them out of its candidates
+  const int sf = (set_feature >= row_offset && set_feature < row_offset + N) ? set_feature - row_offset : -1;
+  const int zf = (zero_feature >= row_offset && zero_feature < row_offset + N) ? zero_feature - row_offset : -1;
+  switch (x_dtype) {
+    case MSAE_F32: return run_fast<MSAE_F32>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
+    case MSAE_BF16: return run_fast<MSAE_BF16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
+    default: return run_fast<MSAE_F16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
+  }
+}
+
+extern "C" size_t msae_rescore_candidates_ws_bytes(int T, int d, int N, int k, int G, int C) {
+  if (T <= 0 || d <= 0 || N <= 0 || k <= 0 || G <= 0 || C <= 0) return 0;
+  return make_plan_ext(T, d, N, k, G * C).bytes;
+}
+
+extern "C" int msae_rescore_candidates(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                                       const float *b_dec, int T, int T_valid, int d, int N, int k, int G, int C,
+                                       const void *records, int set_feature, float set_value, int zero_feature,
+                                       float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
+                                       void *stream) {
+  if (T < 0 || T_valid < 0 || T_valid > T || d <= 0 || N <= 0 || k <= 0 || k > N || k > 256 || G <= 0 || C <= 0 ||
+      (long)G * C < k || (long)G * C > 8192 || d % 64 != 0)
+    return MSAE_EINVAL;
+  if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
+  if (set_feature >= N || zero_feature >= N || !records || !vals || !idx) return MSAE_EINVAL;
+  if (T_valid == 0) return 0;
+  const ExtPlan xp = make_plan_ext(T, d, N, k, G * C);
+  if (ws_bytes < xp.bytes || !ws) return MSAE_EWS;
+  if (!msae_aligned(ws, 256) || !msae_aligned(records, 8) || !msae_aligned(W_enc, 16)) return MSAE_EALIGN;
+  if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || (b_dec && !msae_aligned(b_dec, 16))) return MSAE_EALIGN;
+  unsigned char *wsb = static_cast<unsigned char *>(ws);
+  const unsigned char *rb = static_cast<const unsigned char *>(records);
+  hipStream_t s = (hipStream_t)stream;
+  switch (x_dtype) {
+    case MSAE_F32: return run_rescore_ext<MSAE_F32>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
+    case MSAE_BF16: return run_rescore_ext<MSAE_BF16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
+    default: return run_rescore_ext<MSAE_F16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
+  }
 }

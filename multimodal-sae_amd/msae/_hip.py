@@ -38,6 +38,13 @@ PROTOTYPES = {
     "msae_encode_topk_i64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "msae_shard_record_bytes": (c_size_t, [c_int]),
+    "msae_shard_candidates": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "msae_rescore_candidates_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "msae_rescore_candidates": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "msae_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "msae_decode_i64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -178,6 +178,57 @@ def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_f
             x.new_empty(x.shape[:-1], dtype=torch.int32))
 
 
+def shard_candidates(x: Tensor, b_enc_shard: Optional[Tensor], b_dec: Optional[Tensor], prepared_shard: Tensor,
+                     N_shard: int, k: int, row_offset: int, C: int, set_feature: int = -1,
+                     zero_feature: int = -1) -> Tensor:
+    """Feature-sharded group, sender side (msae_shard_candidates): -> records uint8 [T, record_bytes(C)]."""
+    dev = _hip.require_device(x, b_enc_shard, b_dec, prepared_shard)
+    lib = _hip.load()
+    xa, be, bd = _act(x), _f32c(b_enc_shard), _f32c(b_dec)
+    d = xa.shape[-1]
+    T = xa.numel() // d
+    stride = lib.msae_shard_record_bytes(C)
+    recs = torch.empty(T, stride, dtype=torch.uint8, device=dev)
+    if T == 0:
+        return recs
+    ws = _workspace(dev, lib.msae_encode_topk_ws_bytes(T, d, N_shard, k))
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_shard_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(be), _hip.ptr(bd),
+                                             _hip.ptr(prepared_shard), T, d, N_shard, k, row_offset, C, set_feature,
+                                             zero_feature, _hip.ptr(recs), _hip.ptr(ws), ws.numel(),
+                                             _hip.stream_of(xa)), "msae_shard_candidates")
+    return recs
+
+
+def rescore_candidates(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor], k: int,
+                       records: Tensor, C: int, T_valid: Optional[int] = None, set_feature: int = -1,
+                       set_value: float = 0.0, zero_feature: int = -1) -> Tuple[Tensor, Tensor, Tensor]:
+    """Feature-sharded group, owner side (msae_rescore_candidates): records uint8 [G, T, record_bytes(C)] of
+    this rank's T tokens -> (top_acts f32 [T, k], top_indices int64 [T, k] global ids, status int32 [T])."""
+    dev = _hip.require_device(x, W_enc, b_enc, b_dec, records)
+    lib = _hip.load()
+    xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
+    N, d = W.shape
+    T = xa.numel() // d
+    G = records.shape[0]
+    assert records.dtype == torch.uint8 and records.is_contiguous() and records.shape[1] == T, records.shape
+    assert records.shape[2] == lib.msae_shard_record_bytes(C)
+    T_valid = T if T_valid is None else T_valid
+    vals = torch.zeros(T, k, dtype=torch.float32, device=dev) if T_valid < T else torch.empty(T, k, dtype=torch.float32, device=dev)
+    idx = torch.zeros(T, k, dtype=torch.int64, device=dev) if T_valid < T else torch.empty(T, k, dtype=torch.int64, device=dev)
+    status = torch.zeros(T, dtype=torch.int32, device=dev) if T_valid < T else torch.empty(T, dtype=torch.int32, device=dev)
+    if T_valid == 0:
+        return vals, idx, status
+    ws = _workspace(dev, lib.msae_rescore_candidates_ws_bytes(T, d, N, k, G, C))
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_rescore_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W), _hip.ptr(be),
+                                               _hip.ptr(bd), T, T_valid, d, N, k, G, C, _hip.ptr(records), set_feature,
+                                               set_value, zero_feature, _hip.ptr(vals), _hip.ptr(idx),
+                                               _hip.ptr(status), _hip.ptr(ws), ws.numel(), _hip.stream_of(xa)),
+                   "msae_rescore_candidates")
+    return vals, idx, status
+
+
 def encode_topk_resolved(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
                          prepared: Optional[Tensor], k: int, set_feature: int = -1,
                          set_value: float = 0.0, zero_feature: int = -1):

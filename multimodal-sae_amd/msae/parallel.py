@@ -21,6 +21,17 @@ Rank g of G owns rows [g*N/G, (g+1)*N/G) of W_enc / b_enc.  Every rank sees the 
      tokens [g*T/G, (g+1)*T/G) and an all-gather returns the full [T, d] to every rank (the hook
      that replaces the layer output needs it everywhere; the caching path skips it).
 
+mode="candidates" (what bench.py times when it can): the ranks exchange CANDIDATES instead of finished local
+top-k_loc lists, so the HBM-bound exact re-score is done once per token by the token's owner instead of ~k_loc + band
+rows per token on EVERY rank (measured per rank at G = 8: 23 rows per token against 45 / 8):
+
+  1. msae_shard_candidates: candidate pass over the shard, per token the C best by upper value u (+ z sigma each,
+     + tau = the largest u the rest of the shard can reach) -- the per-shard TopK, by upper bound
+  2. ONE all-to-all of the records (12 C + 8 bytes per token and shard): rank r receives its T/G tokens' records
+  3. msae_rescore_candidates on the owner: union of the G lists, exact re-score against the replicated f32 W_enc
+     (2 GiB of 288 GB), the single-GPU verification rule with tau = max over the shards -> bit-identical top-k
+  4. one small all-gather hands every rank all tokens' (top_acts, top_indices, status); decode as above.
+
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm).
 """
 from __future__ import annotations
@@ -58,6 +69,18 @@ def default_k_loc(k: int, world: int) -> int:
     return min(k, mean + int(-(-5 * (k / world) ** 0.5 // 1)))
 
 
+def default_candidates(k: int, world: int) -> int:
+    """Candidates a shard sends per token: the ~1.4 k features inside the error band of the k-th value fall
+    Binomial(., 1/G) into a shard; mean + 6 sigma + 4, as a power of two (a shard that holds more only raises its
+    tau: the token is then recomputed exactly)."""
+    m = 1.4 * k / max(world, 1)
+    c = int(m + 6 * m ** 0.5 + 4)
+    p = 16
+    while p < c:
+        p *= 2
+    return p
+
+
 def token_slice(T: int, rank: int, world: int):
     per = (T + world - 1) // world
     return min(rank * per, T), min((rank + 1) * per, T), per
@@ -71,7 +94,9 @@ class ShardedSae:
                  rank: int = 0, world: int = 1, group=None,
                  encode_fn: Optional[Callable] = None, decode_fn: Optional[Callable] = None,
                  force_collectives: bool = False, k_loc: Optional[int] = None,
-                 row_offset: Optional[int] = None):
+                 row_offset: Optional[int] = None, mode: str = "topk", W_enc_full: Optional[Tensor] = None,
+                 b_enc_full: Optional[Tensor] = None, n_cand: Optional[int] = None,
+                 cand_fn: Optional[Callable] = None, rescore_fn: Optional[Callable] = None):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
@@ -96,6 +121,22 @@ class ShardedSae:
             encode_fn = lambda x, kk: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk)
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
         self._encode, self._decode = encode_fn, decode_fn
+        # mode "candidates": per-shard candidate lists travel, the owner of a token re-scores (module docstring)
+        assert mode in ("topk", "candidates")
+        self.mode = mode if self.collective else "topk"
+        if self.mode == "candidates":
+            self.n_cand = n_cand or default_candidates(k, world)
+            self.W_enc_full, self.b_enc_full = W_enc_full, b_enc_full
+            if cand_fn is None:
+                from . import ops
+
+                assert W_enc_full is not None, "mode='candidates' re-scores against the replicated W_enc"
+                prep_c = ops.prepare_encoder(W_enc_shard)
+                cand_fn = lambda x: ops.shard_candidates(x, self.b_enc, self.b_dec, prep_c, self.n_loc, self.k,
+                                                         self.row_offset, self.n_cand)
+                rescore_fn = lambda x, recs, tv: ops.rescore_candidates(x, self.W_enc_full, self.b_enc_full, self.b_dec,
+                                                                        self.k, recs, self.n_cand, tv)
+            self._cand, self._rescore = cand_fn, rescore_fn
 
     def _pack(self, vals: Tensor, idx: Tensor) -> Tensor:
         """[T, kk] (f32, LOCAL i64) -> int32 [2, T, kk] = (value bits, GLOBAL feature id): what travels."""
@@ -129,10 +170,32 @@ class ShardedSae:
         dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
         return self._merge_gathered(flat, T, kk)
 
+    def _encode_candidates(self, x: Tensor):
+        T, G = x.shape[0], self.world
+        lo, hi, per = token_slice(T, self.rank, G)
+        recs = self._cand(x)                                            # [T, stride] uint8
+        if per * G != T:
+            recs = torch.cat((recs, recs.new_zeros(per * G - T, recs.shape[1])))
+        send = recs.view(G, per, recs.shape[1])
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)            # recv[g] = shard g's records of MY tokens
+        xl = x[lo:hi]
+        if hi - lo != per:
+            xl = torch.cat((xl, xl.new_zeros(per - (hi - lo), x.shape[1])))
+        vals, idx, status = self._rescore(xl.contiguous(), recv, hi - lo)
+        # every rank gets all tokens' results: one all-gather of (value bits | feature id | status) as int32
+        pack = torch.cat((vals.contiguous().view(torch.int32), idx.to(torch.int32), status.view(-1, 1)), 1).contiguous()
+        full = torch.empty((G * per, pack.shape[1]), dtype=torch.int32, device=pack.device)
+        dist.all_gather_into_tensor(full, pack, group=self.group)
+        k = self.k
+        return (full[:T, :k].contiguous().view(torch.float32), full[:T, k:2 * k].to(torch.int64), full[:T, 2 * k].contiguous())
+
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
         if not self.collective:
             return self._encode(x, self.k)
+        if self.mode == "candidates":
+            return self._encode_candidates(x)
         vals, idx, status = self._encode(x, self.k_loc)
         mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
@@ -163,6 +226,21 @@ class ShardedSae:
             mv2, mi2, _ = e0._merge_gathered(torch.cat(packs, 0), int(redo.numel()), e0.k)
             mv[redo], mi[redo] = mv2, mi2
         return mv, mi, int(redo.numel())
+
+    @staticmethod
+    def encode_emulated_candidates(engines, x: Tensor):
+        """mode="candidates" of a G-rank group executed in ONE process: every shard's records for all tokens, the
+        owner-side re-score once per token slice, exactly as the ranks would see them after the all-to-all."""
+        G, T = len(engines), x.shape[0]
+        recs = [e._cand(x) for e in engines]                            # G x [T, stride]
+        outs = []
+        for e in engines:
+            lo, hi, per = token_slice(T, e.rank, G)
+            if hi <= lo:
+                continue
+            recv = torch.stack([r[lo:hi] for r in recs]).contiguous()   # [G, hi - lo, stride]
+            outs.append(e._rescore(x[lo:hi].contiguous(), recv, hi - lo))
+        return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
 
     def decode(self, vals: Tensor, idx: Tensor, gather: bool = True, async_gather: bool = False) -> Tensor:
         """Token-sharded decode.  With `async_gather` the all-gather of the reconstruction is issued

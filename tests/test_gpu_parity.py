@@ -536,6 +536,9 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
     assert "error" not in res and "feature-sharded" in res["config"]["parallelism"]
     assert res["sharded_bit_identical_to_single_gpu_on_256_tokens"] is True
+    modes = res["shard_modes"]          # both exchange schemes ran on RCCL (all-gather; all-to-all) and agree
+    assert modes["per_shard_topk"]["bit_identical_256"] is True
+    assert modes["candidate_exchange"]["bit_identical_256"] is True
     assert "error" not in res["replicas"] and res["replicas"]["value"] > 0 and res["replicas"]["scaling"] == "weak"
 
 
@@ -571,6 +574,38 @@ def test_feature_sharded_group_emulated_on_one_gpu(dev, G):
         lo, hi, _ = __import__("msae.parallel", fromlist=["token_slice"]).token_slice(T, r, G)
         parts.append(ops.decode(mi[lo:hi].contiguous(), mv[lo:hi].contiguous(), W_dec, b_dec))
     assert torch.equal(torch.cat(parts), full)
+
+
+@pytest.mark.parametrize("G,bump", [(2, 0.0), (4, 0.0), (8, 0.0), (8, 1.5)])
+def test_feature_sharded_candidate_exchange_emulated_on_one_gpu(dev, coarse, G, bump):
+    """mode="candidates" of the feature-sharded group (msae_shard_candidates -> records -> msae_rescore_candidates),
+    the G ranks run one after the other on ONE GPU with the records sliced as the all-to-all would deliver them.
+    Bit-identical to the single-GPU encode on every token, including a token count that does not divide by G;
+    the bias bump crowds shard 0's part of the global top-k beyond the C records it sends (those tokens must come
+    back through the exact recompute, not wrong)."""
+    from msae import ops
+    from msae.parallel import ShardedSae
+
+    d, N, T, k = 1024, 65536, 2048 + 3, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 51)
+    if bump:
+        b_enc[: N // G // 8] += bump
+    W_dec = torch.zeros(8, d, device=dev)       # not used by the encode
+    x = _rand_x(dev, T, d, 53)
+    n_loc = N // G
+    engines = [ShardedSae(W_enc[r * n_loc:(r + 1) * n_loc].contiguous(), b_enc[r * n_loc:(r + 1) * n_loc].contiguous(),
+                          W_dec, b_dec, k, rank=r, world=G, mode="candidates", W_enc_full=W_enc, b_enc_full=b_enc,
+                          n_cand=16 if bump else None) for r in range(G)]
+    mv, mi, st = ShardedSae.encode_emulated_candidates(engines, x)
+    ev, ei, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, ops.prepare_encoder(W_enc), k)
+    n_fb = int((st == 1).sum())
+    print(f"\nG={G} bump={bump} C={engines[0].n_cand}: exact recompute on {n_fb} of {T} tokens")
+    assert int((st >= 2).sum()) == 0
+    assert torch.equal(mi, ei) and torch.equal(mv, ev)
+    if bump:
+        assert n_fb > 0, "the crowded shard should have overflowed its records for some tokens"
+    else:
+        assert n_fb <= 0.02 * T
 
 
 @pytest.mark.parametrize("T,G,kl,k", [(100, 8, 16, 32), (33, 2, 32, 32), (17, 4, 24, 32), (5, 8, 64, 256)])

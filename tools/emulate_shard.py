@@ -31,3 +31,40 @@ for G in (8, 4, 2, 1):
     torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 10 * 1e3
     print(f"G={G} k_loc={kl}: encode {t:.3f} ms  stages(prep,sample,tau,gemm,rescore,fallback)={np.round(st,3).tolist()}  merge {tm:.3f}  decode(T/G) {td:.3f}  verified {(s==0).float().mean().item():.4f}")
     del W_enc, W_dec, prep
+
+# ---- mode="candidates": per-rank cost = shard_candidates over all T tokens + rescore_candidates over T/G tokens.
+# The other shards' records are emulated by this shard's own records with the feature ids shifted into their ranges
+# (same list sizes and error bands; the re-score then reads rows of all shards, as on the real group).
+from msae.parallel import default_candidates
+W_full, b_full, W_dec, b_dec, x = bench.make_inputs(dev, T, d, N, rows=(0, N), dec_rows=(0, 8))
+for G in (8, 4, 2):
+    C = default_candidates(k, G)
+    nl = N // G
+    preps = ops.prepare_encoder(W_full[:nl])
+    per = T // G
+    def sender():
+        return ops.shard_candidates(x, b_full[:nl], b_dec, preps, nl, k, 0, C)
+    for _ in range(3): recs = sender()
+    torch.cuda.synchronize(); lib.msae_profile_begin(10); t0 = time.perf_counter()
+    for _ in range(10): recs = sender()
+    torch.cuda.synchronize(); ts = (time.perf_counter() - t0) / 10 * 1e3
+    buf = (ctypes.c_float * 60)(); n = ctypes.c_int(0); lib.msae_profile_end(buf, ctypes.byref(n))
+    st = np.array(buf[:]).reshape(10, 6).mean(0)
+    # real records of every shard for rank 0's tokens (each shard's candidate pass run here, untimed)
+    allr = []
+    for g in range(G):
+        pg = ops.prepare_encoder(W_full[g * nl:(g + 1) * nl])
+        allr.append(ops.shard_candidates(x[:per].contiguous(), b_full[g * nl:(g + 1) * nl], b_dec, pg, nl, k, g * nl, C))
+        del pg
+    recv = torch.stack(allr).contiguous()
+    xl = x[:per].contiguous()
+    for _ in range(3): v, i, s = ops.rescore_candidates(xl, W_full, b_full, b_dec, k, recv, C)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): v, i, s = ops.rescore_candidates(xl, W_full, b_full, b_dec, k, recv, C)
+    torch.cuda.synchronize(); tr = (time.perf_counter() - t0) / 10 * 1e3
+    ev, ei, _ = ops.encode_topk(xl, W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
+    same = bool(torch.equal(ei, i) and torch.equal(ev, v))
+    print(f"G={G} candidates C={C}: shard pass {ts:.3f} ms stages(prep,sample,tau,gemm,pack)={np.round(st[:5],3).tolist()}  "
+          f"owner re-score of T/G tokens {tr:.3f} ms  record {recs.shape[1]} B/token/shard  exact-recompute {(s==1).float().mean().item():.4f}  "
+          f"== single GPU: {same}")
+    del preps
