@@ -509,9 +509,9 @@ constexpr int G_BM = GemmBf16::BM;
 #ifndef MSAE_RESCORE_U
 #define MSAE_RESCORE_U 16
 #endif
-#ifndef MSAE_RESCORE_LPR      // lanes that share a row of W_enc in the re-scoring stream: 1, or 4 (64-B pieces per
-#define MSAE_RESCORE_LPR 1    // row and instruction, 16 rows per pass: measured 1.61 ms against 1.17 -- not the default)
-#endif
+#ifndef MSAE_RESCORE_LPR      // lanes that share a row of W_enc in the FIRST round's re-scoring stream: 1, or 4 (64-B
+#define MSAE_RESCORE_LPR 1    // pieces per row and instruction, 16 rows per pass: measured 1.61 ms against 1.17 -- not
+#endif                        // the default).  Follow-up rounds of a few rows always use 4.
 static_assert(MSAE_RESCORE_U * 4 == 64, "one re-scoring batch must be the 64 floats fast_shape_ok() guarantees");
 struct RescoreArgs {
   const float *a32; const float *W_enc, *b_enc;
@@ -526,6 +526,7 @@ struct RescoreArgs {
   // EXT (feature-sharded group, msae_rescore_candidates): the candidate lists come as the shards' records
   // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
   const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
+  int lpr;   // lanes per row in the first round (1, 2, 4): small batches need the extra bytes in flight (rescore_shape)
 };
 
 // One shard's record of a token (msae_shard_candidates): C keys (order key of the upper value u | 0x7FFFFFFF -
@@ -732,6 +733,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
               acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
               if constexpr (LPR == 4)   // quad_perm:[3,0,1,2] -- lane i takes lane i - 1's value, lane 0 lane 3's
                 acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xF, 0xF, false));
+              if constexpr (LPR == 2)   // quad_perm:[1,0,3,2] -- the two lanes of a pair swap
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));
             }
           }
         };
@@ -753,12 +756,16 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         }
       }
     };
-    if constexpr (MSAE_RESCORE_LPR == 4) {
-      if (p.d % (4 * MSAE_RESCORE_U * 4) == 0) run_pass(std::integral_constant<int, 4>());
-      else run_pass(std::integral_constant<int, 1>());
-    } else {
-      run_pass(std::integral_constant<int, 1>());
-    }
+    // A follow-up round re-scores a handful of rows: with a lane per row each of them is a latency chain (16 KB at
+    // 512 B in flight = 32 round trips, ~60 us whatever the load); four lanes per row carry 2 KB in flight each.
+    // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
+    // p.lpr lanes per row and as many waves per token.
+    const bool few = rounds > 1 && target - done <= NT / 4;
+    int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
+    while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
+    if (lpr == 4) run_pass(std::integral_constant<int, 4>());
+    else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
+    else run_pass(std::integral_constant<int, 1>());
     done = target;
     viol = viol || (__syncthreads_or(my_viol) != 0);
     wave_sort_desc_u64<NT>(res, nrp, lane);
@@ -877,6 +884,36 @@ __global__ __launch_bounds__(64) void pack_candidates_kernel(PackArgs p) {
     tail[0] = b;
     tail[1] = 0.f;
   }
+}
+
+// waves per token and lanes per row of the first round: k > 64 -> 4 waves (longer lists); batches that cannot fill
+// 256 CUs x 8 waves with a lane per row get 2 or 4 lanes per row (and waves per token) instead
+inline void rescore_shape(int T, int k, int &nw, int &lpr) {
+  nw = k <= 64 ? 1 : 4;
+  lpr = 1;
+  if (k <= 64) {
+    const long lanes = (long)T * (k + 13);
+    if (lanes * 4 <= 131072) lpr = 4;
+    else if (lanes * 2 <= 131072) lpr = 2;
+    nw = lpr;
+  }
+}
+template <bool EXT>
+inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, const float *a32, const float *W_enc,
+                                 hipStream_t s) {
+  int nw;
+  rescore_shape(T, k, nw, ra.lpr);
+#define MSAE_RS_LAUNCH(NWV)                                                                                          \
+  do {                                                                                                               \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT>,                                  \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                        \
+    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);         \
+  } while (0)
+  if (nw == 1) MSAE_RS_LAUNCH(1);
+  else if (nw == 2) MSAE_RS_LAUNCH(2);
+  else MSAE_RS_LAUNCH(4);
+#undef MSAE_RS_LAUNCH
+  return 0;
 }
 
 // three scratch ranges in one launch (candidate counters, flag list, column maxima)
@@ -1557,15 +1594,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.fb_cap = T;
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
-    if (k <= 64) {
-      MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<1>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(select_rescore_kernel<1>, dim3(T), dim3(64), smem, s, ra, (const float *)a32, W_enc);
-    } else {
-      MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<4>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(select_rescore_kernel<4>, dim3(T), dim3(256), smem, s, ra, (const float *)a32, W_enc);
-    }
+    const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    if (lrc) return lrc;
   }
   prof_mark(5, s);
 #ifndef MSAE_ABL_NOFALLBACK   // tuning builds only: keep the GEMM ablations' stage timings clean
@@ -1791,15 +1821,8 @@ int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const
   ra.ext = recs; ra.ext_G = G; ra.ext_C = C; ra.ext_T = T; ra.ext_stride = shard_record_bytes(C); ra.ext_valid = T_valid;
   const int nrp = next_pow2(xp.r_max + 1);
   const size_t smem = ((size_t)xp.cap + nrp) * 8 + (size_t)xp.cap * 8 + 64;
-  if (k <= 64) {
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<1, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((select_rescore_kernel<1, true>), dim3(T_valid), dim3(64), smem, s, ra, (const float *)a32, W_enc);
-  } else {
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<4, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((select_rescore_kernel<4, true>), dim3(T_valid), dim3(256), smem, s, ra, (const float *)a32, W_enc);
-  }
+  const int lrc = launch_select_rescore<true>(ra, T_valid, k, smem, (const float *)a32, W_enc, s);
+  if (lrc) return lrc;
   FusedPlan pl{};                       // the exact fallback reads only these fields
   pl.off_flag = xp.off_flag; pl.off_fbdense = xp.off_fbdense; pl.fb_cap = xp.fb_cap; pl.fb_chunks = xp.fb_chunks;
   int rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals,

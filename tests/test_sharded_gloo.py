@@ -93,3 +93,104 @@ def test_merge_topk_is_canonical_with_ties():
     assert i.tolist() == [[5, 7, 3, 9, 0, 1]] and v.tolist() == [[2.0, 2.0, 1.0, 1.0, -0.0, 0.0]]
     v, i = merge_topk(vals, idx, 8)
     assert i.tolist()[0][-2:] == [4, 2]
+
+
+# ---- mode="candidates": per-shard candidate records, all-to-all, owner-side re-score ------------------------------
+def _order_key(v: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    b = np.where(b == 0x80000000, 0, b)
+    return np.where(b & 0x80000000, (~b) & 0xFFFFFFFF, b | 0x80000000)
+
+
+def _cand_worker(rank, world, port, T, d, N, k, C, out_dir, cluster):
+    for p in (REPO, REPO / "tests", REPO / "multimodal-sae_amd"):
+        sys.path.insert(0, str(p))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import synth
+    from oracle import oracle
+    from msae.parallel import ShardedSae
+
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0
+    x = synth.activations(T, d, seed=32)
+    n_loc = N // world
+    lo, hi = rank * n_loc, (rank + 1) * n_loc
+    stride = 12 * C + 8
+    stats = {"fallback": 0}
+
+    def cand_fn(xt):
+        """records of this shard as msae_shard_candidates lays them out (exact values as upper values, z sigma 0)"""
+        pre = oracle.pre_acts(xt.numpy(), W_enc[lo:hi], b_enc[lo:hi], b_dec)
+        rec = np.zeros((len(pre), stride), dtype=np.uint8)
+        for t, row in enumerate(pre):
+            key = (_order_key(row) << np.uint64(32)) | (np.uint64(0x7FFFFFFF) - (np.arange(lo, hi, dtype=np.uint64)))
+            order = np.argsort(key)[::-1]
+            rec[t, : 8 * C] = key[order[:C]].view(np.uint8)
+            tail = np.array([row[order[C]] if len(order) > C else 0.0, 0.0], dtype=np.float32)
+            rec[t, 12 * C:] = tail.view(np.uint8)
+        return torch.from_numpy(rec)
+
+    def rescore_fn(xl, recv, t_valid):
+        G, per, _ = recv.shape
+        r = recv.numpy()
+        vals, idx = np.zeros((per, k), np.float32), np.zeros((per, k), np.int64)
+        for t in range(t_valid):
+            keys = np.concatenate([r[g, t, : 8 * C].view(np.uint64) for g in range(G)])
+            tau = max(float(r[g, t, 12 * C: 12 * C + 4].view(np.float32)[0]) for g in range(G))
+            feats = (0x7FFFFFFF - (keys[keys != 0] & np.uint64(0xFFFFFFFF)).astype(np.int64))
+            pre = oracle.pre_acts(xl[t:t + 1].numpy(), W_enc, b_enc, b_dec)[0]
+            ckey = (_order_key(pre[feats]) << np.uint64(32)) | (np.uint64(0x7FFFFFFF) - feats.astype(np.uint64))
+            top = feats[np.argsort(ckey)[::-1][:k]]
+            if len(top) < k or not pre[top[-1]] > tau:       # the lists cannot prove the top-k: exact recompute
+                stats["fallback"] += 1
+                v, i = oracle.encode_topk(xl[t:t + 1].numpy(), W_enc, b_enc, b_dec, k)
+                vals[t], idx[t] = v[0], i[0]
+            else:
+                vals[t], idx[t] = pre[top], top
+        return torch.from_numpy(vals), torch.from_numpy(idx), torch.zeros(per, dtype=torch.int32)
+
+    def decode_fn(idx, vals):
+        return torch.from_numpy(oracle.decode(idx.numpy(), vals.numpy(), W_dec, b_dec))
+
+    eng = ShardedSae(torch.from_numpy(W_enc[lo:hi]), torch.from_numpy(b_enc[lo:hi]), torch.from_numpy(W_dec),
+                     torch.from_numpy(b_dec), k, rank=rank, world=world, group=dist.group.WORLD,
+                     encode_fn=lambda *a: None, decode_fn=decode_fn, mode="candidates", n_cand=C,
+                     cand_fn=cand_fn, rescore_fn=rescore_fn)
+    out = eng.forward(torch.from_numpy(x))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(), i=out["top_indices"].numpy(),
+             r=out["sae_out"].numpy(), fallback=stats["fallback"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,k,C,cluster", [(13, 8, 8, False), (8, 8, 16, False), (13, 16, 8, True)])
+def test_candidate_exchange_equals_single_shard(tmp_path, T, k, C, cluster):
+    """ShardedSae(mode="candidates") over gloo, world 2: record layout, all-to-all slicing (13 tokens do not divide
+    by 2: the padded token), owner-side results and their all-gather, token-sharded decode.  `cluster` puts more of
+    the global top-k into shard 0 than its C records hold, so the owner must take the exact recompute."""
+    import synth
+    from oracle import oracle
+
+    d, N, world = 64, 1024, 2
+    port = _free_port()
+    mp.spawn(_cand_worker, args=(world, port, T, d, N, k, C, str(tmp_path), cluster), nprocs=world, join=True)
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0
+    x = synth.activations(T, d, seed=32)
+    ref_v, ref_i = oracle.encode_topk(x, W_enc, b_enc, b_dec, k)
+    ref_r = oracle.decode(ref_i, ref_v, W_dec, b_dec)
+    fb = 0
+    for rank in range(world):
+        g = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(g["i"], ref_i), f"rank {rank}: indices differ"
+        assert np.array_equal(g["v"], ref_v)
+        assert np.array_equal(g["r"], ref_r)
+        fb += int(g["fallback"])
+    if cluster:
+        assert fb > 0
