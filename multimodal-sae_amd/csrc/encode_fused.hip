@@ -1001,7 +1001,7 @@ struct FusedPlan {
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_dense, bytes;
 };
 
-inline FusedPlan make_plan(int T, int d, int N, int k) {
+inline FusedPlan make_plan(int T, int d, int N, int k, int shard_C = 0) {
   FusedPlan p{};
   p.fast = fast_shape_ok(N, d) && T > EXACT_T_MAX && k <= 256 && k >= 1;
   size_t o = 0;
@@ -1012,6 +1012,12 @@ inline FusedPlan make_plan(int T, int d, int N, int k) {
     // tau = r-th largest of the 1/32 sample: ~32*r survivors, Gamma(r)-distributed.  r = 16 keeps
     // P(fewer than ~2k survivors) and P(overflow) below 1e-9 per token (r = 8 flagged 3 of 8192)
     p.r = k / 8 > 16 ? k / 8 : 16;         // k = 256: r = 32 -> ~1024 survivors, capacity 4096
+    if (k < 32) p.r = k / 2 > 8 ? k / 2 : 8;   // small k (a shard's k_loc): ~k + band rows are needed, 256+ survive
+    // A shard of a feature-sharded group only has to deliver its C best: 256+ survivors are plenty (its share of
+    // the needed set is below C / 1.5 by construction of C, P(Gamma(8) x 32 below that) ~ 1e-5), and the default
+    // would put 512 survivors per token into 1/G of the columns -- at G = 8 that is 2048 per output tile, the
+    // size of the epilogue's LDS queue.
+    if (shard_C > 0) { const int rs = shard_C / 8 > 8 ? shard_C / 8 : 8; if (rs < p.r) p.r = rs; }
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
     p.small = p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
@@ -1841,7 +1847,7 @@ extern "C" int msae_shard_candidates(const void *x, int x_dtype, const float *b_
   if (T < 0 || d <= 0 || N <= 0 || k <= 0 || C <= 0 || row_offset < 0 || !records) return MSAE_EINVAL;
   if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
   if (T == 0) return 0;
-  FusedPlan pl = make_plan(T, d, N, k);
+  FusedPlan pl = make_plan(T, d, N, k, C);
   if (!pl.fast || !prepared || C > pl.cap) return MSAE_ENOTIMPL;   // shapes without the candidate pass: use msae_encode_topk per shard
   pl.small = false;
   if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
