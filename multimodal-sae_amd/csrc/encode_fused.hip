@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict
   for (int t = t0; t < t1; ++t) {
     f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
     if (b_dec) v = v - bd;
-    *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
+    if (a32) *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
     m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
     m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
   }
@@ -338,7 +338,10 @@ __global__ __launch_bounds__(1024) void pick_outliers_kernel(const unsigned *__r
 
 // one workgroup per token row (rows >= T of the padded tile are zero): per-token scales, int8 rows and
 // the row constants of the error band, rowc[t] = (sx, m, P = z^2 |a_t|^2 / 12, 0)
-__global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ a32, int T, int d,
+// SRC = MSAE_F32 with x == a32 and b_dec == nullptr reads the prepared f32 activations; a shard of a feature-sharded
+// group (nobody re-scores there) reads x - b_dec straight from the input instead and never writes a32.
+template <int SRC>
+__global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x, const float *__restrict__ b_dec, int T, int d,
                                                       const int *__restrict__ odims,
                                                       const unsigned char *__restrict__ is_out,
                                                       signed char *__restrict__ xq,
@@ -352,10 +355,14 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
     if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
   }
-  const float *row = a32 + (size_t)t * d;
+  auto load4 = [&](int c) {
+    f32x4 v = load_x4<SRC>(x, (size_t)t * d + c);
+    if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+    return v;
+  };
   float m_in = 0.f, m_out = 0.f, ss = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+    const f32x4 v = load4(c);
     const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
     i32x4 packed;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q);
+      const f32x4 v = load4(c + 4 * q);
       const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q);
       unsigned w = 0;
 #pragma unroll
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const float *__restrict__ 
   }
   if (threadIdx.x < MAX_OUT) {
     const int dim = odims[threadIdx.x];
-    int iv = dim >= 0 ? (int)rintf(row[dim] * inv_o) : 0;
+    int iv = dim >= 0 ? (int)rintf((load_x1<SRC>(x, (size_t)t * d + dim) - (b_dec ? b_dec[dim] : 0.f)) * inv_o) : 0;
     iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
     xqo[(size_t)t * MAX_OUT + threadIdx.x] = (signed char)iv;
   }
@@ -1506,10 +1513,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
-    hipLaunchKernelGGL(prep_colmax_kernel<DT>, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
-                       colmax);
+    hipLaunchKernelGGL(prep_colmax_kernel<DT>, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
+                       shard ? (float *)nullptr : a32, colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
-    hipLaunchKernelGGL(quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, a32, T, d, odims, is_out, xq, xqo, rowc, zz12);
+    if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
+      hipLaunchKernelGGL(quant_x_kernel<DT>, dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12);
+    else
+      hipLaunchKernelGGL(quant_x_kernel<MSAE_F32>, dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr, T, d,
+                         odims, is_out, xq, xqo, rowc, zz12);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
                        reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp);
     colc = cc_main; colc_s = cc_samp;
