@@ -125,6 +125,31 @@ def test_small_T_path_equals_exact(dev, T):
     assert n_fallback <= 0.05 * 64 * T
 
 
+@pytest.mark.parametrize("kind", hostile.KINDS)
+def test_small_T_path_on_heterogeneous_weights(dev, kind):
+    """The S = 1 path on every hostile weight family (N = 16384: each of the 2048 stream workgroups sees 8 rows and
+    hands on its best 3 + a bound): bit-identical to the exact path for 96 single tokens and 32 groups of 3, every
+    token resolved; reports how many took the exact recompute."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W, b, bd = hostile.weights(kind, N, d, dev, seed=13)
+    prepared = ops.prepare_encoder(W)
+    xs = hostile.activations(192, d, dev, seed=14)
+    n_fb = n_tok = 0
+    for T, reps in ((1, 96), (3, 32)):
+        for c in range(reps):
+            x = xs[c * T:(c + 1) * T]
+            ev, ei = ops.topk(ops.pre_acts(x, W, b, bd), k)
+            v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)
+            assert int((status >= 2).sum()) == 0
+            assert torch.equal(i, ei) and torch.equal(v, ev), (kind, T, c)
+            n_fb += int((status == 1).sum())
+            n_tok += T
+    print(f"\n{kind}: exact recompute on {n_fb} of {n_tok} small-batch tokens")
+    assert n_fb <= 0.25 * n_tok, "the small-batch path should verify most tokens on its own"
+
+
 def test_width_262144_against_oracle(dev):
     """BASELINE configs[4] width: fused == exact on every token, exact == CPU oracle on 16 tokens."""
     from msae import ops
