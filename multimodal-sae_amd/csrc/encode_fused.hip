@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
 // per-token quantisation with the outliers in their own 128-wide k-tile at scale m[t]*sx[t].
 // int8 pass: prep_x and colmax in one sweep -- a thread owns four columns (b_dec in registers) and walks its
 // rows: a32 = x - b_dec is written once and never read back for the maxima.
-template <int DT>
+template <int DT, bool WRITE_A32>
 __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
                                                           int T, int d, float *__restrict__ a32,
                                                           unsigned *__restrict__ colmax_bits) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict
   for (int t = t0; t < t1; ++t) {
     f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
     if (b_dec) v = v - bd;
-    if (a32) *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
+    if constexpr (WRITE_A32) *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
     m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
     m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
   }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void pick_outliers_kernel(const unsigned *__r
 // the row constants of the error band, rowc[t] = (sx, m, P = z^2 |a_t|^2 / 12, 0)
 // SRC = MSAE_F32 with x == a32 and b_dec == nullptr reads the prepared f32 activations; a shard of a feature-sharded
 // group (nobody re-scores there) reads x - b_dec straight from the input instead and never writes a32.
-template <int SRC>
+template <int SRC, bool FROM_X>
 __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x, const float *__restrict__ b_dec, int T, int d,
                                                       const int *__restrict__ odims,
                                                       const unsigned char *__restrict__ is_out,
@@ -355,10 +355,15 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
   }
+  const float *__restrict__ row32 = static_cast<const float *>(x) + (size_t)t * d;   // SRC == MSAE_F32 && !FROM_X: a32
   auto load4 = [&](int c) {
-    f32x4 v = load_x4<SRC>(x, (size_t)t * d + c);
-    if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
-    return v;
+    if constexpr (!FROM_X) {
+      return *reinterpret_cast<const f32x4 *>(row32 + c);
+    } else {
+      f32x4 v = load_x4<SRC>(x, (size_t)t * d + c);
+      if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+      return v;
+    }
   };
   float m_in = 0.f, m_out = 0.f, ss = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
@@ -406,7 +411,12 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   }
   if (threadIdx.x < MAX_OUT) {
     const int dim = odims[threadIdx.x];
-    int iv = dim >= 0 ? (int)rintf((load_x1<SRC>(x, (size_t)t * d + dim) - (b_dec ? b_dec[dim] : 0.f)) * inv_o) : 0;
+    float av = 0.f;
+    if (dim >= 0) {
+      if constexpr (!FROM_X) av = row32[dim];
+      else av = load_x1<SRC>(x, (size_t)t * d + dim) - (b_dec ? b_dec[dim] : 0.f);
+    }
+    int iv = dim >= 0 ? (int)rintf(av * inv_o) : 0;
     iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
     xqo[(size_t)t * MAX_OUT + threadIdx.x] = (signed char)iv;
   }
@@ -1513,14 +1523,18 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
-    hipLaunchKernelGGL(prep_colmax_kernel<DT>, dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
-                       shard ? (float *)nullptr : a32, colmax);
+    if (shard)
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
+                         (float *)nullptr, colmax);
+    else
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+                         colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
-      hipLaunchKernelGGL(quant_x_kernel<DT>, dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12);
+      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12);
     else
-      hipLaunchKernelGGL(quant_x_kernel<MSAE_F32>, dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr, T, d,
-                         odims, is_out, xq, xqo, rowc, zz12);
+      hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
+                         T, d, odims, is_out, xq, xqo, rowc, zz12);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
                        reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp);
     colc = cc_main; colc_s = cc_samp;
