@@ -999,15 +999,19 @@ inline void prof_mark(int i, hipStream_t s) {
 //                 rotate per step, ~6 cycles per element instead of ~15 for a one-lane chain out of LDS);
 //                 the LAST wave of a token to finish sorts the exact values and writes the outputs: verified
 //                 iff v_k lies above tau
-constexpr int SMALL_T_MAX = 4, SMALL_R = 96, SMALL_RMAX = 127, SMALL_K_MAX = 64;   // candidates per token: R .. RMAX
+constexpr int SMALL_T_MAX = 16, SMALL_T_DOT4 = 4;      // small path: T <= 16 (d <= 4096), T <= 4 for wider inputs
+constexpr int SMALL_DOT4_PREF = 1;                     // T = 1: dot4 stream (0.130 ms vs 0.154); T >= 2: MFMA stream
+                                                       // (T = 2 / 3 / 4: 0.158 / 0.156 / 0.159 ms vs 0.165 / 0.205 / 0.213)
+constexpr int SMALL_R = 96, SMALL_RMAX = 127, SMALL_K_MAX = 64;   // candidates per token: R .. RMAX
+constexpr int SMALL_MF_EMIT = 5;                       // MFMA stream: survivors per workgroup (one per CU) and token
 constexpr int SMALL_GRID = 2048;                       // gemv workgroups of 4 waves (8 per CU)
 constexpr int SMALL_EMIT = 3;                          // survivors per workgroup and token
 constexpr int SMALL_WG_ROWS = 128;                     // most rows of one workgroup (32 per wave)
 constexpr int SMALL_SURV = SMALL_GRID * SMALL_EMIT;    // 6144 keys per token
 static_assert(SMALL_RMAX < SMALL_SURV && SMALL_RMAX + 1 <= 128, "candidate list: 127 exact values + the hook's set_feature");
 inline bool small_shape_ok(int T, int d, int N, int k) {
-  return T <= SMALL_T_MAX && k <= SMALL_K_MAX && d % 1024 == 0 && d <= 8192 && N >= 4096 &&
-         N <= SMALL_GRID * SMALL_WG_ROWS && i8_shape_ok(N, d);
+  return T <= SMALL_T_MAX && (T <= SMALL_T_DOT4 || d <= 4096) && k <= SMALL_K_MAX && d % 1024 == 0 && d <= 8192 &&
+         N >= 4096 && N <= SMALL_GRID * SMALL_WG_ROWS && i8_shape_ok(N, d);
 }
 
 struct FusedPlan {
@@ -1254,6 +1258,143 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
   }
 }
 
+// 5 <= T <= 16 tokens: the same weight stream on the matrix cores.  One 8-wave workgroup per CU keeps both int8
+// planes of the (<= 16) tokens in LDS ([16][d + 16]: the pad spreads the token rows over the banks); a wave owns
+// blocks of 16 features n0 .. n0 + 15 (strided over all waves of the grid) and walks k in steps of 64:
+//   B = 16 B per lane straight from global (feature l % 16, bytes 16 (l / 16) .. of the step: 16 rows x 64 B per
+//       instruction, non-temporal), A = the two planes' fragments from LDS, v_mfma_i32_16x16x64_i8 x 2
+// -> C[token 4 (l / 16) + r][feature l % 16] in 4 + 4 accumulator registers.  u = coarse + z sigma as in the dot4
+// stream; every lane keeps the SMALL_MF_EMIT + 1 best keys of each of its 4 token slots, the 16 lanes of a token
+// group and then the 8 waves merge them (max-reduce rounds), and the workgroup emits its EMIT best + bound.
+template <int DSEG>
+__global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__restrict__ wq, const f32x4 *__restrict__ wstat,
+                                                        const float *__restrict__ b_enc, int N, int T,
+                                                        const signed char *__restrict__ xhi,
+                                                        const signed char *__restrict__ xlo,
+                                                        const f32x4 *__restrict__ rowc, float zz12, int skip_a,
+                                                        int skip_b, unsigned long long *__restrict__ surv,
+                                                        unsigned *__restrict__ bound) {
+  constexpr int d = DSEG * 1024, PITCH = d + 16, KEEP = SMALL_MF_EMIT + 1, KS = d / 64, UN = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  signed char *xs = reinterpret_cast<signed char *>(smem);                       // [2][16][PITCH]
+  unsigned long long *wtop = reinterpret_cast<unsigned long long *>(smem + 2 * 16 * PITCH);   // [16][8][KEEP]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+  for (int i = threadIdx.x; i < 2 * 16 * (d / 16); i += 512) {          // planes -> LDS, rows >= T zero
+    const int pl = i / (16 * (d / 16)), r = (i / (d / 16)) % 16, c = (i % (d / 16)) * 16;
+    i32x4 v = {0, 0, 0, 0};
+    if (r < T) v = *reinterpret_cast<const i32x4 *>((pl ? xlo : xhi) + (size_t)r * d + c);
+    *reinterpret_cast<i32x4 *>(xs + (size_t)(pl * 16 + r) * PITCH + c) = v;
+  }
+  float sxz[4], pz[4], rz[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = lg * 4 + r;
+    const f32x4 rc = rowc[t < T ? t : T - 1];
+    sxz[r] = rc[0]; pz[r] = rc[2]; rz[r] = rc[0] * rc[0] * zz12;
+  }
+  unsigned long long top[4][KEEP];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < KEEP; ++q) top[r][q] = 0ull;
+  __syncthreads();
+  const signed char *ah_p = xs + (size_t)l15 * PITCH + lg * 16;          // this lane's A fragment: token l15, k quarter lg
+  const signed char *al_p = ah_p + (size_t)16 * PITCH;
+  const int n_blocks = N / 16, wave_g = blockIdx.x * 8 + wv, n_waves = gridDim.x * 8;
+  for (int blk = wave_g; blk < n_blocks; blk += n_waves) {
+    const int n0 = blk * 16;
+    const signed char *bp = wq + (size_t)(n0 + l15) * d + lg * 16;
+    i32x4 acc_h = {0, 0, 0, 0}, acc_l = {0, 0, 0, 0};
+    i32x4 ba[UN], bb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) ba[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + u * 64));
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += 2 * UN) {                            // KS % (2 UN) == 0 (d % 1024 == 0)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) bb[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + (ks + UN + u) * 64));
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const i32x4 ah = *reinterpret_cast<const i32x4 *>(ah_p + (ks + u) * 64);
+        const i32x4 al = *reinterpret_cast<const i32x4 *>(al_p + (ks + u) * 64);
+        acc_h = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, ba[u], acc_h, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, ba[u], acc_l, 0, 0, 0);
+      }
+      if (ks + 2 * UN < KS) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) ba[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + (ks + 2 * UN + u) * 64));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const i32x4 ah = *reinterpret_cast<const i32x4 *>(ah_p + (ks + UN + u) * 64);
+        const i32x4 al = *reinterpret_cast<const i32x4 *>(al_p + (ks + UN + u) * 64);
+        acc_h = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah, bb[u], acc_h, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bb[u], acc_l, 0, 0, 0);
+      }
+    }
+    const int n = n0 + l15;
+    const f32x4 st = wstat[n];
+    const float bias = b_enc ? b_enc[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = lg * 4 + r;
+      const float c = (128.f * (float)acc_h[r] + (float)acc_l[r]) * (sxz[r] * st[0]) + bias;
+      const float zs = __builtin_sqrtf(__builtin_fmaf(pz[r], st[1], rz[r] * st[2]));
+      unsigned long long key = t < T ? rank_key((n == skip_a || n == skip_b) ? -__builtin_inff() : c + zs, n) : 0ull;
+#pragma unroll
+      for (int q = 0; q < KEEP; ++q) {                   // sorted insert: the list stays descending
+        const unsigned long long cur = top[r][q];
+        const bool gt = key > cur;
+        top[r][q] = gt ? key : cur;
+        key = gt ? cur : key;
+      }
+    }
+  }
+  // the 16 lanes of a token group merge their lists: KEEP rounds of "largest head wins and is popped"
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int round = 0; round < KEEP; ++round) {
+      unsigned long long m = top[r][0];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 16);
+        m = o > m ? o : m;
+      }
+      if (top[r][0] == m && m != 0ull) {                 // keys are unique: exactly one lane pops
+#pragma unroll
+        for (int q = 0; q + 1 < KEEP; ++q) top[r][q] = top[r][q + 1];
+        top[r][KEEP - 1] = 0ull;
+      }
+      if (l15 == round) wtop[((size_t)(lg * 4 + r) * 8 + wv) * KEEP + round] = m;
+    }
+  }
+  __syncthreads();
+  // wave w finishes tokens 2 w and 2 w + 1: the 8 waves' lists (8 KEEP keys) -> EMIT best + bound
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int t = wv * 2 + half;
+    if (t >= T) continue;
+    unsigned long long k0 = lane < 8 * KEEP ? wtop[(size_t)t * 8 * KEEP + lane] : 0ull;
+    unsigned long long best[KEEP];
+#pragma unroll
+    for (int e = 0; e < KEEP; ++e) {
+      unsigned long long m = k0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+      }
+      best[e] = m;
+      if (k0 == m) k0 = 0ull;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < SMALL_MF_EMIT; ++e) surv[(size_t)t * SMALL_SURV + (size_t)blockIdx.x * SMALL_MF_EMIT + e] = best[e];
+      bound[(size_t)t * SMALL_GRID + blockIdx.x] = (unsigned)(best[SMALL_MF_EMIT] >> 32);
+    }
+  }
+}
+
 // one 1024-thread workgroup per token, six survivors per thread in registers.  A bisection on the 32-bit
 // order key of the upper value finds a threshold with SMALL_R .. SMALL_RMAX survivors at or above it (one
 // ballot count + one barrier per step, ~16 steps); those are the candidates (any order), and tau = the largest
@@ -1262,7 +1403,7 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
 __global__ __launch_bounds__(1024) void select_small_kernel(const unsigned long long *__restrict__ surv,
                                                             const unsigned *__restrict__ bound,
                                                             unsigned long long *__restrict__ cand,
-                                                            float *__restrict__ tau) {
+                                                            float *__restrict__ tau, int n_surv, int n_bound) {
   constexpr int PER = SMALL_SURV / 1024;
   static_assert(SMALL_SURV % 1024 == 0 && SMALL_GRID % 1024 == 0, "survivors per thread");
   __shared__ int cnt[33];
@@ -1274,13 +1415,13 @@ __global__ __launch_bounds__(1024) void select_small_kernel(const unsigned long 
   unsigned v[PER];
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
-    k[e] = surv[(size_t)t * SMALL_SURV + e * 1024 + tid];
+    k[e] = e * 1024 + tid < n_surv ? surv[(size_t)t * SMALL_SURV + e * 1024 + tid] : 0ull;
     v[e] = (unsigned)(k[e] >> 32);
   }
   unsigned below = 0u;                                   // largest value that will NOT be a candidate
 #pragma unroll
   for (int e = 0; e < SMALL_GRID / 1024; ++e) {
-    const unsigned b = bound[(size_t)t * SMALL_GRID + e * 1024 + tid];
+    const unsigned b = e * 1024 + tid < n_bound ? bound[(size_t)t * SMALL_GRID + e * 1024 + tid] : 0u;
     below = b > below ? b : below;
   }
   if (tid < 33) cnt[tid] = 0;
@@ -1455,7 +1596,28 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(SMALL_GRID), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, \
                      rowc, zz12, skip_a, skip_b, surv, bound)
   const int dseg = d / 1024;
-  if (T == 1) {
+  int n_surv = SMALL_SURV, n_bound = SMALL_GRID;
+  static const int dot4_max = [] { const char *e = getenv("MSAE_SMALL_DOT4_MAX"); return e ? atoi(e) : SMALL_DOT4_PREF; }();
+  if (T > dot4_max && d <= 4096) {
+    static int n_cu = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return cus > 0 ? cus : 256;
+    }();
+    const int grid_m = n_cu < SMALL_GRID ? n_cu : SMALL_GRID;
+    n_surv = grid_m * SMALL_MF_EMIT; n_bound = grid_m;
+    const size_t smem_m = (size_t)2 * 16 * (d + 16) + (size_t)16 * 8 * (SMALL_MF_EMIT + 1) * 8;
+#define MSAE_GEMV_M(DSEG)                                                                                          \
+  do {                                                                                                             \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)gemv_mfma_kernel<DSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)smem_m));                                                                \
+    hipLaunchKernelGGL(gemv_mfma_kernel<DSEG>, dim3(grid_m), dim3(512), smem_m, s, wq, wstat, b_enc, N, T, xhi, xlo, rowc, \
+                       zz12, skip_a, skip_b, surv, bound);                                                         \
+  } while (0)
+    switch (dseg) { case 1: MSAE_GEMV_M(1); break; case 2: MSAE_GEMV_M(2); break; case 4: MSAE_GEMV_M(4); break;
+                    default: return MSAE_ENOTIMPL; }
+#undef MSAE_GEMV_M
+  } else if (T == 1) {
     switch (dseg) { case 1: MSAE_GEMV(1, 1); break; case 2: MSAE_GEMV(2, 1); break; case 4: MSAE_GEMV(4, 1); break;
                     case 8: MSAE_GEMV(8, 1); break; default: return MSAE_ENOTIMPL; }
   } else if (T == 2) {
@@ -1466,7 +1628,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
                     default: return MSAE_ENOTIMPL; }
   }
 #undef MSAE_GEMV
-  hipLaunchKernelGGL(select_small_kernel, dim3(T), dim3(1024), 0, s, surv, bound, cand, tau);
+  hipLaunchKernelGGL(select_small_kernel, dim3(T), dim3(1024), 0, s, surv, bound, cand, tau, n_surv, n_bound);
   prof_mark(4, s);
 #define MSAE_RESCORE(DSEG)                                                                                         \
   hipLaunchKernelGGL(rescore_small_kernel<DSEG>, dim3(SMALL_RMAX, T), dim3(64), 0, s, a32, W_enc, b_enc, k, cand, tau, wstat, \
@@ -1736,9 +1898,18 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
 }
 
+// 17 .. 32 tokens: two passes of the MFMA weight stream (<= 16 tokens each, 2 x ~0.1 ms) beat the padded 256-row tile
+static bool small_chunked(int T, int d, int N, int k, const FusedPlan &pl) {
+  return pl.fast && pl.i8 && !pl.small && T > SMALL_T_MAX && T <= 2 * SMALL_T_MAX && d <= 4096 &&
+         small_shape_ok(SMALL_T_MAX, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
+}
+
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k) {
   if (T <= 0 || d <= 0 || N <= 0 || k <= 0) return 0;
-  return make_plan(T, d, N, k).bytes;
+  const FusedPlan pl = make_plan(T, d, N, k);
+  size_t b = pl.bytes;
+  if (small_chunked(T, d, N, k, pl)) { const size_t c = make_plan(SMALL_T_MAX, d, N, k).bytes; b = c > b ? c : b; }
+  return b;
 }
 
 static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
@@ -1775,6 +1946,25 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
   if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || !msae_aligned(W_enc, 16) ||
       (b_dec && !msae_aligned(b_dec, 16)))
     return MSAE_EALIGN;
+  if (small_chunked(T, d, N, k, pl)) {
+    const size_t esz = x_dtype == MSAE_F32 ? 4 : 2;
+    for (int t0 = 0; t0 < T; t0 += SMALL_T_MAX) {
+      const int Tc = T - t0 < SMALL_T_MAX ? T - t0 : SMALL_T_MAX;
+      const FusedPlan pc = make_plan(Tc, d, N, k);
+      if (!pc.small || pc.bytes > ws_bytes) return MSAE_EWS;
+      const void *xc = static_cast<const unsigned char *>(x) + (size_t)t0 * d * esz;
+      const IdxOut ic{idx.i32 ? idx.i32 + (size_t)t0 * k : nullptr, idx.i64 ? idx.i64 + (size_t)t0 * k : nullptr};
+      int32_t *sc = status ? status + t0 : nullptr;
+      int rc;
+      switch (x_dtype) {
+        case MSAE_F32: rc = run_small<MSAE_F32>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
+        case MSAE_BF16: rc = run_small<MSAE_BF16>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
+        default: rc = run_small<MSAE_F16>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
+      }
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (pl.small) {
     switch (x_dtype) {
       case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);

@@ -95,11 +95,12 @@ def test_trained_like_full_width(dev, coarse, k):
     _compare(ops, x, W, b, bd, k, f"trained_like/{coarse} full width k={k}", max_fallback=0.05)
 
 
-@pytest.mark.parametrize("T", [1, 2, 3, 4])
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 8, 13, 16, 17, 32])
 def test_small_T_path_equals_exact(dev, T):
-    """The S = 1 path (steering decode steps, features/steering.py:86,105-124): T <= 4 tokens take the weight-
-    streaming encoder (two-plane int8 activations, dot4, row-per-wave exact re-score).  Bit-identical to the
-    exact path on trained-like weights at full width, including the hooks' edits, for 64 different inputs."""
+    """The S = 1 path (steering decode steps, features/steering.py:86,105-124): T <= 16 tokens take the weight-
+    streaming encoder (two-plane int8 activations; dot4 for T <= 4, the 16x16x64 MFMA stream above; row-per-wave
+    exact re-score).  Bit-identical to the exact path on trained-like weights at full width, including the hooks'
+    edits, for 64 different inputs."""
     from msae import ops
 
     d, N, k = 4096, 131072, 32
@@ -128,8 +129,8 @@ def test_small_T_path_equals_exact(dev, T):
 @pytest.mark.parametrize("kind", hostile.KINDS)
 def test_small_T_path_on_heterogeneous_weights(dev, kind):
     """The S = 1 path on every hostile weight family (N = 16384: each of the 2048 stream workgroups sees 8 rows and
-    hands on its best 3 + a bound): bit-identical to the exact path for 96 single tokens and 32 groups of 3, every
-    token resolved; reports how many took the exact recompute."""
+    hands on its best 3 + a bound; the MFMA stream for 7 and 16 tokens): bit-identical to the exact path for 96
+    single tokens, 32 groups of 3, 16 of 7 and 8 of 16, every token resolved; reports how many took the exact recompute."""
     from msae import ops
 
     d, N, k = 1024, 16384, 32
@@ -137,7 +138,7 @@ def test_small_T_path_on_heterogeneous_weights(dev, kind):
     prepared = ops.prepare_encoder(W)
     xs = hostile.activations(192, d, dev, seed=14)
     n_fb = n_tok = 0
-    for T, reps in ((1, 96), (3, 32)):
+    for T, reps in ((1, 96), (3, 32), (7, 16), (16, 8)):
         for c in range(reps):
             x = xs[c * T:(c + 1) * T]
             ev, ei = ops.topk(ops.pre_acts(x, W, b, bd), k)
