@@ -1266,6 +1266,11 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
 // -> C[token 4 (l / 16) + r][feature l % 16] in 4 + 4 accumulator registers.  u = coarse + z sigma as in the dot4
 // stream; every lane keeps the SMALL_MF_EMIT + 1 best keys of each of its 4 token slots, the 16 lanes of a token
 // group and then the 8 waves merge them (max-reduce rounds), and the workgroup emits its EMIT best + bound.
+#ifdef MSAE_MF_PLAIN_LOADS
+#define MSAE_MF_LOAD(p) (*(p))
+#else
+#define MSAE_MF_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 template <int DSEG>
 __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__restrict__ wq, const f32x4 *__restrict__ wstat,
                                                         const float *__restrict__ b_enc, int N, int T,
@@ -1307,11 +1312,11 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__res
     i32x4 acc_h = {0, 0, 0, 0}, acc_l = {0, 0, 0, 0};
     i32x4 ba[UN], bb[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) ba[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + u * 64));
+    for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + u * 64));
 #pragma nounroll
     for (int ks = 0; ks < KS; ks += 2 * UN) {                            // KS % (2 UN) == 0 (d % 1024 == 0)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) bb[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + (ks + UN + u) * 64));
+      for (int u = 0; u < UN; ++u) bb[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (ks + UN + u) * 64));
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const i32x4 ah = *reinterpret_cast<const i32x4 *>(ah_p + (ks + u) * 64);
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__res
       }
       if (ks + 2 * UN < KS) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) ba[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(bp + (ks + 2 * UN + u) * 64));
+        for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (ks + 2 * UN + u) * 64));
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
