@@ -38,6 +38,7 @@ timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat
 timeout 300 python tools/latency_small_T.py > $OUT/${R}_latency_small_T.txt 2>&1; grep "T=" $OUT/${R}_latency_small_T.txt
 timeout 600 python tools/emulate_shard.py > $OUT/${R}_emulate_shard.txt 2>&1; grep "G=" $OUT/${R}_emulate_shard.txt
 timeout 300 python tools/train_step_bench.py > $OUT/${R}_train_step.txt 2>&1; tail -1 $OUT/${R}_train_step.txt
+timeout 300 python tools/cache_throughput.py 2>/dev/null | grep "tokens/s" > $OUT/${R}_cache_throughput.txt; cat $OUT/${R}_cache_throughput.txt
 echo "== T=1 step kernel timeline =="
 rm -rf $OUT/prof_t1
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_t1 -o t1 -- python $OLDPWD/tools/t1_trace.py > $OLDPWD/$OUT/t1.log 2>&1)
