@@ -133,7 +133,10 @@ inline float guard_z() {
   return g_guard_z;
 }
 constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
-constexpr float GUARD_ZETA = 1.f;         // first round reaches zeta sigma below the k-th coarse value
+#ifndef MSAE_GUARD_ZETA
+#define MSAE_GUARD_ZETA 1.f
+#endif
+constexpr float GUARD_ZETA = MSAE_GUARD_ZETA;   // first round reaches zeta sigma below the k-th coarse value
 constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
 
 // z^2 sigma^2 of one (token, feature) pair; rc = (sx, m, P, -), cc = (sw, Q, Si, So).  Same expression as the
