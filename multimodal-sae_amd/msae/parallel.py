@@ -183,19 +183,27 @@ class ShardedSae:
         if hi - lo != per:
             xl = torch.cat((xl, xl.new_zeros(per - (hi - lo), x.shape[1])))
         vals, idx, status = self._rescore(xl.contiguous(), recv, hi - lo)
-        # every rank gets all tokens' results: one all-gather of (value bits | feature id | status) as int32
+        # every rank gets all tokens' results: one all-gather of (value bits | feature id | status) as int32,
+        # asynchronous -- forward() decodes this rank's own tokens from (vals, idx) meanwhile
         pack = torch.cat((vals.contiguous().view(torch.int32), idx.to(torch.int32), status.view(-1, 1)), 1).contiguous()
         full = torch.empty((G * per, pack.shape[1]), dtype=torch.int32, device=pack.device)
-        dist.all_gather_into_tensor(full, pack, group=self.group)
+        work = dist.all_gather_into_tensor(full, pack, group=self.group, async_op=True)
         k = self.k
-        return (full[:T, :k].contiguous().view(torch.float32), full[:T, k:2 * k].to(torch.int64), full[:T, 2 * k].contiguous())
+
+        def join():
+            work.wait()
+            return (full[:T, :k].contiguous().view(torch.float32), full[:T, k:2 * k].to(torch.int64),
+                    full[:T, 2 * k].contiguous())
+
+        return join, (vals[: hi - lo], idx[: hi - lo]), pack
 
     def encode(self, x: Tensor):
         """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
         if not self.collective:
             return self._encode(x, self.k)
         if self.mode == "candidates":
-            return self._encode_candidates(x)
+            join, _, _keep = self._encode_candidates(x)
+            return join()
         vals, idx, status = self._encode(x, self.k_loc)
         mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
@@ -257,21 +265,37 @@ class ShardedSae:
         else:
             T = vals.shape[0]
             lo, hi, per = token_slice(T, self.rank, self.world)
-            local = self._decode(idx[lo:hi].contiguous(), vals[lo:hi].contiguous())
-            if gather:
-                d = local.shape[-1]
-                pad = torch.zeros(per, d, dtype=local.dtype, device=local.device)
-                pad[: hi - lo] = local
-                full = torch.empty(self.world * per, d, dtype=local.dtype, device=local.device)
-                work = dist.all_gather_into_tensor(full, pad, group=self.group, async_op=async_gather)
-                if async_gather:
-                    self._pending = (work, pad, full)        # keep the buffers alive until joined
-                out = full[:T]
-            else:
-                out = local
+            out = self._gather_recon(self._decode(idx[lo:hi].contiguous(), vals[lo:hi].contiguous()), T, gather, async_gather)
         if ev is not None:
             ev[1].record()
         return out
+
+    def _decode_local(self, lvals: Tensor, lidx: Tensor, T: int, gather: bool = True, async_gather: bool = False) -> Tensor:
+        """decode() for a rank that already holds exactly its own token slice's (vals, idx)."""
+        ev = None
+        if self.decode_events is not None and self.decode_event_i < len(self.decode_events):
+            ev = self.decode_events[self.decode_event_i]
+            self.decode_event_i += 1
+            ev[0].record()
+        self.synchronize()
+        out = self._gather_recon(self._decode(lidx.contiguous(), lvals.contiguous()), T, gather, async_gather)
+        if ev is not None:
+            ev[1].record()
+        return out
+
+    def _gather_recon(self, local: Tensor, T: int, gather: bool, async_gather: bool) -> Tensor:
+        """all-gather of the token-sharded reconstruction (optionally asynchronous: see decode)."""
+        lo, hi, per = token_slice(T, self.rank, self.world)
+        if not gather:
+            return local
+        d = local.shape[-1]
+        pad = torch.zeros(per, d, dtype=local.dtype, device=local.device)
+        pad[: hi - lo] = local
+        full = torch.empty(self.world * per, d, dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(full, pad, group=self.group, async_op=async_gather)
+        if async_gather:
+            self._pending = (work, pad, full)        # keep the buffers alive until joined
+        return full[:T]
 
     def synchronize(self):
         """Join an outstanding asynchronous reconstruction gather (stream-ordered wait)."""
@@ -281,6 +305,12 @@ class ShardedSae:
             self._pending = None
 
     def forward(self, x: Tensor, async_gather: bool = False) -> dict:
+        if self.collective and self.mode == "candidates":
+            # the owner already holds its tokens' results: decode them while the result gather is in flight
+            join, (lv, li), _keep = self._encode_candidates(x)
+            recon = self._decode_local(lv, li, x.shape[0], async_gather=async_gather)
+            vals, idx, status = join()
+            return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
         vals, idx, status = self.encode(x)
         recon = self.decode(vals, idx, async_gather=async_gather)
         return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
