@@ -372,16 +372,17 @@ __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int co
   return __builtin_fmaf(pz, col_c[2 * C::NT + col], __builtin_fmaf(rz * mf * mf, col_c[4 * C::NT + col], rz * col_c[3 * C::NT + col]));
 }
 
-template <class C, bool DENSE>
+template <class C, bool DENSE, class F>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
-                                              unsigned char *smem, const float *side, int tl_tile = 0) {
+                                              unsigned char *smem, const float *side, F &&after_barrier, int tl_tile = 0) {
   const int l31 = lane & 31, kh = lane >> 5;
   constexpr int QCAP = C::QCAP;
   unsigned *q_count = reinterpret_cast<unsigned *>(smem + C::LDS_RING_BYTES + C::SIDE_BYTES);
   unsigned long long *queue = reinterpret_cast<unsigned long long *>(smem + C::LDS_RING_BYTES + C::SIDE_BYTES + 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                        // side[] written; previous tile's flush done
+  after_barrier();
   if constexpr (!DENSE) {
     if (threadIdx.x == 0) *q_count = 0u;
     __syncthreads();
@@ -612,8 +613,18 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     const unsigned char *base = pf_a ? op.A + (size_t)(tm0 + pf_row) * op.ldA : op.B + (size_t)(tn0 + pf_row) * op.ldB;
     gemm_warm_l2(base + (size_t)kmain * C::ROWB, pf_voff, pf_sink);
   };
+  // Tuning option (-DMSAE_GEMM_PRESTAGE; measured 4.22 ms against 4.17-4.18 without, NOT the default): with an outlier
+  // tile in front, stage the tile's first MAIN k-tile one step early -- in the predecessor's epilogue (the prologue
+  // for the workgroup's first tile) -- because the outlier iteration (one k-step of MFMAs) cannot hide a DMA issued
+  // inside it.  The wait it removes is cheaper than the DMA issue it moves into the VALU-bound epilogue.
+#ifdef MSAE_GEMM_PRESTAGE
+  constexpr bool PRESTAGE = true;
+#else
+  constexpr bool PRESTAGE = false;
+#endif
   if (tile_id == (int)blockIdx.x) {   // later tiles: staged by their predecessor
     stage(m0, n0, 0, 0);
+    if (PRESTAGE && lead) stage(m0, n0, 1, 1);
     warm(m0, n0, 1 < op.nk ? 1 : 0);  // keeps "the youngest load is a warming load" true from the first wait on
   }
 
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     if (kt == 0) MSAE_TL(1);
     if (kt == 1) MSAE_TL(2);
     auto stage_next = [&]() {
-      if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
+      if (kt + 1 < ntiles) { if (!(PRESTAGE && lead && kt == 0)) stage(m0, n0, kt + 1, (seq + 1) & 1); }
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     };
 #ifdef MSAE_GEMM_STAGGER
@@ -722,7 +733,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
     side[5 * C::NT + tid_] = side5;
   }
-  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side, tl_tile);
+  // behind the epilogue's first barrier every wave is done with the last k-tile's slot: the next tile's first main
+  // k-tile lands there while the epilogue runs (its outlier tile is already in the other slot)
+  gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side,
+                          [&] { if (PRESTAGE && lead && has_next) stage(m0n, n0n, 1, (seq + 1) & 1); }, tl_tile);
   MSAE_TL(6);
   }
 }
