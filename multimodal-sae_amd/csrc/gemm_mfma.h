@@ -305,6 +305,40 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [] {});
 }
 
+// Compact outlier tile (at most 32 outlier dims: one k-step).  The k-loop is bound by the L2 -> LDS delivery, and a
+// full 64 KB tile of which 32 B per row carry data is 3 % of an output tile's bytes for nothing: only bytes [0, 32) of
+// each 128-B row are staged -- 16 pieces of 32 rows x 32 B, two per wave -- into a dense [512][32 B] image (A rows,
+// then B rows) at the head of the slot.
+template <class C>
+__device__ __forceinline__ void gemm_stage_lead_compact(const unsigned char *__restrict__ Ao,
+                                                        const unsigned char *__restrict__ Bo, int m0, int n0,
+                                                        unsigned char *lds, int slot, int wave, int lane) {
+  static_assert(C::BM == 256 && C::BN == 256 && C::NWAVES == 8, "16 pieces over 8 waves");
+  unsigned char *base = lds + slot * C::STAGE_BYTES;
+  const unsigned voff = (unsigned)(lane >> 1) * 128u + (unsigned)(lane & 1) * 16u;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave * 2 + i;                    // 0..7: A rows 32 piece .., 8..15: B rows
+    const bool isA = piece < 8;
+    const int pl = isA ? piece : piece - 8;
+    const unsigned char *sbase = (isA ? Ao + (size_t)m0 * 128 : Bo + (size_t)n0 * 128) + (size_t)pl * 32 * 128;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(base + piece * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+  }
+}
+template <class C>
+__device__ __forceinline__ void gemm_compute_lead_compact(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
+                                                          int wr, int wc, int l31, int kh) {
+  const unsigned char *sB = sA + C::BM * 32;
+  i32x4 a[C::MI], b[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i) a[i] = *reinterpret_cast<const i32x4 *>(sA + (wr * C::TM + i * 32 + l31) * 32 + kh * 16);
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) b[j] = *reinterpret_cast<const i32x4 *>(sB + (wc * C::TN + j * 32 + l31) * 32 + kh * 16);
+  gemm_mfma_step<C>(acc, a, b);
+}
+
 // the outlier k-tile: only its first `nks` k-steps hold data (32 outlier dims per k-step), the rest is zero
 template <class C>
 __device__ __forceinline__ void gemm_compute_lead(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
@@ -597,10 +631,18 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   const int ntiles = op.nk + lead;
   const GemmStageLane sl_main = gemm_stage_lane(lane, (unsigned)op.ldA);   // ldA == ldB (launcher)
   const GemmStageLane sl_lead = gemm_stage_lane(lane, 128u);
+#ifndef MSAE_GEMM_FULL_LEAD
+  const bool lead_compact = lead_ks <= 1;                  // wave-uniform (device-side count of outlier dims)
+#else
+  const bool lead_compact = false;
+#endif
   auto stage = [&](int tm0, int tn0, int tile, int slot) {
-    if (tile < lead)
+    if (tile < lead) {
+      if constexpr (C::I8) {
+        if (lead_compact) { gemm_stage_lead_compact<C>(op.Ao, op.Bo, tm0, tn0, smem, slot, wave, lane); return; }
+      }
       gemm_stage<C>(op.Ao, op.Bo, 128, tm0, tn0, 0, smem, slot, wave, sl_lead);
-    else
+    } else
       gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, sl_main);
   };
   // L2 warming two k-tiles ahead (gemm_warm_l2): this wave's rows of the shared operand tiles
@@ -671,7 +713,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
     MSAE_TLK(kt == 8, 3);
     const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
-    if (park_m) gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
+    if (park_m) {
+      if (lead_compact) { if (lead_ks > 0) { if constexpr (C::I8) gemm_compute_lead_compact<C>(acc, sA, wr, wc, l31, kh); } }
+      else gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
+    }
     else if constexpr (!C::ABL_NOREAD && !C::ABL_NOMFMA && !C::ABL_NOSTAGE)
       gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [&] { if (late) stage_next(); });
     else gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
