@@ -47,6 +47,60 @@ __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__rest
   vmcnt_le<0>();
 }
 
+// Register path for comparison: the same pieces through global_load_dwordx4 -> VGPR (-> ds_write_b128 when WRITE),
+// one k-tile (PPW x 16 B per lane) in flight while the previous one is written / dropped.
+template <int BK, bool WRITE>
+__global__ __launch_bounds__(512) void stream_reg_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
+                                                         size_t ld, int nM, int nN, int nk, int *sink) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int ROWS_PER_PIECE = 1024 / BK, LANES_PER_ROW = BK / 16;
+  constexpr int PIECES = 512 * BK / 1024, PPW = PIECES / 8, SLOT = 512 * BK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane / LANES_PER_ROW, lcol = (lane % LANES_PER_ROW) * 16;
+  typedef int i32x4v __attribute__((ext_vector_type(4)));
+  auto fetch = [&](long i, i32x4v (&r)[PPW]) {
+    const int tile_id = (int)blockIdx.x + (int)(i / nk) * (int)gridDim.x, kt = (int)(i % nk);
+    int tm, tn;
+    gemm_map_tile(tile_id, nM, nN, tm, tn);
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      const int piece = wave * PPW + p;
+      const bool isA = piece < PIECES / 2;
+      const int pl = isA ? piece : piece - PIECES / 2;
+      const unsigned char *src = (isA ? A + (size_t)(tm * 256 + pl * ROWS_PER_PIECE + lrow) * ld
+                                      : B + (size_t)(tn * 256 + pl * ROWS_PER_PIECE + lrow) * ld) + (size_t)kt * BK + lcol;
+      r[p] = *reinterpret_cast<const i32x4v *>(src);
+    }
+  };
+  const int tiles = (nM * nN - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const long total = (long)tiles * nk;
+  i32x4v ra[PPW], rb[PPW];
+  int acc = 0;
+  if (total > 0) fetch(0, ra);
+  for (long i = 0; i < total; i += 2) {
+    if (i + 1 < total) fetch(i + 1, rb);
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      if (WRITE) *reinterpret_cast<i32x4v *>(smem + (i & 1) * SLOT + (wave * PPW + p) * 1024 + lane * 16) = ra[p];
+      else acc ^= ra[p][0] ^ ra[p][3];
+    }
+    if (WRITE) __builtin_amdgcn_s_barrier();
+    if (i + 2 < total) fetch(i + 2, ra);
+    if (i + 1 < total) {
+#pragma unroll
+      for (int p = 0; p < PPW; ++p) {
+        if (WRITE) *reinterpret_cast<i32x4v *>(smem + ((i + 1) & 1) * SLOT + (wave * PPW + p) * 1024 + lane * 16) = rb[p];
+        else acc ^= rb[p][1] ^ rb[p][2];
+      }
+      if (WRITE) __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (acc == 0x12345678) sink[0] = acc;
+}
+template <int BK, bool WRITE>
+void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps, int *sink);
+
+static int g_grid = 256;
 template <int BK, int DEPTH>
 void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps) {
   const int nM = T / 256, nN = N / 256, nk = d / BK;
@@ -54,22 +108,46 @@ void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, in
   auto kern = stream_kernel<BK, DEPTH>;
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
   for (int i = 0; i < reps; ++i) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
+    hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
   }
   const double bytes = (double)nM * nN * nk * 512.0 * BK;
   printf("k-tile %3d B x ring %d (%3zu KB LDS, %3d KB in flight): %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n", BK, DEPTH,
-         smem >> 10, (DEPTH - 1) * 512 * BK >> 10, best, bytes / best / 1e6 / 256, bytes / best / 1e9, best * 1e3 / ((double)nM * nN * d / 128 / 256));
+         smem >> 10, (DEPTH - 1) * 512 * BK >> 10, best, bytes / best / 1e6 / g_grid, bytes / best / 1e9, best * 1e3 / ((double)nM * nN * d / 128 / g_grid));
 }
 
-int main() {
-  const int T = 8192, N = 131072, d = 4096;
+template <int BK, bool WRITE>
+void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps, int *sink) {
+  const int nM = T / 256, nN = N / 256, nk = d / BK;
+  const size_t smem = (size_t)2 * 512 * BK;
+  auto kern = stream_reg_kernel<BK, WRITE>;
+  CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk, sink);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int i = 0; i < reps; ++i) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk, sink);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  const double bytes = (double)nM * nN * nk * 512.0 * BK;
+  printf("k-tile %3d B via VGPRs%s: %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n", BK,
+         WRITE ? " + ds_write_b128 + barrier" : " (dropped)             ", best, bytes / best / 1e6 / g_grid, bytes / best / 1e9,
+         best * 1e3 / ((double)nM * nN * d / 128 / g_grid));
+}
+
+int main(int argc, char **argv) {
+  const int T = argc > 1 ? atoi(argv[1]) : 8192, N = argc > 2 ? atoi(argv[2]) : 131072, d = 4096;
+  if (argc > 3) g_grid = atoi(argv[3]);
+  printf("T=%d N=%d d=%d: x %d MB, Wq %d MB, %d workgroups\n", T, N, d, T / 256, N / 256, g_grid);
   unsigned char *A, *B;
   CK(hipMalloc(&A, (size_t)T * d)); CK(hipMalloc(&B, (size_t)N * d));
   CK(hipMemset(A, 1, (size_t)T * d)); CK(hipMemset(B, 2, (size_t)N * d));
@@ -80,5 +158,8 @@ int main() {
   run<32, 4>(A, B, T, N, d, 5);
   run<32, 8>(A, B, T, N, d, 5);
   run<128, 2>(A, B, T, N, d, 5);
+  int *sink; CK(hipMalloc(&sink, 64));
+  run_reg<128, false>(A, B, T, N, d, 5, sink);
+  run_reg<128, true>(A, B, T, N, d, 5, sink);
   return 0;
 }

@@ -1,0 +1,267 @@
+// gemm4w.hip -- standalone prototype (not part of the product): the candidate GEMM's k-loop with FOUR waves per CU
+// (2 x 2, 128 x 128 per wave, 256 accumulator registers each) and REGISTER staging (global_load_dwordx4 -> VGPR ->
+// ds_write_b128) instead of LDS-DMA.  tools/dma_depth.hip measured the register path delivering 58 GB/s per CU against
+// 43.5 for LDS-DMA at the same depth; this asks what a full k-loop makes of it.  int8, 256 x 256 x 128-byte k-tiles,
+// 2-slot LDS ring, T=8192 N=131072 d=4096; prints us per k-tile and checks a few outputs against a naive reference.
+#include <cstdio>
+#include <cstdlib>
+#include "../multimodal-sae_amd/csrc/gemm_mfma.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int SETS>
+__global__ __launch_bounds__(256) void gemm4w_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
+                                                     size_t ld, int nM, int nN, int nk, int *__restrict__ out, int N) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int SLOT = 512 * 128, PPW = 16;            // 64 pieces of 8 rows x 128 B per k-tile, 16 per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int r_in = lane >> 3, c_in = lane & 7;
+  auto fetch = [&](int tm, int tn, int kt, v4i (&r)[PPW]) {
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      const int piece = wave * PPW + p;                  // 0..31 A rows, 32..63 B rows
+      const bool isA = piece < 32;
+      const int row = (isA ? tm * 256 : tn * 256) + (piece & 31) * 8 + r_in;
+      r[p] = *reinterpret_cast<const v4i *>((isA ? A : B) + (size_t)row * ld + (size_t)kt * 128 + c_in * 16);
+    }
+  };
+  auto put = [&](int slot, const v4i (&r)[PPW]) {
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+      const int piece = wave * PPW + p;
+      const int row = (piece & 31) * 8 + r_in;         // row inside its operand tile
+      unsigned char *tile = smem + slot * SLOT + (piece < 32 ? 0 : 256 * 128);
+      *reinterpret_cast<v4i *>(tile + row * 128 + ((c_in ^ gemm_swz(row)) << 4)) = r[p];
+    }
+  };
+  for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
+    int tm, tn;
+    gemm_map_tile(tile_id, nM, nN, tm, tn);
+    v16i acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    v4i ra[PPW], rb[PPW];
+    fetch(tm, tn, 0, ra);
+    put(0, ra);
+    if (nk > 1) fetch(tm, tn, 1, ra);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (SETS == 2 && kt + 2 < nk) fetch(tm, tn, kt + 2, (kt & 1) ? ra : rb);     // two k-tiles in flight
+      const unsigned char *sA = smem + (kt & 1) * SLOT, *sB = sA + 256 * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        v4i a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = gemm_frag(sA, wr * 128 + i * 32 + l31, ks * 2 + kh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = gemm_frag(sB, wc * 128 + j * 32 + l31, ks * 2 + kh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) {
+        if (SETS == 2) put((kt + 1) & 1, (kt & 1) ? rb : ra);
+        else { put((kt + 1) & 1, ra); if (kt + 2 < nk) fetch(tm, tn, kt + 2, ra); }
+      }
+      __syncthreads();
+    }
+    // checksum of the tile's accumulators (keeps them live) + a few outputs for the correctness check
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s ^= acc[i][j][e];
+    if (s == 0x7fffffff) out[0] = s;
+    if (tile_id < 2 && lane == 0) {   // C[row][col]: col = l31, row = (e&3) + 8*(e>>2) + 4*kh  -> row 0 col 0 of block (i, j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[16 + tile_id * 64 + wave * 16 + i * 4 + j] = acc[i][j][0];
+    }
+  }
+}
+
+// ---- hand-scheduled variant: asm ds_read / ds_write / waits with counted lgkmcnt and vmcnt ---------------------------
+template <int IMM> __device__ __forceinline__ v4i ldsr(unsigned addr) {
+  v4i v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory"); return v;
+}
+__device__ __forceinline__ void ldsw(unsigned addr, const v4i &v) {
+  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+template <int N> __device__ __forceinline__ void lgkm_tied(v4i (&a)[4], v4i (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_tied8(v4i *r) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void rd8(v4i (&a)[4], v4i (&b)[4], unsigned ra, unsigned rb) {
+  a[0] = ldsr<0>(ra); a[1] = ldsr<4096>(ra); a[2] = ldsr<8192>(ra); a[3] = ldsr<12288>(ra);
+  b[0] = ldsr<0>(rb); b[1] = ldsr<4096>(rb); b[2] = ldsr<8192>(rb); b[3] = ldsr<12288>(rb);
+}
+__device__ __forceinline__ void mfma16(v16i (&acc)[4][4], const v4i (&a)[4], const v4i (&b)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm4w_sched_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
+                                                           size_t ld, int nM, int nN, int nk, int *__restrict__ out, int N) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int SLOT = 512 * 128, PPW = 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int r_in = lane >> 3, c_in = lane & 7;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  // fragment read addresses (slot 0): row base + swizzled chunk of k-step ks
+  const unsigned sw = (unsigned)gemm_swz(l31);
+  unsigned offk[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) offk[ks] = (((unsigned)(ks * 2 + kh)) ^ sw) << 4;
+  const unsigned rowA = lds0 + (unsigned)(wr * 128 + l31) * 128u, rowB = lds0 + 256u * 128u + (unsigned)(wc * 128 + l31) * 128u;
+  // staging: piece p of this wave = rows (piece & 31) * 8 + r_in of A (piece < 32) or B
+  unsigned wdst[PPW];
+#pragma unroll
+  for (int p = 0; p < PPW; ++p) {
+    const int piece = wave * PPW + p, row = (piece & 31) * 8 + r_in;
+    wdst[p] = lds0 + (piece < 32 ? 0u : 256u * 128u) + (unsigned)row * 128u + (unsigned)((c_in ^ gemm_swz(row)) << 4);
+  }
+  const bool stA = wave < 2;                              // waves 0,1 stage A rows, waves 2,3 B rows (16 pieces = 128 rows each)
+  for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
+    int tm, tn;
+    gemm_map_tile(tile_id, nM, nN, tm, tn);
+    const unsigned char *src0 = (stA ? A + (size_t)(tm * 256 + (wave & 1) * 128 + r_in) * ld
+                                     : B + (size_t)(tn * 256 + (wave & 1) * 128 + r_in) * ld) + c_in * 16;
+    v16i acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    v4i rg[PPW];
+    auto fetch8 = [&](int kt, int half) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        rg[half * 8 + p] = *reinterpret_cast<const v4i *>(src0 + (size_t)(half * 8 + p) * 8 * ld + (size_t)kt * 128);
+    };
+    // prologue: tile 0 -> slot 0, tile 1 in flight
+    fetch8(0, 0); fetch8(0, 1);
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) ldsw(wdst[p], rg[p]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nk > 1) { fetch8(1, 0); fetch8(1, 1); }
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned so = (unsigned)(kt & 1) * SLOT, sn = (unsigned)((kt + 1) & 1) * SLOT;
+      const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+      v4i a0[4], b0[4], a1[4], b1[4];
+      rd8(a0, b0, rowA + so + offk[0], rowB + so + offk[0]);
+      rd8(a1, b1, rowA + so + offk[1], rowB + so + offk[1]);
+      lgkm_tied<8>(a0, b0);
+      mfma16(acc, a0, b0);
+      if (more) {                                          // first half of the next tile -> LDS
+        vm_tied8<8>(rg);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) ldsw(wdst[p] + sn, rg[p]);
+      }
+      rd8(a0, b0, rowA + so + offk[2], rowB + so + offk[2]);
+      if (more) lgkm_tied<15>(a1, b1); else lgkm_tied<8>(a1, b1);
+      mfma16(acc, a1, b1);
+      if (more) {
+        vm_tied8<0>(rg + 8);
+#pragma unroll
+        for (int p = 8; p < PPW; ++p) ldsw(wdst[p] + sn, rg[p]);
+      }
+      rd8(a1, b1, rowA + so + offk[3], rowB + so + offk[3]);
+      if (more) lgkm_tied<15>(a0, b0); else lgkm_tied<8>(a0, b0);     // (first 8 writes and) k-step 2 fragments landed
+      if (more2) fetch8(kt + 2, 0);                        // their registers are free: the first 8 writes have completed
+      mfma16(acc, a0, b0);
+      lgkm_tied<0>(a1, b1);
+      if (more2) fetch8(kt + 2, 1);
+      mfma16(acc, a1, b1);
+      __builtin_amdgcn_s_barrier();
+    }
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s ^= acc[i][j][e];
+    if (s == 0x7fffffff) out[0] = s;
+    if (tile_id < 2 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[16 + tile_id * 64 + wave * 16 + i * 4 + j] = acc[i][j][0];
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+__global__ void fill(unsigned char *p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
+    p[i] = (unsigned char)(signed char)((int)(z % 7) - 3);
+  }
+}
+
+template <int SETS>
+void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int *out, const signed char *hA, const signed char *hB) {
+  const int nM = T / 256, nN = N / 256, nk = d / 128;
+  const size_t smem = 2 * 512 * 128;
+  auto kern = SETS == 0 ? gemm4w_sched_kernel : gemm4w_kernel<(SETS ? SETS : 1)>;
+  CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int i = 0; i < 5; ++i) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  int h[16 + 128]; CK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+  int bad = 0;
+  for (int tile = 0; tile < 2; ++tile) {
+    int tm, tn; { int b = tile; const int xcd = b & 7, slot = b >> 3; const int st = (slot / 32) * 8 + xcd; tm = (st % (nM / 8)) * 8 + (slot % 32) % 8; tn = (st / (nM / 8)) * 4 + (slot % 32) / 8; }
+    for (int wave = 0; wave < 4; ++wave) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+      const int row = tm * 256 + (wave >> 1) * 128 + i * 32, col = tn * 256 + (wave & 1) * 128 + j * 32;
+      long ref = 0; for (int k = 0; k < d; ++k) ref += (long)hA[(size_t)row * d + k] * hB[(size_t)col * d + k];
+      if ((int)ref != h[16 + tile * 64 + wave * 16 + i * 4 + j]) ++bad;
+    }
+  }
+  const double ops = 2.0 * T * N * d;
+  printf("4 waves, register staging, %d set(s) in flight: %7.3f ms  %6.0f TOP/s  %5.2f us per k-tile   outputs checked: %s\n", SETS, best,
+         ops / best / 1e9, best * 1e3 / ((double)nM * nN * nk / 256), bad ? "MISMATCH" : "ok");
+}
+
+int main() {
+  const int T = 8192, N = 131072, d = 4096;
+  unsigned char *A, *B; int *out;
+  CK(hipMalloc(&A, (size_t)T * d)); CK(hipMalloc(&B, (size_t)N * d)); CK(hipMalloc(&out, 4096));
+  fill<<<2048, 256>>>(A, (size_t)T * d, 1); fill<<<2048, 256>>>(B, (size_t)N * d, 2);
+  CK(hipDeviceSynchronize());
+  // host copies of the rows the check touches (tiles 0 and 1: a few rows of A and B)
+  signed char *hA = (signed char *)malloc((size_t)T * d), *hB = (signed char *)malloc((size_t)2048 * d * 4);
+  CK(hipMemcpy(hA, A, (size_t)T * d, hipMemcpyDeviceToHost));
+  signed char *hBfull = (signed char *)malloc((size_t)N * d);
+  CK(hipMemcpy(hBfull, B, (size_t)N * d, hipMemcpyDeviceToHost));
+  run<1>(A, B, T, N, d, out, hA, hBfull);
+  run<0>(A, B, T, N, d, out, hA, hBfull);     // "0 set(s)" = the hand-scheduled kernel
+  (void)hB;
+  return 0;
+}
