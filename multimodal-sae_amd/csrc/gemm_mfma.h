@@ -179,6 +179,32 @@ __device__ __forceinline__ void gemm_stage_pieces(const unsigned char *__restric
                  :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
   }
 }
+// Hybrid staging (tuning builds, -DMSAE_GEMM_HYBRID): the LDS-DMA instruction delivers 43.5 GB/s per CU, the same pieces
+// through VGPRs 58 (tools/dma_depth.hip) -- but 8 waves x 128 accumulators leave room for 16 staging registers at
+// most.  So a wave moves its four A pieces by LDS-DMA and its four B pieces through registers: global_load_dwordx4
+// when the k-tile is staged, ds_write_b128 into the slot right before the barrier that publishes it.
+struct GemmBRegs { i32x4 r[4]; };
+template <class C>
+__device__ __forceinline__ void gemm_fetch_b(GemmBRegs &br, const unsigned char *__restrict__ B, size_t ld, int n0,
+                                             size_t kbyte, int wave, const GemmStageLane &sl) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = wave * 4 + i;
+    const unsigned voff = sl.off ^ ((unsigned)(pl & 1) << 6);
+    const unsigned char *sbase = B + (size_t)(n0 + pl * 8) * ld + kbyte;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(br.r[i]) : "v"(voff), "s"(sbase) : "memory");
+  }
+}
+template <class C>
+__device__ __forceinline__ void gemm_put_b(GemmBRegs &br, unsigned char *lds, int slot, int wave, int lane) {
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
+      lds + slot * C::STAGE_BYTES + C::A_BYTES + wave * 4096 + lane * 16);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(br.r[0]), "+v"(br.r[1]), "+v"(br.r[2]), "+v"(br.r[3]) :: "memory");
+  asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\t"
+               "ds_write_b128 %0, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+               :: "v"(dst), "v"(br.r[0]), "v"(br.r[1]), "v"(br.r[2]), "v"(br.r[3]) : "memory");
+}
+
 // this wave's even share (PPW pieces) of one k-tile
 template <class C>
 __device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A,
@@ -630,6 +656,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   const int lead = has_out ? 1 : 0;
   const int ntiles = op.nk + lead;
   const GemmStageLane sl_main = gemm_stage_lane(lane, (unsigned)op.ldA);   // ldA == ldB (launcher)
+#ifdef MSAE_GEMM_HYBRID
+  GemmBRegs bregs;
+#endif
   const GemmStageLane sl_lead = gemm_stage_lane(lane, 128u);
 #ifndef MSAE_GEMM_FULL_LEAD
   const bool lead_compact = lead_ks <= 1;                  // wave-uniform (device-side count of outlier dims)
@@ -642,8 +671,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         if (lead_compact) { gemm_stage_lead_compact<C>(op.Ao, op.Bo, tm0, tn0, smem, slot, wave, lane); return; }
       }
       gemm_stage<C>(op.Ao, op.Bo, 128, tm0, tn0, 0, smem, slot, wave, sl_lead);
-    } else
+    } else {
+#ifdef MSAE_GEMM_HYBRID
+      gemm_stage_pieces<C, 4>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave * 4, sl_main);
+      gemm_fetch_b<C>(bregs, op.B, op.ldB, tn0, (size_t)(tile - lead) * C::ROWB, wave, sl_main);
+#else
       gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, sl_main);
+#endif
+    }
   };
   // L2 warming two k-tiles ahead (gemm_warm_l2): this wave's rows of the shared operand tiles
   const bool pf_a = wave < 4;
@@ -683,6 +718,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (tid_ < C::BM) side_m[tid_] = side2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#ifdef MSAE_GEMM_HYBRID
+    if (kt >= lead) gemm_put_b<C>(bregs, smem, seq & 1, wave, lane);   // this k-tile's B pieces: registers -> its slot
+#endif
     MSAE_TLK(kt == 8, 1);
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
     MSAE_TLK(kt == 8, 2);
