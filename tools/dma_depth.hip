@@ -10,7 +10,7 @@
 
 template <int N> __device__ __forceinline__ void vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BK, int DEPTH>
+template <int BK, int DEPTH, bool COMPUTE = false>
 __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
                                                      size_t ld, int nM, int nN, int nk) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -38,13 +38,40 @@ __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__rest
   auto stage_seq = [&](long i) {
     if (i < total) stage((int)blockIdx.x + (int)(i / nk) * (int)gridDim.x, (int)(i % nk), (int)(i % DEPTH));
   };
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  typedef int v16i_ __attribute__((ext_vector_type(16)));
+  v16i_ acc[8];
+  if constexpr (COMPUTE) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[q][e] = 0;
+  }
   for (int i = 0; i < DEPTH - 1; ++i) stage_seq(i);
   for (long i = 0; i < total; ++i) {
     vmcnt_le<(DEPTH - 2) * PPW>();          // k-tile i landed (this wave's pieces); the newer ones may be in flight
     __builtin_amdgcn_s_barrier();
     stage_seq(i + DEPTH - 1);
+    if constexpr (COMPUTE) {                // the product's work per 32 bytes of k: 6 fragment reads + 8 MFMAs (128 x 64 per wave)
+      const unsigned char *slot = smem + (int)(i % DEPTH) * SLOT;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        v4i_ f[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          f[q] = *reinterpret_cast<const v4i_ *>(slot + (((wave * 6 + q) * 32 + (lane & 31)) * BK) % SLOT + (((ks * 2 + (lane >> 5)) * 16) % BK));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[q & 3], f[4 + (q >> 2)], acc[q], 0, 0, 0);
+      }
+    }
   }
   vmcnt_le<0>();
+  if constexpr (COMPUTE) {
+    int sx = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sx ^= acc[q][0] ^ acc[q][15];
+    if (sx == 0x7fffffff) smem[0] = 1;
+  }
 }
 
 // Register path for comparison: the same pieces through global_load_dwordx4 -> VGPR (-> ds_write_b128 when WRITE),
@@ -101,11 +128,11 @@ template <int BK, bool WRITE>
 void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps, int *sink);
 
 static int g_grid = 256;
-template <int BK, int DEPTH>
+template <int BK, int DEPTH, bool COMPUTE = false>
 void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps) {
   const int nM = T / 256, nN = N / 256, nk = d / BK;
   const size_t smem = (size_t)DEPTH * 512 * BK;
-  auto kern = stream_kernel<BK, DEPTH>;
+  auto kern = stream_kernel<BK, DEPTH, COMPUTE>;
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
@@ -118,7 +145,8 @@ void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, in
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
   }
   const double bytes = (double)nM * nN * nk * 512.0 * BK;
-  printf("k-tile %3d B x ring %d (%3zu KB LDS, %3d KB in flight): %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n", BK, DEPTH,
+  printf("%sk-tile %3d B x ring %d (%3zu KB LDS, %3d KB in flight): %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n",
+         COMPUTE ? "+reads+MFMA " : "", BK, DEPTH,
          smem >> 10, (DEPTH - 1) * 512 * BK >> 10, best, bytes / best / 1e6 / g_grid, bytes / best / 1e9, best * 1e3 / ((double)nM * nN * d / 128 / g_grid));
 }
 
@@ -158,6 +186,10 @@ int main(int argc, char **argv) {
   run<32, 4>(A, B, T, N, d, 5);
   run<32, 8>(A, B, T, N, d, 5);
   run<128, 2>(A, B, T, N, d, 5);
+  run<128, 2, true>(A, B, T, N, d, 5);
+  run<64, 4, true>(A, B, T, N, d, 5);
+  run<64, 3, true>(A, B, T, N, d, 5);
+  run<128, 2, true>(A, B, T, N, d, 5);
   int *sink; CK(hipMalloc(&sink, 64));
   run_reg<128, false>(A, B, T, N, d, 5, sink);
   run_reg<128, true>(A, B, T, N, d, 5, sink);

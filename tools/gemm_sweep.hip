@@ -36,7 +36,7 @@ template <class C>
 void run(const char *name, Ctx &c, int reps) {
   GemmOperands op{};
   op.A = (const unsigned char *)c.A; op.B = (const unsigned char *)c.B;
-  op.ldA = op.ldB = (size_t)c.d * 2; op.nk = c.d * 2 / 128;   // int8 configs read the same bytes as 2*d int8
+  op.ldA = op.ldB = (size_t)c.d * 2; op.nk = c.d * 2 / C::ROWB;   // int8 configs read the same bytes as 2*d int8
   GemmEpilogue ep{};
   float md = -1.f;
   if (!C::I8) {  // correctness on the small problem (first Ns features) against the naive reference
