@@ -31,7 +31,7 @@ echo "== rescore stats =="
 MSAE_HIP_LIB=tools/bin/libmsae_dbg.so timeout 600 python tools/rescore_stats.py bench trained_like > $OUT/${R}_rescore_stats.txt 2>&1; tail -4 $OUT/${R}_rescore_stats.txt
 echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
-timeout 900 python tools/soak_fused.py --tokens 131072 --N 131072 --d 4096 --out $OUT/${R}_soak_128k_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
+timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
 timeout 900 python tools/soak_fused.py --tokens 131072 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_128k_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
 echo "== shapes / latency / shard emulation / training =="
 timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat $OUT/${R}_other_shapes.txt | grep "T="
