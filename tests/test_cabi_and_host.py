@@ -244,3 +244,33 @@ def test_cache_spill_to_disk_equals_in_memory(tmp_path):
     assert torch.equal(caches[0].feature_locations["model.layers.24"], caches[1].feature_locations["model.layers.24"])
     assert torch.equal(caches[0].feature_activations["model.layers.24"], caches[1].feature_activations["model.layers.24"])
     assert not any(f.endswith(".safetensors") for _, _, fs in __import__("os").walk(tmp_path) for f in fs)
+
+
+def test_shard_helpers_and_argument_checks_without_a_gpu():
+    """Host logic of the feature-sharded group: list sizes, token slices, record size, and the argument checks of the
+    candidate-exchange entry points (they return MSAE_E* codes before touching the device)."""
+    import ctypes
+
+    from msae import _hip
+    from msae.parallel import default_candidates, default_k_loc, token_slice
+
+    assert [default_candidates(32, g) for g in (2, 4, 8)] == [64, 64, 32]
+    assert default_candidates(256, 8) == 128
+    assert [default_k_loc(32, g) for g in (1, 2, 4, 8)] == [32, 32, 23, 14]
+    covered = []
+    for r in range(8):
+        lo, hi, per = token_slice(8195, r, 8)
+        assert per == 1025 and 0 <= lo <= hi <= 8195
+        covered += list(range(lo, hi))
+    assert covered == list(range(8195))
+    lib = _hip.load()
+    assert lib.msae_shard_record_bytes(32) == 32 * 12 + 8 and lib.msae_shard_record_bytes(0) == 0
+    assert lib.msae_rescore_candidates_ws_bytes(1024, 4096, 131072, 32, 8, 32) > 1024 * 4096 * 4
+    assert lib.msae_rescore_candidates_ws_bytes(0, 4096, 131072, 32, 8, 32) == 0
+    null = ctypes.c_void_p(None)
+    # G * C < k, missing records, negative sizes: MSAE_EINVAL (-1); too small a workspace: MSAE_EWS
+    einval = lib.msae_rescore_candidates(null, 2, null, null, null, 4, 4, 4096, 131072, 32, 2, 8, null, -1, 0.0, -1, null, null,
+                                         null, null, 0, null)
+    assert einval < 0
+    assert lib.msae_shard_candidates(null, 2, null, null, null, 4, 4096, 16384, 32, 0, 0, -1, -1, null, null, 0, null) < 0
+    assert lib.msae_error_string(einval).decode()
