@@ -118,7 +118,8 @@ class ShardedSae:
 
             prepared = ops.prepare_encoder(W_enc_shard)
             # every token the kernel cannot verify is recomputed exactly inside the call (status 0 / 1 only)
-            encode_fn = lambda x, kk: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk)
+            encode_fn = lambda x, kk, **ed: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk,
+                                                           **self._local_edits(ed))
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
         self._encode, self._decode = encode_fn, decode_fn
         # mode "candidates": per-shard candidate lists travel, the owner of a token re-scores (module docstring)
@@ -132,11 +133,22 @@ class ShardedSae:
 
                 assert W_enc_full is not None, "mode='candidates' re-scores against the replicated W_enc"
                 prep_c = ops.prepare_encoder(W_enc_shard)
-                cand_fn = lambda x: ops.shard_candidates(x, self.b_enc, self.b_dec, prep_c, self.n_loc, self.k,
-                                                         self.row_offset, self.n_cand)
-                rescore_fn = lambda x, recs, tv: ops.rescore_candidates(x, self.W_enc_full, self.b_enc_full, self.b_dec,
-                                                                        self.k, recs, self.n_cand, tv)
+                cand_fn = lambda x, **ed: ops.shard_candidates(x, self.b_enc, self.b_dec, prep_c, self.n_loc, self.k,
+                                                               self.row_offset, self.n_cand,
+                                                               set_feature=ed.get("set_feature", -1),
+                                                               zero_feature=ed.get("zero_feature", -1))
+                rescore_fn = lambda x, recs, tv, **ed: ops.rescore_candidates(x, self.W_enc_full, self.b_enc_full,
+                                                                              self.b_dec, self.k, recs, self.n_cand, tv, **ed)
             self._cand, self._rescore = cand_fn, rescore_fn
+
+    def _local_edits(self, ed: dict) -> dict:
+        """The hooks' edits name GLOBAL features (features/steering.py:113-114, patching/utils.py:43-48): only the
+        shard that owns one applies it (set_feature then enters the merge once, with its forced value)."""
+        out = dict(ed)
+        for key in ("set_feature", "zero_feature"):
+            f = out.get(key, -1)
+            out[key] = f - self.row_offset if self.row_offset <= f < self.row_offset + self.n_loc else -1
+        return out
 
     def _pack(self, vals: Tensor, idx: Tensor) -> Tensor:
         """[T, kk] (f32, LOCAL i64) -> int32 [2, T, kk] = (value bits, GLOBAL feature id): what travels."""
@@ -170,10 +182,10 @@ class ShardedSae:
         dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
         return self._merge_gathered(flat, T, kk)
 
-    def _encode_candidates(self, x: Tensor):
+    def _encode_candidates(self, x: Tensor, **ed):
         T, G = x.shape[0], self.world
         lo, hi, per = token_slice(T, self.rank, G)
-        recs = self._cand(x)                                            # [T, stride] uint8
+        recs = self._cand(x, **ed)                                      # [T, stride] uint8
         if per * G != T:
             recs = torch.cat((recs, recs.new_zeros(per * G - T, recs.shape[1])))
         send = recs.view(G, per, recs.shape[1])
@@ -182,7 +194,7 @@ class ShardedSae:
         xl = x[lo:hi]
         if hi - lo != per:
             xl = torch.cat((xl, xl.new_zeros(per - (hi - lo), x.shape[1])))
-        vals, idx, status = self._rescore(xl.contiguous(), recv, hi - lo)
+        vals, idx, status = self._rescore(xl.contiguous(), recv, hi - lo, **ed)
         # every rank gets all tokens' results: one all-gather of (value bits | feature id | status) as int32,
         # asynchronous -- forward() decodes this rank's own tokens from (vals, idx) meanwhile
         pack = torch.cat((vals.contiguous().view(torch.int32), idx.to(torch.int32), status.view(-1, 1)), 1).contiguous()
@@ -197,20 +209,27 @@ class ShardedSae:
 
         return join, (vals[: hi - lo], idx[: hi - lo]), pack
 
-    def encode(self, x: Tensor):
-        """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T])."""
+    def encode(self, x: Tensor, set_feature: int = -1, set_value: float = 0.0, zero_feature: int = -1):
+        """-> (top_acts [T,k] f32, top_indices [T,k] int64 GLOBAL feature ids, status [T]).  The optional edits are
+        the hooks' (`latents[:, set_feature] = set_value`, `latents[:, zero_feature] = 0` before the TopK), by global
+        feature id."""
+        ed = {}
+        if set_feature >= 0:
+            ed.update(set_feature=set_feature, set_value=set_value)
+        if zero_feature >= 0:
+            ed.update(zero_feature=zero_feature)
         if not self.collective:
-            return self._encode(x, self.k)
+            return self._encode(x, self.k, **ed)
         if self.mode == "candidates":
-            join, _, _keep = self._encode_candidates(x)
+            join, _, _keep = self._encode_candidates(x, **ed)
             return join()
-        vals, idx, status = self._encode(x, self.k_loc)
+        vals, idx, status = self._encode(x, self.k_loc, **ed)
         mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
             redo = torch.nonzero(flagged).flatten()             # identical on every rank
             if redo.numel():
                 self.second_round_tokens += int(redo.numel())
-                v2, i2, s2 = self._encode(x[redo].contiguous(), self.k)
+                v2, i2, s2 = self._encode(x[redo].contiguous(), self.k, **ed)
                 mv2, mi2, _ = self._gather_merge(v2, i2)
                 mv[redo], mi[redo] = mv2, mi2
                 status = status.clone()
@@ -218,36 +237,36 @@ class ShardedSae:
         return mv, mi, status
 
     @staticmethod
-    def encode_emulated(engines, x: Tensor):
+    def encode_emulated(engines, x: Tensor, **ed):
         """The G ranks of a feature-sharded group executed one after the other in ONE process (one GPU):
         same local encodes, same packs laid out as all_gather_into_tensor would, same merge kernel, same
         truncation check and second round -- only the transport is a torch.cat.  For tests and per-rank
         cost studies on a single-GPU box.  -> (vals, idx, number of second-round tokens)."""
         e0 = engines[0]
         T = x.shape[0]
-        packs = [e._pack(*e._encode(x, e.k_loc)[:2]) for e in engines]
+        packs = [e._pack(*e._encode(x, e.k_loc, **ed)[:2]) for e in engines]
         mv, mi, flagged = e0._merge_gathered(torch.cat(packs, 0), T, e0.k_loc)
         redo = torch.nonzero(flagged).flatten() if e0.k_loc < e0.k else flagged.new_zeros(0, dtype=torch.long)
         if redo.numel():
             xr = x[redo].contiguous()
-            packs = [e._pack(*e._encode(xr, e.k)[:2]) for e in engines]
+            packs = [e._pack(*e._encode(xr, e.k, **ed)[:2]) for e in engines]
             mv2, mi2, _ = e0._merge_gathered(torch.cat(packs, 0), int(redo.numel()), e0.k)
             mv[redo], mi[redo] = mv2, mi2
         return mv, mi, int(redo.numel())
 
     @staticmethod
-    def encode_emulated_candidates(engines, x: Tensor):
+    def encode_emulated_candidates(engines, x: Tensor, **ed):
         """mode="candidates" of a G-rank group executed in ONE process: every shard's records for all tokens, the
         owner-side re-score once per token slice, exactly as the ranks would see them after the all-to-all."""
         G, T = len(engines), x.shape[0]
-        recs = [e._cand(x) for e in engines]                            # G x [T, stride]
+        recs = [e._cand(x, **ed) for e in engines]                      # G x [T, stride]
         outs = []
         for e in engines:
             lo, hi, per = token_slice(T, e.rank, G)
             if hi <= lo:
                 continue
             recv = torch.stack([r[lo:hi] for r in recs]).contiguous()   # [G, hi - lo, stride]
-            outs.append(e._rescore(x[lo:hi].contiguous(), recv, hi - lo))
+            outs.append(e._rescore(x[lo:hi].contiguous(), recv, hi - lo, **ed))
         return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs]))
 
     def decode(self, vals: Tensor, idx: Tensor, gather: bool = True, async_gather: bool = False) -> Tensor:

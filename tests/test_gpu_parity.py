@@ -608,6 +608,34 @@ def test_feature_sharded_candidate_exchange_emulated_on_one_gpu(dev, coarse, G, 
         assert n_fb <= 0.02 * T
 
 
+@pytest.mark.parametrize("mode", ["topk", "candidates"])
+def test_feature_sharded_hook_edits_emulated(dev, mode):
+    """The hooks' edits on a feature-sharded SAE (global feature ids: steering.py:113-114 sets a latent, patching/
+    utils.py:43-48 zeroes one): only the owning shard applies them, and the merged result equals the single-GPU
+    encode with the same edits -- both exchange schemes, G = 4, edits in two different shards."""
+    from msae import ops
+    from msae.parallel import ShardedSae
+
+    d, N, T, k, G = 1024, 65536, 515, 32, 4
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 61)
+    W_dec = torch.zeros(8, d, device=dev)
+    x = _rand_x(dev, T, d, 63)
+    n_loc = N // G
+    engines = [ShardedSae(W_enc[r * n_loc:(r + 1) * n_loc].contiguous(), b_enc[r * n_loc:(r + 1) * n_loc].contiguous(),
+                          W_dec, b_dec, k, rank=r, world=G, mode=mode, W_enc_full=W_enc, b_enc_full=b_enc) for r in range(G)]
+    prepared = ops.prepare_encoder(W_enc)
+    hot = int(ops.pre_acts(x[:1], W_enc, b_enc, b_dec)[0].argmax())          # a feature that IS in the top-k: zero it
+    for ed in (dict(set_feature=n_loc + 77, set_value=12.5), dict(zero_feature=hot),
+               dict(set_feature=3 * n_loc + 5, set_value=0.75, zero_feature=hot)):
+        ev, ei, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k, **ed)
+        if mode == "topk":
+            mv, mi, _ = ShardedSae.encode_emulated(engines, x, **ed)
+        else:
+            mv, mi, st = ShardedSae.encode_emulated_candidates(engines, x, **ed)
+            assert int((st >= 2).sum()) == 0
+        assert torch.equal(mi, ei) and torch.equal(mv, ev), (mode, ed)
+
+
 @pytest.mark.parametrize("T,G,kl,k", [(100, 8, 16, 32), (33, 2, 32, 32), (17, 4, 24, 32), (5, 8, 64, 256)])
 def test_merge_kernel_matches_torch_merge(dev, T, G, kl, k):
     """HIP merge of the all-gathered per-shard pairs == the torch merge used on CPU/gloo (itself
