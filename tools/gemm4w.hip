@@ -5,6 +5,7 @@
 // 2-slot LDS ring, T=8192 N=131072 d=4096; prints us per k-tile and checks a few outputs against a naive reference.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "../multimodal-sae_amd/csrc/gemm_mfma.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -210,6 +211,142 @@ __global__ __launch_bounds__(256) void gemm4w_sched_kernel(const unsigned char *
   }
 }
 
+// ---- v2: accumulators pinned to physical AGPRs (tools/gemm4w_asm.inc), every memory op and wait in inline asm, two
+// staging sets (two k-tiles of loads in flight), branch-free steady state (the loop is unrolled by two) ----------------
+#include "gemm4w_asm.inc"
+__device__ __forceinline__ v4i gld(const unsigned char *p) {
+  v4i v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory"); return v;
+}
+__device__ __forceinline__ void vm_wait16_tied(v4i (&r)[16]) {
+  asm volatile("s_waitcnt vmcnt(16)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) :: "memory");
+}
+__device__ __forceinline__ void vm_wait0_tied(v4i (&r)[16]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) :: "memory");
+}
+template <int IMM> __device__ __forceinline__ void ldsw_i(unsigned addr, const v4i &v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(IMM) : "memory");
+}
+
+template <int MODE>   // 0: the kernel; 1: no staging in the loop (timing only: stale data); 2: no loads, writes only (timing only)
+__global__ __launch_bounds__(256) void gemm4w_v2_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
+                                                        size_t ld, int nM, int nN, int nk, int *__restrict__ out, int N) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr unsigned SLOT = 512 * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int r_in = lane >> 3, c_in = lane & 7;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const unsigned sw = (unsigned)gemm_swz(l31);
+  unsigned offk[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) offk[ks] = (((unsigned)(ks * 2 + kh)) ^ sw) << 4;
+  const unsigned rowA = lds0 + (unsigned)(wr * 128 + l31) * 128u, rowB = lds0 + 256u * 128u + (unsigned)(wc * 128 + l31) * 128u;
+  // this wave stages 128 consecutive rows of one operand: waves 0,1 -> A rows 0-127 / 128-255, waves 2,3 -> B.  Piece p
+  // = rows 8 p .. 8 p + 7 of that range; its LDS image: row * 128 + swizzled chunk.  swz(row + 8) = swz(row) ^ 4, so odd
+  // pieces flip chunk bit 2 (two write addresses, immediate offsets p * 1024 for the rest)
+  const unsigned wbase = lds0 + (wave >= 2 ? 256u * 128u : 0u) + (unsigned)((wave & 1) * 128 + r_in) * 128u;
+  const unsigned wev = wbase + (unsigned)((c_in ^ gemm_swz(r_in)) << 4), wod = wbase + (unsigned)((c_in ^ gemm_swz(r_in + 8)) << 4);
+  for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
+    int tm, tn;
+    gemm_map_tile(tile_id, nM, nN, tm, tn);
+    const unsigned char *src = (wave < 2 ? A + (size_t)(tm * 256 + (wave & 1) * 128 + r_in) * ld
+                                         : B + (size_t)(tn * 256 + (wave & 1) * 128 + r_in) * ld) + c_in * 16;
+    const size_t pstride = 8 * ld;
+    g4w_zero();
+    v4i sa[16], sb[16];
+    auto fetch = [&](v4i (&r)[16], int kt) {
+      const unsigned char *p = src + (size_t)kt * 128;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] = gld(p + q * pstride);
+    };
+    auto put4 = [&](const v4i (&r)[16], unsigned so, auto grp) {       // pieces 4 g .. 4 g + 3 of the set -> slot at so
+      constexpr int g = decltype(grp)::value;
+      ldsw_i<(4 * g + 0) * 1024>(wev + so, r[4 * g + 0]); ldsw_i<(4 * g + 1) * 1024>(wod + so, r[4 * g + 1]);
+      ldsw_i<(4 * g + 2) * 1024>(wev + so, r[4 * g + 2]); ldsw_i<(4 * g + 3) * 1024>(wod + so, r[4 * g + 3]);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // Software-pipelined body of one k-tile.  On entry the fragments of k-steps 0 and 1 of slot `so` are in flight in
+    // (a0, b0) / (a1, b1).  Six groups of 8 MFMAs carry the staging (3 pieces each: wait for them in `ws` -- vmcnt(13):
+    // 13 - 3g older loads of the set + the 3g of this iteration are younger --, write them to slot `sn`, issue the
+    // same pieces' loads of the k-tile after next into `fs`); then every LDS op of the wave is waited for, the
+    // barrier publishes slot `sn`, and the NEXT k-tile's first fragments are read while the last 16 MFMAs run.
+    // STAGE 2: write + fetch, 1: write only, 0: neither; LAST: no next k-tile to read ahead
+    v4i a0[4], b0[4], a1[4], b1[4];
+    auto body = [&](unsigned so, unsigned sn, v4i (&ws)[16], v4i (&fs)[16], int kt, auto stage_tag, auto last_tag) {
+      constexpr int STAGE = decltype(stage_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value != 0;
+      const unsigned char *fp = src + (size_t)(kt + 2) * 128;
+      auto piece = [&](auto qtag) {
+        constexpr int q = decltype(qtag)::value;
+        if constexpr (STAGE >= 1) ldsw_i<q * 1024>((q & 1 ? wod : wev) + sn, ws[q]);
+        if constexpr (STAGE == 2) fs[q] = gld(fp + (size_t)q * pstride);
+      };
+      auto stage3 = [&](auto gtag) {
+        constexpr int g = decltype(gtag)::value;
+        if constexpr (g < 5) {
+          if constexpr (STAGE == 2) asm volatile("s_waitcnt vmcnt(13)" : "+v"(ws[3 * g]), "+v"(ws[3 * g + 1]), "+v"(ws[3 * g + 2]) :: "memory");
+          else if constexpr (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ws[3 * g]), "+v"(ws[3 * g + 1]), "+v"(ws[3 * g + 2]) :: "memory");
+          piece(std::integral_constant<int, 3 * g>()); piece(std::integral_constant<int, 3 * g + 1>());
+          piece(std::integral_constant<int, 3 * g + 2>());
+        } else {
+          if constexpr (STAGE == 2) asm volatile("s_waitcnt vmcnt(15)" : "+v"(ws[15]) :: "memory");
+          else if constexpr (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ws[15]) :: "memory");
+          piece(std::integral_constant<int, 15>());
+        }
+      };
+      using G0 = std::integral_constant<int, 0>; using G1 = std::integral_constant<int, 1>; using G2 = std::integral_constant<int, 2>;
+      using G3 = std::integral_constant<int, 3>; using G4 = std::integral_constant<int, 4>; using G5 = std::integral_constant<int, 5>;
+      // younger than the k-step-0 fragments at this point: the 8 reads of k-step 1
+      lgkm_tied<8>(a0, b0);
+      g4w_mfma8_0(a0[0], a0[1], b0); stage3(G0());
+      g4w_mfma8_1(a0[2], a0[3], b0); stage3(G1());
+      rd8(a0, b0, rowA + so + offk[2], rowB + so + offk[2]);
+      if constexpr (STAGE >= 1) lgkm_tied<14>(a1, b1); else lgkm_tied<8>(a1, b1);     // younger: 6 writes + 8 reads
+      g4w_mfma8_0(a1[0], a1[1], b1); stage3(G2());
+      g4w_mfma8_1(a1[2], a1[3], b1); stage3(G3());
+      rd8(a1, b1, rowA + so + offk[3], rowB + so + offk[3]);
+      if constexpr (STAGE >= 1) lgkm_tied<14>(a0, b0); else lgkm_tied<8>(a0, b0);
+      g4w_mfma8_0(a0[0], a0[1], b0); stage3(G4());
+      g4w_mfma8_1(a0[2], a0[3], b0); stage3(G5());
+      lgkm_tied<0>(a1, b1);                              // k-step 3 fragments AND every write of this wave
+      __builtin_amdgcn_s_barrier();                      // slot sn complete; nobody reads slot so any more after k-step 3's reads
+      if constexpr (!LAST) rd8(a0, b0, rowA + sn + offk[0], rowB + sn + offk[0]);
+      g4w_mfma8_0(a1[0], a1[1], b1);
+      g4w_mfma8_1(a1[2], a1[3], b1);
+      if constexpr (!LAST) rd8(a1, b1, rowA + sn + offk[1], rowB + sn + offk[1]);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+    // prologue: k-tile 0 -> slot 0, k-tile 1 in flight in sa, k-steps 0 / 1 of slot 0 in flight
+    fetch(sa, 0);
+    vm_wait0_tied(sa);
+    put4(sa, 0u, I0()); put4(sa, 0u, I1()); put4(sa, 0u, I2()); put4(sa, 0u, I3());
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fetch(sa, 1);
+    __builtin_amdgcn_s_barrier();
+    rd8(a0, b0, rowA + offk[0], rowB + offk[0]);
+    rd8(a1, b1, rowA + offk[1], rowB + offk[1]);
+    int kt = 0;
+    using SM = std::integral_constant<int, MODE == 0 ? 2 : (MODE == 1 ? 0 : 1)>;
+    for (; kt + 3 < nk; kt += 2) {                     // nk even: pairs (sa = next, sb = after next), then swapped
+      body(0u, SLOT, sa, sb, kt, SM(), S0());
+      body(SLOT, 0u, sb, sa, kt + 1, SM(), S0());
+    }
+    body(0u, SLOT, sa, sb, kt, S1(), S0());             // kt = nk - 2: write the last k-tile, nothing left to fetch
+    body(SLOT, 0u, sb, sa, kt + 1, S0(), S1());         // kt = nk - 1
+    if (tile_id < 2 && lane == 0) {
+      int r[16];
+#define G4W_OUT(B) g4w_read_##B(r); out[16 + tile_id * 64 + wave * 16 + B] = r[0];
+      G4W_OUT(0) G4W_OUT(1) G4W_OUT(2) G4W_OUT(3) G4W_OUT(4) G4W_OUT(5) G4W_OUT(6) G4W_OUT(7)
+      G4W_OUT(8) G4W_OUT(9) G4W_OUT(10) G4W_OUT(11) G4W_OUT(12) G4W_OUT(13) G4W_OUT(14) G4W_OUT(15)
+#undef G4W_OUT
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
 __global__ void fill(unsigned char *p, size_t n, unsigned seed) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
@@ -222,7 +359,7 @@ template <int SETS>
 void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int *out, const signed char *hA, const signed char *hB) {
   const int nM = T / 256, nN = N / 256, nk = d / 128;
   const size_t smem = 2 * 512 * 128;
-  auto kern = SETS == 0 ? gemm4w_sched_kernel : gemm4w_kernel<(SETS ? SETS : 1)>;
+  auto kern = SETS == 0 ? gemm4w_sched_kernel : (SETS == 3 ? gemm4w_v2_kernel<0> : (SETS == 4 ? gemm4w_v2_kernel<1> : (SETS == 5 ? gemm4w_v2_kernel<2> : gemm4w_kernel<(SETS == 2 ? 2 : 1)>)));
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
@@ -262,6 +399,10 @@ int main() {
   CK(hipMemcpy(hBfull, B, (size_t)N * d, hipMemcpyDeviceToHost));
   run<1>(A, B, T, N, d, out, hA, hBfull);
   run<0>(A, B, T, N, d, out, hA, hBfull);     // "0 set(s)" = the hand-scheduled kernel
+  run<3>(A, B, T, N, d, out, hA, hBfull);     // "3 set(s)" = v2: AGPR-pinned accumulators, two staging sets
+  run<4>(A, B, T, N, d, out, hA, hBfull);     // "4": v2 without staging in the loop (outputs wrong by construction)
+  run<5>(A, B, T, N, d, out, hA, hBfull);     // "5": v2 with the LDS writes but without the loads
+  run<3>(A, B, T, N, d, out, hA, hBfull);
   (void)hB;
   return 0;
 }
