@@ -330,6 +330,16 @@ __global__ __launch_bounds__(256) void gemm4w_v2_kernel(const unsigned char *__r
     rd8(a1, b1, rowA + offk[1], rowB + offk[1]);
     int kt = 0;
     using SM = std::integral_constant<int, MODE == 0 ? 2 : (MODE == 1 ? 0 : 1)>;
+    if constexpr (MODE == 3) {                         // MFMAs only: no fragment reads, no barrier, no staging (timing only)
+      lgkm_tied<0>(a0, b0); lgkm_tied<0>(a1, b1);
+      for (; kt + 3 < nk; kt += 2) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+          g4w_mfma8_0(a0[0], a0[1], b0); g4w_mfma8_1(a0[2], a0[3], b0);
+          g4w_mfma8_0(a1[0], a1[1], b1); g4w_mfma8_1(a1[2], a1[3], b1);
+        }
+      }
+    } else
     for (; kt + 3 < nk; kt += 2) {                     // nk even: pairs (sa = next, sb = after next), then swapped
       body(0u, SLOT, sa, sb, kt, SM(), S0());
       body(SLOT, 0u, sb, sa, kt + 1, SM(), S0());
@@ -359,7 +369,7 @@ template <int SETS>
 void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int *out, const signed char *hA, const signed char *hB) {
   const int nM = T / 256, nN = N / 256, nk = d / 128;
   const size_t smem = 2 * 512 * 128;
-  auto kern = SETS == 0 ? gemm4w_sched_kernel : (SETS == 3 ? gemm4w_v2_kernel<0> : (SETS == 4 ? gemm4w_v2_kernel<1> : (SETS == 5 ? gemm4w_v2_kernel<2> : gemm4w_kernel<(SETS == 2 ? 2 : 1)>)));
+  auto kern = SETS == 0 ? gemm4w_sched_kernel : (SETS == 3 ? gemm4w_v2_kernel<0> : (SETS == 4 ? gemm4w_v2_kernel<1> : (SETS == 5 ? gemm4w_v2_kernel<2> : (SETS == 6 ? gemm4w_v2_kernel<3> : gemm4w_kernel<(SETS == 2 ? 2 : 1)>))));
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
@@ -402,6 +412,7 @@ int main() {
   run<3>(A, B, T, N, d, out, hA, hBfull);     // "3 set(s)" = v2: AGPR-pinned accumulators, two staging sets
   run<4>(A, B, T, N, d, out, hA, hBfull);     // "4": v2 without staging in the loop (outputs wrong by construction)
   run<5>(A, B, T, N, d, out, hA, hBfull);     // "5": v2 with the LDS writes but without the loads
+  run<6>(A, B, T, N, d, out, hA, hBfull);     // "6": v2 with MFMAs only
   run<3>(A, B, T, N, d, out, hA, hBfull);
   (void)hB;
   return 0;
