@@ -32,7 +32,7 @@ MSAE_HIP_LIB=tools/bin/libmsae_dbg.so timeout 600 python tools/rescore_stats.py 
 echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
-timeout 900 python tools/soak_fused.py --tokens 131072 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_128k_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
+timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_1M_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
 echo "== shapes / latency / shard emulation / training =="
 timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat $OUT/${R}_other_shapes.txt | grep "T="
 timeout 300 python tools/latency_small_T.py > $OUT/${R}_latency_small_T.txt 2>&1; grep "T=" $OUT/${R}_latency_small_T.txt
