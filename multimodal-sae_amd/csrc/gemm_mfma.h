@@ -495,6 +495,53 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
         // round trip whenever ANY lane of the wave has one (27 % of the elements): 0.55 ms of the pass.  So
         // the 16 outputs of this lane's column are tested branch-free -- count, last survivor's value and
         // position -- and the lane reserves its queue slots with ONE LDS atomic per 16 outputs.
+#ifdef MSAE_EPI_BALLOT
+        // wave-level bookkeeping: the 16 tests leave 16 lane masks in SGPRs; their population counts, the ONE LDS
+        // atomic of the wave and the slot of every survivor (mbcnt) come from those masks on the scalar unit, so the
+        // hot loop carries no per-lane counters at all
+        float v[16];
+        bool hit[16];
+        unsigned long long m[16], any = 0ull;
+        const unsigned long long live_m = __builtin_amdgcn_ballot_w64(c_live[j]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = value(e);
+          hit[e] = __builtin_fmaf(c_h[j], bt[e], v[e]) > tau[e];
+          m[e] = __builtin_amdgcn_ballot_w64(hit[e]) & live_m;               // the compare's own lane mask
+          any |= m[e];
+        }
+        if (any) {                                                            // wave-uniform
+          unsigned total = 0;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) total += (unsigned)__builtin_popcountll(m[e]);
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(q_count, total);                    // LDS atomic, one per wave and column block
+          base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if (m[e]) {                                                       // wave-uniform
+              if (hit[e] && c_live[j]) {
+                unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[e], 0u));
+                const int row = row_of(e);
+                if (slot < QCAP) {
+                  queue[slot] = ((unsigned long long)__float_as_uint(v[e]) << 32) | (unsigned)(row << 16 | col);
+                } else {                                                      // queue full: slow path
+                  const float u = v[e] + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
+                  if (u > row_c[row]) {
+                    const int t = m0 + row;
+                    const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+                    const int gslot = atomicAdd(ep.cnt + t, 1);
+                    if (gslot < ep.cap)
+                      ep.cand[(size_t)t * ep.cap + gslot] =
+                          ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+                  }
+                }
+              }
+              base += (unsigned)__builtin_popcountll(m[e]);
+            }
+          }
+        }
+#else
         unsigned cnt = 0;
         float hv = 0.f;
         int he = 0;
@@ -536,6 +583,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
             }
           }
         }
+#endif
       }
     }
   }
