@@ -535,6 +535,7 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["fast_path_verified_frac"] > 0.99
     assert "error" not in res and "feature-sharded" in res["config"]["parallelism"]
+    assert res["headline"].startswith("feature-sharded") and res["scaling"] == "strong"
     assert res["sharded_bit_identical_to_single_gpu_on_256_tokens"] is True
     modes = res["shard_modes"]          # both exchange schemes ran on RCCL (all-gather; all-to-all) and agree
     assert modes["per_shard_topk"]["bit_identical_256"] is True
