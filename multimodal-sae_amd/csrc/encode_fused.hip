@@ -602,7 +602,17 @@ __device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, f
 // overflowed their list / have tau <= 0 / more than r_max rows to read) go to the exact path.
 // EXT: the list is the union of the shards' records; keys[] then carries the list POSITION in its low word
 // (feature and z sigma are looked up by position: ef[], ezs[]).
-template <int NW, bool EXT = false>   // waves per token: 1 for k <= 64, 4 for larger k (longer lists, more rows per round)
+#ifdef MSAE_RESCORE_TL   // tuning builds (tools/rescore_timeline.py): s_memtime stamps of thread 0 of the first 64 tokens
+__device__ unsigned long long g_rs_tl[64 * 16];
+#define MSAE_RTL(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (slot) < 16) g_rs_tl[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MSAE_RTL(slot) do { } while (0)
+#endif
+// LDSA (small batches, p.lpr > 1): the token's activations are copied to LDS once and every lane reads the 16 B that
+// belong to ITS piece of the row (ds_read_b128, counted waits) -- the scalar loads of the default path return out of
+// order, so each pair of them is a full lgkmcnt(0) round trip (128 per pass), which nothing hides when a token's
+// waves are alone on their SIMDs.
+template <int NW, bool EXT = false, bool LDSA = false>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
 __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -611,6 +621,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   unsigned long long *res = keys + p.cap;
   [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
   [[maybe_unused]] int *ef = reinterpret_cast<int *>(ezs + p.cap);        // EXT only: [cap] global feature by position
+  [[maybe_unused]] float *a_lds = EXT ? reinterpret_cast<float *>(ef + p.cap) : ezs;   // LDSA only: [d]
   constexpr int NT = 64 * NW;
   __shared__ float s_cc[NT], s_zs[NT], s_pick[2];
   __shared__ int s_n;
@@ -620,7 +631,12 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   if constexpr (EXT) { if (t >= p.ext_valid) return; }
   int cnt, n;
   float tau;
+  MSAE_RTL(0);
   const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
+  if constexpr (LDSA) {                                   // published by the barriers of the list sort below
+    for (int i = 4 * (int)threadIdx.x; i < p.d; i += 4 * 64 * NW)
+      *reinterpret_cast<f32x4 *>(a_lds + i) = *reinterpret_cast<const f32x4 *>(a + i);
+  }
   f32x4 rc = {0.f, 0.f, 0.f, 0.f};
   const bool i8 = p.i8 != 0;
   int np;
@@ -662,7 +678,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
   }
   for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
+  MSAE_RTL(1);
   wave_sort_desc_u64<NT>(keys, np, lane);   // upper value desc (index asc on ties)
+  MSAE_RTL(2);
   const int has_set = p.set_feature >= 0 ? 1 : 0;
   if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
 
@@ -670,7 +688,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const int lim = n < p.r_max ? n : p.r_max;
   int target = lim;
   {
-    const int mt = n < NT ? n : NT;
+    const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
+    const int mt = n < mt_max ? n : mt_max;
     float my_cc = -__builtin_inff(), my_zs = 0.f;
     if (lane < mt) {
       const unsigned long long key = keys[lane];
@@ -701,7 +720,13 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       target = n1 < lim ? n1 : lim;
     }
   }
+  if constexpr (LDSA) {   // small batch: one pass reads 64 NW / lpr rows whatever the target -- fill it (fewer second rounds)
+    const int rpp = p.lpr > 0 ? NT / p.lpr : NT;
+    const int fill = rpp < lim ? rpp : lim;
+    if (target < fill) target = fill;
+  }
 
+  MSAE_RTL(3);
   const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
   bool ok = false, viol = false;
@@ -744,13 +769,22 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         auto consume = [&](const f32x4 (&src)[RS_U], int kk) {
 #pragma unroll
           for (int u = 0; u < RS_U; ++u) {
+            [[maybe_unused]] f32x4 av;                   // LDSA: the activations of this lane's own piece
+            if constexpr (LDSA) av = *reinterpret_cast<const f32x4 *>(a_lds + kk + 4 * LPR * u + 4 * q);
 #pragma unroll
             for (int qq = 0; qq < LPR; ++qq) {
               const int k0 = kk + 4 * LPR * u + 4 * qq;
-              acc = __builtin_fmaf(a[k0 + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
-              acc = __builtin_fmaf(a[k0 + 1], src[u][1], acc);
-              acc = __builtin_fmaf(a[k0 + 2], src[u][2], acc);
-              acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
+              if constexpr (LDSA) {                      // only sub-step qq == q carries the true partial sum
+                acc = __builtin_fmaf(av[0], src[u][0], acc);
+                acc = __builtin_fmaf(av[1], src[u][1], acc);
+                acc = __builtin_fmaf(av[2], src[u][2], acc);
+                acc = __builtin_fmaf(av[3], src[u][3], acc);
+              } else {
+                acc = __builtin_fmaf(a[k0 + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
+                acc = __builtin_fmaf(a[k0 + 1], src[u][1], acc);
+                acc = __builtin_fmaf(a[k0 + 2], src[u][2], acc);
+                acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
+              }
               if constexpr (LPR == 4)   // quad_perm:[3,0,1,2] -- lane i takes lane i - 1's value, lane 0 lane 3's
                 acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xF, 0xF, false));
               if constexpr (LPR == 2)   // quad_perm:[1,0,3,2] -- the two lanes of a pair swap
@@ -788,7 +822,12 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     else run_pass(std::integral_constant<int, 1>());
     done = target;
     viol = viol || (__syncthreads_or(my_viol) != 0);
-    wave_sort_desc_u64<NT>(res, nrp, lane);
+    MSAE_RTL(2 + 2 * rounds);
+    {   // res[] is zero (= empty, the smallest key) behind the slots written so far: sort the filled prefix only
+      const int filled = next_pow2(done + has_set > 2 ? done + has_set : 2);
+      wave_sort_desc_u64<NT>(res, filled < nrp ? filled : nrp, lane);
+    }
+    MSAE_RTL(3 + 2 * rounds);
     const bool have_k = done + has_set >= p.k;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
     const int needed = have_k ? count_ge(keys, n, v_k) : n;     // candidates with u >= v_k
@@ -799,6 +838,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     __syncthreads();
   }
 
+  MSAE_RTL(14);
+#ifdef MSAE_RESCORE_TL
+  if (threadIdx.x == 0 && blockIdx.x < 64) g_rs_tl[blockIdx.x * 16 + 15] = ((unsigned long long)rounds << 32) | (unsigned)done;
+#endif
   for (int j = lane; j < p.k; j += NT) {
     const unsigned long long key = res[j];
     const int fi = key ? rank_key_index(key) : 0;
@@ -923,15 +966,18 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
                                  hipStream_t s) {
   int nw;
   rescore_shape(T, k, nw, ra.lpr);
-#define MSAE_RS_LAUNCH(NWV)                                                                                          \
+  const bool ldsa = ra.lpr > 1 && smem + (size_t)ra.d * 4 <= 96 * 1024;      // small batch: activations in LDS
+  if (ldsa) smem += (size_t)ra.d * 4;
+#define MSAE_RS_LAUNCH(NWV, LDSAV)                                                                                   \
   do {                                                                                                               \
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT>,                                  \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT, LDSAV>,                           \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                        \
-    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);         \
+    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
   } while (0)
-  if (nw == 1) MSAE_RS_LAUNCH(1);
-  else if (nw == 2) MSAE_RS_LAUNCH(2);
-  else MSAE_RS_LAUNCH(4);
+  if (ldsa) { if (nw == 2) MSAE_RS_LAUNCH(2, true); else MSAE_RS_LAUNCH(4, true); }
+  else if (nw == 1) MSAE_RS_LAUNCH(1, false);
+  else if (nw == 2) MSAE_RS_LAUNCH(2, false);
+  else MSAE_RS_LAUNCH(4, false);
 #undef MSAE_RS_LAUNCH
   return 0;
 }
@@ -1827,6 +1873,12 @@ extern "C" int msae_set_guard_z(float z) {
 extern "C" int msae_debug_timeline(unsigned long long *host_out) {   // tuning builds only (tools/gemm_timeline.py)
   if (!g_timeline) return MSAE_EINVAL;
   return (int)hipMemcpy(host_out, g_timeline, 64 * 8 * 8, hipMemcpyDeviceToHost);
+}
+#endif
+
+#ifdef MSAE_RESCORE_TL
+extern "C" int msae_debug_rescore_timeline(unsigned long long *host_out) {   // tuning builds only (tools/rescore_timeline.py)
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rs_tl), 64 * 16 * 8);
 }
 #endif
 
