@@ -10,7 +10,7 @@ src, dst = sys.argv[1], sys.argv[2]
 d = json.load(open(src))
 KEYS = {"gemm_kernel<int8,THRESH>": ("gemm_kernel<GemmCfg<256, 256, 2, 2, 4, true, 0>, false>",),
         "gemm_kernel<bf16,THRESH>": ("gemm_kernel<GemmCfg<256, 256, 2, 2, 4, false, 0>, false>",),
-        "select_rescore_kernel": ("select_rescore_kernel<1>", "select_rescore_kernel<1, false>"), "decode_fwd_v4_kernel": ("decode_fwd_v4_kernel",)}
+        "select_rescore_kernel": ("select_rescore_kernel<1>", "select_rescore_kernel<1, false"), "decode_fwd_v4_kernel": ("decode_fwd_v4_kernel",)}
 out = {}
 for name, pats in KEYS.items():
     for k, v in d.items():
