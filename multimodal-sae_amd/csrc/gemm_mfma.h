@@ -733,7 +733,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   const int pf_wi = (m0 / C::BM) & 7, pf_wj = (n0 / C::BN) & 3;         // position inside the XCD's 8 x 4 super-tile
   const int pf_row = pf_a ? pf_wj * 64 + wave * 16 : pf_wi * 32 + (wave - 4) * 8;   // first row inside the tile
   const unsigned pf_voff = (unsigned)(lane & (pf_a ? 15 : 7)) * (unsigned)op.ldA;
-  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + C::LDS_BYTES - C::PF_SINK_BYTES);
+#ifdef MSAE_GEMM_WARM   // (the pointer is made opaque first: the cast of a KNOWN LDS global folds into an instruction the backend
+  unsigned char *sink_p = smem + C::LDS_BYTES - C::PF_SINK_BYTES;        // rejects, "V_CMP_NE_U32 0, src_shared_base")
+  asm volatile("" : "+s"(sink_p));
+  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)sink_p;
+#else
+  const unsigned pf_sink = 0;
+#endif
   auto warm = [&](int tm0, int tn0, int kmain) {         // main k-tile index (>= 0) of the tile at (tm0, tn0)
     const unsigned char *base = pf_a ? op.A + (size_t)(tm0 + pf_row) * op.ldA : op.B + (size_t)(tn0 + pf_row) * op.ldB;
     gemm_warm_l2(base + (size_t)kmain * C::ROWB, pf_voff, pf_sink);
