@@ -675,11 +675,78 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
     rc = p.rowc[t];
     np = next_pow2(n > 2 ? n : 2);
-    for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
   }
   for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
   MSAE_RTL(1);
-  wave_sort_desc_u64<NT>(keys, np, lane);   // upper value desc (index asc on ties)
+  // keys[0, n_sorted) hold the n_sorted largest keys in descending order (upper value desc, index asc on ties).
+  // PARTIAL: of a list of ~650 candidates a token uses the first 40-60, so one wave first SELECTS its PRE_LO..PRE_HI
+  // largest (keys in registers, bisection on the value word with ballot counts, a handful of steps) and sorts only
+  // those 128 slots; whoever then needs a candidate behind them (count_needed, the target check of a round) gets the
+  // full sort after all -- the presorted prefix is the same keys in the same places.
+  constexpr int PRE_LO = 96, PRE_HI = 128, PRE_MIN = 192, PRE_PK = 32;
+  int n_sorted = n;
+  bool partial = false;
+  auto full_sort = [&]() {
+    if constexpr (!EXT) {
+      __syncthreads();
+      for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+    }
+    wave_sort_desc_u64<NT>(keys, np, lane);
+  };
+  if constexpr (!EXT && NW == 1) {
+#ifndef MSAE_RESCORE_NO_PRESELECT
+    if (n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
+      const int nj = (n + 63) >> 6;
+      unsigned long long kreg[PRE_PK];
+#pragma unroll
+      for (int j = 0; j < PRE_PK; ++j) {
+        const int i = j * 64 + lane;
+        kreg[j] = (j < nj && i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+      }
+      unsigned lo = 0u, hi = 0xFFFFFFFFu;     // count(value word >= lo) > PRE_HI, count(>= hi) < PRE_LO
+      int c_sel = -1;
+      unsigned thr = 0u;
+      while (hi - lo > 1u) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int jb = 0; jb < PRE_PK; jb += 8) {             // one branch per eight key slots (empty slots hold 0)
+          if (jb < nj) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j)
+              c += __builtin_popcountll(__builtin_amdgcn_ballot_w64((unsigned)(kreg[j] >> 32) >= mid));
+          }
+        }
+        if (c > PRE_HI) lo = mid;
+        else if (c < PRE_LO) hi = mid;
+        else { c_sel = c; thr = mid; break; }
+      }
+      if (c_sel > 0) {                                       // (ties across the window: no such threshold -> full sort)
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < PRE_PK; ++j) {
+          if (j < nj) {
+            const bool take = (unsigned)(kreg[j] >> 32) >= thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            if (take) keys[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = kreg[j];
+            base += __builtin_popcountll(m);
+          }
+        }
+        for (int i = c_sel + lane; i < PRE_HI; i += NT) keys[i] = 0ull;
+        wave_sort_desc_u64<NT>(keys, PRE_HI, lane);
+        partial = true;
+        n_sorted = c_sel;
+      }
+    }
+#endif
+  }
+  if (!partial) full_sort();
+  auto need_full = [&]() { full_sort(); partial = false; n_sorted = n; };
+  auto count_needed = [&](float v) {         // candidates with u >= v (over the whole list)
+    int c = count_ge(keys, n_sorted, v);
+    if (partial && c >= n_sorted) { need_full(); c = count_ge(keys, n, v); }
+    return c;
+  };
   MSAE_RTL(2);
   const int has_set = p.set_feature >= 0 ? 1 : 0;
   if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
@@ -715,7 +782,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     __syncthreads();
     if (kk >= 1 && kk <= mt && p.z2 > 0.f) {
       const float thr1 = s_pick[0] - GUARD_ZETA * s_pick[1] * __builtin_amdgcn_rsqf(p.z2);
-      int n1 = count_ge(keys, n, thr1);
+      int n1 = count_needed(thr1);
       if (n1 < p.k + 4) n1 = p.k + 4;
       target = n1 < lim ? n1 : lim;
     }
@@ -814,6 +881,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // 512 B in flight = 32 round trips, ~60 us whatever the load); four lanes per row carry 2 KB in flight each.
     // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
     // p.lpr lanes per row and as many waves per token.
+    if (partial && target > n_sorted) need_full();          // wave-uniform
     const bool few = rounds > 1 && target - done <= NT / 4;
     int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
     while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
@@ -830,7 +898,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     MSAE_RTL(3 + 2 * rounds);
     const bool have_k = done + has_set >= p.k;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
-    const int needed = have_k ? count_ge(keys, n, v_k) : n;     // candidates with u >= v_k
+    const int needed = have_k ? count_needed(v_k) : n;          // candidates with u >= v_k
     ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f;
     if (ok || viol || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
     target = needed > done ? needed : done + 1;
@@ -1958,18 +2026,10 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
 }
 
-// 17 .. 32 tokens: two passes of the MFMA weight stream (<= 16 tokens each, 2 x ~0.1 ms) beat the padded 256-row tile
-static bool small_chunked(int T, int d, int N, int k, const FusedPlan &pl) {
-  return pl.fast && pl.i8 && !pl.small && T > SMALL_T_MAX && T <= 2 * SMALL_T_MAX && d <= 4096 &&
-         small_shape_ok(SMALL_T_MAX, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
-}
-
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k) {
   if (T <= 0 || d <= 0 || N <= 0 || k <= 0) return 0;
   const FusedPlan pl = make_plan(T, d, N, k);
-  size_t b = pl.bytes;
-  if (small_chunked(T, d, N, k, pl)) { const size_t c = make_plan(SMALL_T_MAX, d, N, k).bytes; b = c > b ? c : b; }
-  return b;
+  return pl.bytes;
 }
 
 static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
@@ -2006,25 +2066,6 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
   if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || !msae_aligned(W_enc, 16) ||
       (b_dec && !msae_aligned(b_dec, 16)))
     return MSAE_EALIGN;
-  if (small_chunked(T, d, N, k, pl)) {
-    const size_t esz = x_dtype == MSAE_F32 ? 4 : 2;
-    for (int t0 = 0; t0 < T; t0 += SMALL_T_MAX) {
-      const int Tc = T - t0 < SMALL_T_MAX ? T - t0 : SMALL_T_MAX;
-      const FusedPlan pc = make_plan(Tc, d, N, k);
-      if (!pc.small || pc.bytes > ws_bytes) return MSAE_EWS;
-      const void *xc = static_cast<const unsigned char *>(x) + (size_t)t0 * d * esz;
-      const IdxOut ic{idx.i32 ? idx.i32 + (size_t)t0 * k : nullptr, idx.i64 ? idx.i64 + (size_t)t0 * k : nullptr};
-      int32_t *sc = status ? status + t0 : nullptr;
-      int rc;
-      switch (x_dtype) {
-        case MSAE_F32: rc = run_small<MSAE_F32>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
-        case MSAE_BF16: rc = run_small<MSAE_BF16>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
-        default: rc = run_small<MSAE_F16>(xc, W_enc, b_enc, b_dec, pp, pb, Tc, d, N, k, set_feature, set_value, zero_feature, vals + (size_t)t0 * k, ic, sc, wsb, pc, s); break;
-      }
-      if (rc) return rc;
-    }
-    return 0;
-  }
   if (pl.small) {
     switch (x_dtype) {
       case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);

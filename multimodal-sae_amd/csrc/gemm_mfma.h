@@ -713,6 +713,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 #else
   const bool lead_compact = false;
 #endif
+  // ONE row of output tiles (T <= BM): all workgroups read the SAME A tile, and walking its k-tiles in step they ask
+  // the same few L2 lines at the same moment.  Integer accumulation does not depend on the order, so each workgroup
+  // starts its k-walk at its own k-tile (the 32 workgroups of an XCD at 32 different ones) and wraps around.
+#ifndef MSAE_GEMM_NO_KROT
+  const int krot = (C::I8 && nM == 1) ? (int)(gridDim.x >= 64 ? blockIdx.x >> 3 : blockIdx.x) % op.nk : 0;   // (few tiles: the sample pass)
+#else
+  const int krot = 0;
+#endif
   auto stage = [&](int tm0, int tn0, int tile, int slot) {
     if (tile < lead) {
       if constexpr (C::I8) {
@@ -724,7 +732,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       gemm_stage_pieces<C, 4>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave * 4, sl_main);
       gemm_fetch_b<C>(bregs, op.B, op.ldB, tn0, (size_t)(tile - lead) * C::ROWB, wave, sl_main);
 #else
-      gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave, sl_main);
+      int kq = tile - lead + krot;                         // (a select, no control flow: see gemm_stage_pieces)
+      kq -= kq >= op.nk ? op.nk : 0;
+      gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)kq * C::ROWB, smem, slot, wave, sl_main);
 #endif
     }
   };

@@ -83,6 +83,29 @@ def test_fused_equals_exact_on_heterogeneous_weights(dev, coarse, kind):
     _compare(ops, x, W, b, bd, k, f"{kind}/{coarse} d={d} N={N} T={T}")
 
 
+@pytest.mark.parametrize("cluster", [160, 230])
+def test_cluster_of_near_duplicates_needs_more_than_the_presorted_prefix(dev, coarse, cluster):
+    """select_rescore presorts only the ~100-128 largest candidates of a token's list.  Here `cluster` features are
+    copies of one direction scaled by 1 + 1e-4 j and every token points along it: their exact values are distinct
+    but closer together than the error band, so all of them have u >= v_k and the token needs `cluster` re-scored
+    rows -- the full sort has to be taken after all, and the result must still be the exact path's."""
+    from msae import ops
+
+    d, N, T, k = 1024, 32768, 4096, 32     # T large enough for the one-wave-per-token kernel (rescore_shape)
+    W, b, bd = hostile.weights("gauss", N, d, dev, seed=11)
+    g = torch.Generator(device=dev).manual_seed(77)
+    base = torch.randn(d, generator=g, device=dev)
+    base /= base.norm()
+    rows = torch.randperm(N, generator=g, device=dev)[:cluster]
+    scale = 1.0 + 1e-4 * torch.arange(cluster, device=dev, dtype=torch.float32)
+    W[rows] = base[None, :] * scale[:, None]
+    b[rows] = 0.0
+    x = torch.randn(T, d, generator=g, device=dev) + 6.0 * base[None, :]
+    x = (x + bd).to(torch.bfloat16)
+    hist = _compare(ops, x, W.contiguous(), b, bd, k, f"cluster{cluster}/{coarse}", max_fallback=1.0)
+    assert hist["verified"] >= 0.9 * T, hist      # <= r_max = 8 k rows: still the fused path, not the exact fallback
+
+
 @pytest.mark.parametrize("k", [1, 2, 32, 256])
 def test_trained_like_full_width(dev, coarse, k):
     """configs[1] width with everything at once: log-normal norms, correlated rows, spikes, dead block,
