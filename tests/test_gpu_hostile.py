@@ -122,7 +122,8 @@ def test_trained_like_full_width(dev, coarse, k):
 def test_small_T_path_equals_exact(dev, T):
     """The S = 1 path (steering decode steps, features/steering.py:86,105-124): T <= 16 tokens take the weight-
     streaming encoder (two-plane int8 activations; dot4 for T <= 4, the 16x16x64 MFMA stream above; row-per-wave
-    exact re-score).  Bit-identical to the exact path on trained-like weights at full width, including the hooks'
+    exact re-score); 17 and 32 tokens take the padded MFMA tile with the small-batch re-score (4 lanes per row,
+    activations in LDS).  Bit-identical to the exact path on trained-like weights at full width, including the hooks'
     edits, for 64 different inputs."""
     from msae import ops
 
