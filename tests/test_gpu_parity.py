@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+import hostile
 import synth
 from oracle import oracle
 
@@ -508,6 +509,42 @@ def test_cpu_tensors_raise(dev):
 
     with pytest.raises(RuntimeError):
         ops.topk(torch.zeros(2, 8), 2)
+
+
+@pytest.mark.parametrize("T", [1, 8, 200])
+def test_encode_and_decode_replay_from_a_hip_graph(dev, T):
+    """The entry points allocate nothing and never synchronise (include/msae.h), so a caller may capture them into a
+    HIP graph: a captured encode + decode, replayed on new inputs written into the captured buffer, must equal the
+    eager calls bit for bit (small-T weight stream and padded-tile path)."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W, b, bd = hostile.weights("trained_like", N, d, dev, seed=31)
+    Wd = (W / (W.norm(dim=1, keepdim=True) + 1e-6)).contiguous()
+    prep = ops.prepare_encoder(W)
+    xs_all = hostile.activations(3 * T, d, dev, seed=32)
+    xs = xs_all[:T].clone()
+
+    def step(inp):
+        v, i, st = ops.encode_topk(inp, W, b, bd, prep, k)
+        return v, i, st, ops.decode(i, v, Wd, bd)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(xs)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = step(xs)
+    for c in range(3):
+        xs.copy_(xs_all[c * T:(c + 1) * T])
+        g.replay()
+        torch.cuda.synchronize()
+        ref = step(xs_all[c * T:(c + 1) * T].contiguous())
+        for a, r in zip(out, ref):
+            assert torch.equal(a, r)
 
 
 def test_bench_under_torchrun_with_rccl_collectives(dev):
