@@ -212,15 +212,17 @@ def main():
         torch.cuda.synchronize()
         dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(steps)]
+        prof = None
         if profile:   # stage events are recorded on the launch stream during the timed region
-            lib.msae_profile_begin(steps)
+            prof = ops.StageProfile(steps)
             eng.decode_events, eng.decode_event_i = dec_ev, 0
         if ddp:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            out = eng.forward(xin, async_gather=eng.collective)
+        with ops.profiling(prof):
+            for _ in range(steps):
+                out = eng.forward(xin, async_gather=eng.collective)
         eng.synchronize()
         torch.cuda.synchronize()
         if ddp:
@@ -228,10 +230,8 @@ def main():
         el = time.perf_counter() - t0
         stage, dec_ms = np.zeros((0, 6)), float("nan")
         if profile:
-            buf = (ctypes.c_float * (steps * 6))()
-            n_steps = ctypes.c_int(0)
-            lib.msae_profile_end(buf, ctypes.byref(n_steps))
-            stage = np.array(buf[:]).reshape(steps, 6)[: n_steps.value]
+            stage = prof.read().astype(np.float64)
+            prof.close()
             if eng.decode_event_i:
                 dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev[: eng.decode_event_i]]))
             eng.decode_events = None

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MSAE_ABI_VERSION 1
+#define MSAE_ABI_VERSION 2
 
 /* element type of the activation tensor x handed over by the LLM hook (sae.py:174 up-casts) */
 enum { MSAE_F32 = 0, MSAE_BF16 = 1, MSAE_F16 = 2 };
@@ -58,6 +58,33 @@ enum {
   MSAE_EWS = -3,      /* workspace too small */
   MSAE_ENOTIMPL = -4  /* shape outside what this build supports */
 };
+
+/* ---- per-call options of the fused encoder ---------------------------------------------------------
+ * The library keeps NO mutable process state: what used to be msae_set_coarse_mode / msae_set_guard_z /
+ * msae_set_status_detail / msae_profile_begin (ABI 1) travels with the call.  Zero-initialise, set `size`,
+ * fill what you need; NULL wherever a `const msae_options *` is taken means "all defaults".  Calls with
+ * different options may run concurrently from different threads / streams.
+ *   coarse_mode   operand type of the candidate pass: MSAE_COARSE_INT8 (per-token / per-feature scales, massive-
+ *                 activation dims in a separately scaled k-tile), MSAE_COARSE_BF16, or MSAE_COARSE_DEFAULT
+ *                 (environment MSAE_COARSE=bf16|int8, else int8).  Either way the candidates are re-scored with
+ *                 the exact f32 chain, so outputs do not depend on it; the workspace size does (pass the same
+ *                 options to the *_ws_bytes helper).
+ *   guard_z       width z of the candidate pass's error band in standard deviations of its per-(token, feature)
+ *                 rounding noise; 0 = default (environment MSAE_GUARD_Z, else 7); 0.25 <= z <= 64.  A larger z
+ *                 re-scores more rows per token; results of verified tokens do not depend on it.
+ *   status_detail diagnostics (tools/soak_fused.py): a token recomputed inside the call reports
+ *                 status = 1 | reason << 8 (reason bits below) instead of 1, so `status & 0xFF` is the code.
+ *   profile       a handle from msae_profile_create (stage timing, below) or NULL. */
+enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1 };
+typedef struct msae_options {
+  uint32_t size;          /* sizeof(msae_options) of the caller's header */
+  int32_t coarse_mode;    /* MSAE_COARSE_* */
+  float guard_z;          /* 0 = default */
+  int32_t status_detail;  /* 0 / 1 */
+  void *profile;          /* msae_profile_create handle or NULL */
+} msae_options;
+/* Fills *opts with the defaults (coarse_mode MSAE_COARSE_DEFAULT, guard_z 0, no detail, no profile). */
+void msae_options_init(msae_options *opts);
 
 int msae_abi_version(void);
 const char *msae_error_string(int code);
@@ -86,20 +113,10 @@ int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_
 size_t msae_encoder_prepared_bytes(int N, int d);
 int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream);
 /* Same buffer after a weight update (one training step): rebuilds only the operands that the coarse
- * mode in force (msae_set_coarse_mode) reads -- the other mode's operands go stale, so call
- * msae_encoder_prepare again before switching modes. */
-int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void *stream);
-
-/* Operand type of the fused encoder's candidate pass: 1 = int8 MFMA (default: per-token / per-feature
- * scales, massive-activation dims in a separately scaled k-tile), 0 = bf16 MFMA.  Either way the
- * candidates are re-scored with the exact f32 chain, so outputs do not depend on the choice.  The
- * environment variable MSAE_COARSE=bf16|int8 sets the initial value.  Changes the workspace size. */
-int msae_set_coarse_mode(int mode);
-
-/* Width z of the error band of the candidate pass, in standard deviations of its per-(token,
- * feature) rounding noise (default 7; 0.25 <= z <= 64; environment MSAE_GUARD_Z sets the initial value).
- * A larger z re-scores more rows per token; results of verified tokens do not depend on it. */
-int msae_set_guard_z(float z);
+ * mode of `opts` reads -- the other mode's operands go stale, so call msae_encoder_prepare again before
+ * encoding in the other mode. */
+int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const msae_options *opts,
+                         void *stream);
 
 /* Fused Sae.encode: vals/idx[T][k] = canonical top-k of relu((x - b_dec) W_enc^T + b_enc), with
  * the reference hooks' edits of the dense latents applied before TopK:
@@ -111,20 +128,17 @@ int msae_set_guard_z(float z);
  * Values >= 2 exist only between the kernels of one call: 2 | reason bits (4 list overflow, 8
  * threshold <= 0, 16 fewer than k candidates, 32 too many rows inside the band, 64 a re-scored pair
  * was more than 6 sigma from its coarse value: the error model does not describe this token). */
-size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k);
-/* Diagnostics (tools/soak_fused.py): with detail on, a token recomputed inside the call reports
- * status = 1 | reason << 8 (reason = the bits above) instead of 1, so `status & 0xFF` is the code. */
-int msae_set_status_detail(int on);
+size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,
                      int set_feature, float set_value, int zero_feature, float *vals, int32_t *idx,
-                     int32_t *status, void *ws, size_t ws_bytes, void *stream);
+                     int32_t *status, void *ws, size_t ws_bytes, const msae_options *opts, void *stream);
 /* The same call writing 64-bit indices (EncoderOutput.top_indices is int64 in the reference: Tensor.topk,
  * sae.py:179-181); saves the widening pass on the latency path (one decode step of steering). */
 int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                          const float *b_dec, const void *prepared, int T, int d, int N, int k,
                          int set_feature, float set_value, int zero_feature, float *vals, int64_t *idx,
-                         int32_t *status, void *ws, size_t ws_bytes, void *stream);
+                         int32_t *status, void *ws, size_t ws_bytes, const msae_options *opts, void *stream);
 
 /* ---- feature-sharded group (BASELINE configs[2]: "per-shard TopK + RCCL merge over xGMI") ------
  * The encoder's feature axis is split over G ranks; every rank sees the same T tokens.  Re-scoring a local top-k
@@ -133,7 +147,8 @@ int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const f
  *                            by upper value u as one record of msae_shard_record_bytes(C) bytes:
  *                            uint64 key[C] (order key of u << 32 | 0x7FFFFFFF - GLOBAL feature id, 0 = empty),
  *                            float z_sigma[C], float tau (largest u any OTHER feature of the shard can have; +inf when
- *                            the shard cannot bound it), float 0.  ws as for msae_encode_topk(T, d, N/G, k).
+ *                            the shard cannot bound it), float 0.  ws as for msae_encode_topk(T, d, N/G, k) with the
+ *                            same options.
  *   (all-to-all / all-gather of the records: rank r needs the records of its tokens from every shard)
  *   msae_rescore_candidates  rank r, its T tokens (T_valid of them real): records[G][T] -> exact top-k against the
  *                            FULL W_enc / b_enc (replicated, 2 GiB of 288 GB), same verification rule as
@@ -144,13 +159,13 @@ size_t msae_shard_record_bytes(int C);
 int msae_shard_candidates(const void *x, int x_dtype, const float *b_enc_shard, const float *b_dec,
                           const void *prepared_shard, int T, int d, int N_shard, int k, int row_offset, int C,
                           int set_feature, int zero_feature, void *records, void *ws, size_t ws_bytes,
-                          void *stream);
+                          const msae_options *opts, void *stream);
 size_t msae_rescore_candidates_ws_bytes(int T, int d, int N, int k, int G, int C);
 int msae_rescore_candidates(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                             const float *b_dec, int T, int T_valid, int d, int N, int k, int G, int C,
                             const void *records, int set_feature, float set_value, int zero_feature,
                             float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
-                            void *stream);
+                            const msae_options *opts, void *stream);
 
 /* ---- k-sparse decoder -------------------------------------------------------------------- */
 
@@ -164,17 +179,21 @@ int msae_decode_f32(const int32_t *idx, const float *acts, const float *W_dec, c
 int msae_decode_i64_f32(const int64_t *idx, const float *acts, const float *W_dec, const float *b_dec,
                         int A, int k, int N, int d, float *out, int32_t *status, void *stream);
 
-/* g_acts[A][k] = grad_out[A][:] . W_dec[idx[A][j]][:]   (dense-dense-sparse-out matmul) */
+/* g_acts[A][k] = grad_out[A][:] . W_dec[idx[A][j]][:]   (dense-dense-sparse-out matmul).  An index outside
+ * [0, N) yields g_acts = 0 for that pair and, when `status` (int32[1], optional) is given, is flagged there
+ * like the forward does (kernels.py:389 device_assert). */
 int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const float *W_dec, int A,
-                             int k, int N, int d, float *g_acts, void *stream);
+                             int k, int N, int d, float *g_acts, int32_t *status, void *stream);
 
 /* g_W_dec[n][:] = sum over (a, j) with idx[a][j] == n of acts[a][j] * grad_out[a][:], written to
  * the WHOLE dense [N][d] buffer (the layout autograd expects for Sae.W_dec.grad; rows without a
  * pair are zero; no pre-zeroing needed).  Pairs are grouped by feature with a counting sort and
- * summed in ascending pair order (segments are sorted whatever their length), so the result is bit-reproducible.  d % 4 == 0. */
+ * summed in ascending pair order (segments are sorted whatever their length), so the result is bit-reproducible.
+ * Pairs whose index lies outside [0, N) contribute nothing and are flagged in `status` (int32[1], optional).
+ * d % 4 == 0. */
 size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N);
 int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
-                             int k, int N, int d, float *g_W_dec, void *ws, size_t ws_bytes,
+                             int k, int N, int d, float *g_W_dec, int32_t *status, void *ws, size_t ws_bytes,
                              void *stream);
 
 /* ---- feature-cache sparsify ------------------------------------------------------------------
@@ -217,13 +236,15 @@ int msae_adam_rows_f32(float *W, const float *G, float *M, float *V, int rows, i
                        float beta2, float eps, int step, void *stream);
 
 /* ---- stage timing of msae_encode_topk's fused path (measurement aid for bench.py) --------------
- * Between _begin and _end every fused msae_encode_topk call records HIP events, on the stream it
- * launches on, at the boundaries of its 6 stages:
+ * A profile handle passed in msae_options::profile makes every fused msae_encode_topk call made with it
+ * record HIP events, on the stream it launches on, at the boundaries of its 6 stages:
  *   0 prep (zero + quantise x) 1 sample GEMM   2 threshold TopK   3 main int8/bf16 MFMA GEMM
  *   4 select + exact re-score 5 exact fallback of flagged tokens
- * _end synchronises on the recorded events and returns stage_ms[n_steps][6] (HOST pointers). */
-int msae_profile_begin(int max_steps);
-int msae_profile_end(float *stage_ms, int *n_steps);
+ * for up to max_steps calls.  _read synchronises on the recorded events and returns stage_ms[n_steps][6]
+ * (HOST pointers) and restarts the handle at step 0.  One handle must not be used by two threads at once. */
+int msae_profile_create(int max_steps, void **handle);
+int msae_profile_read(void *handle, float *stage_ms, int *n_steps);
+int msae_profile_destroy(void *handle);
 
 #ifdef __cplusplus
 }

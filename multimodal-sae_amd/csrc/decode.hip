@@ -109,13 +109,20 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_fwd_scalar_kernel(
 // one wave per (a, j); lanes stride the row in float4s, then a wave reduction.
 __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
     const int32_t *__restrict__ idx, const float *__restrict__ grad_out,
-    const float *__restrict__ W_dec, int A, int k, int N, int d, float *__restrict__ g_acts) {
+    const float *__restrict__ W_dec, int A, int k, int N, int d, float *__restrict__ g_acts,
+    int32_t *__restrict__ status) {
   const int lane = threadIdx.x & 63;
   const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= (long)A * k) return;
   const int a = (int)(pair / k);
-  int i = idx[pair];
-  if ((unsigned)i >= (unsigned)N) i = 0;
+  const int i = idx[pair];
+  if ((unsigned)i >= (unsigned)N) {     // wave-uniform.  kernels.py:389 device_assert: no gradient, flagged
+    if (lane == 0) {
+      g_acts[pair] = 0.f;
+      if (status) atomicOr(status, 1);
+    }
+    return;
+  }
   const float *g = grad_out + (size_t)a * d;
   const float *w = W_dec + (size_t)i * d;
   float acc = 0.f;
@@ -146,11 +153,16 @@ __global__ __launch_bounds__(256) void decode_bwd_acts_kernel(
 // rows read (mostly L2 / Infinity-Cache hits: grad_out is A*d*4 B).
 __global__ __launch_bounds__(256) void wgrad_count_kernel(const int32_t *__restrict__ idx,
                                                           const float *__restrict__ acts, long pairs,
-                                                          int N, int *__restrict__ counts) {
+                                                          int N, int *__restrict__ counts,
+                                                          int32_t *__restrict__ status) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= pairs) return;
   const int i = idx[p];
-  if ((unsigned)i < (unsigned)N && acts[p] != 0.f) atomicAdd(counts + i, 1);
+  if ((unsigned)i >= (unsigned)N) {      // kernels.py:28-36 asserts on the host; here: dropped and flagged
+    if (status) atomicOr(status, 1);
+    return;
+  }
+  if (acts[p] != 0.f) atomicAdd(counts + i, 1);
 }
 
 // single workgroup: offsets[n] = exclusive prefix of counts; cursor = copy; offsets[N] = total
@@ -321,13 +333,13 @@ extern "C" int msae_decode_i64_f32(const int64_t *idx, const float *acts, const 
 
 extern "C" int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out,
                                         const float *W_dec, int A, int k, int N, int d,
-                                        float *g_acts, void *stream) {
+                                        float *g_acts, int32_t *status, void *stream) {
   if (A < 0 || k <= 0 || N <= 0 || d <= 0) return MSAE_EINVAL;
   if (A == 0) return 0;
   if (d % 4 == 0 && (!msae_aligned(W_dec, 16) || !msae_aligned(grad_out, 16))) return MSAE_EALIGN;
   const long pairs = (long)A * k;
   hipLaunchKernelGGL(decode_bwd_acts_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, idx, grad_out, W_dec, A, k, N, d, g_acts);
+                     (hipStream_t)stream, idx, grad_out, W_dec, A, k, N, d, g_acts, status);
   return msae_launch_status();
 }
 
@@ -338,7 +350,8 @@ extern "C" size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N) {
 
 extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
                                         const float *grad_out, int A, int k, int N, int d,
-                                        float *g_W_dec, void *ws, size_t ws_bytes, void *stream) {
+                                        float *g_W_dec, int32_t *status, void *ws, size_t ws_bytes,
+                                        void *stream) {
   if (A < 0 || k <= 0 || N <= 0 || d <= 0 || d % 4 != 0) return MSAE_EINVAL;
   if (!ws || ws_bytes < msae_decode_bwd_wdec_ws_bytes(A, k, N)) return MSAE_EWS;
   if (!msae_aligned(grad_out, 16) || !msae_aligned(g_W_dec, 16) || !msae_aligned(ws, 256)) return MSAE_EALIGN;
@@ -352,7 +365,7 @@ extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
   hipLaunchKernelGGL(wgrad_zero_kernel, dim3(256), dim3(256), 0, s, counts, N + 1);
   if (pairs > 0) {
     const unsigned pb = (unsigned)((pairs + 255) / 256);
-    hipLaunchKernelGGL(wgrad_count_kernel, dim3(pb), dim3(256), 0, s, idx, acts, pairs, N, counts);
+    hipLaunchKernelGGL(wgrad_count_kernel, dim3(pb), dim3(256), 0, s, idx, acts, pairs, N, counts, status);
     hipLaunchKernelGGL(wgrad_scan_kernel, dim3(1), dim3(1024), 0, s, counts, N, offsets, cursor);
     hipLaunchKernelGGL(wgrad_fill_kernel, dim3(pb), dim3(256), 0, s, idx, acts, pairs, N, cursor, perm);
   } else {

@@ -107,31 +107,39 @@ inline Prepared make_prepared(int N, int d) {
   return p;
 }
 
-// ---- coarse-pass operand type: 0 = bf16, 1 = int8 (default; MSAE_COARSE=bf16 overrides) -----------
-int g_coarse_mode = -1;   // -1: not set yet -> environment
-inline int coarse_mode() {
-  if (g_coarse_mode < 0) {
-    const char *e = getenv("MSAE_COARSE");
-    g_coarse_mode = (e && e[0] == 'b') ? 0 : 1;
+// ---- per-call options (msae_options, include/msae.h), resolved once per entry-point call.  The library holds no
+// mutable state: the environment only supplies DEFAULTS (read at the call, never cached), everything else travels
+// with the call.
+struct ProfState;
+struct CallOpts {
+  int mode;          // coarse-pass operand type: 0 = bf16, 1 = int8
+  float z;           // width of the error band: u = coarse + z*sigma
+  int detail;        // status = 1 | reason << 8 for tokens recomputed in the call
+  ProfState *prof;   // stage timing handle or null
+};
+inline bool resolve_opts(const msae_options *o, CallOpts &c) {
+  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr;
+  if (o) {
+    if (o->size < sizeof(msae_options)) return false;
+    c.mode = o->coarse_mode; c.z = o->guard_z; c.detail = o->status_detail ? 1 : 0;
+    c.prof = static_cast<ProfState *>(o->profile);
   }
-  return g_coarse_mode;
-}
-
-int g_status_detail = 0;   // msae_set_status_detail
-#ifdef MSAE_GEMM_TIMELINE
-unsigned long long *g_timeline = nullptr;
-#endif
-
-// ---- width of the error band: u = coarse + z*sigma (MSAE_GUARD_Z / msae_set_guard_z; default 7) ----------
-float g_guard_z = -1.f;
-inline float guard_z() {
-  if (g_guard_z < 0.f) {
+  if (c.mode < 0) {
+    const char *e = getenv("MSAE_COARSE");
+    c.mode = (e && e[0] == 'b') ? 0 : 1;
+  }
+  if (c.mode != 0 && c.mode != 1) return false;
+  if (c.z == 0.f) {
     const char *e = getenv("MSAE_GUARD_Z");
     const float v = e ? (float)atof(e) : 0.f;
-    g_guard_z = (v >= 0.25f && v <= 64.f) ? v : 7.f;
+    c.z = (v >= 0.25f && v <= 64.f) ? v : 7.f;
   }
-  return g_guard_z;
+  return c.z >= 0.25f && c.z <= 64.f;
 }
+
+#ifdef MSAE_GEMM_TIMELINE
+unsigned long long *g_timeline = nullptr;   // tuning builds only
+#endif
 constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
 #ifndef MSAE_GUARD_ZETA
 #define MSAE_GUARD_ZETA 1.f
@@ -1088,14 +1096,16 @@ struct ShardOut { unsigned char *recs; int C; int row_offset; };
 // ---- stage profiling (bench.py roofline): HIP events recorded on the launch stream ------------------
 constexpr int PROF_MARKS = 7;  // boundaries of: prep | sample gemm | tau topk | main gemm | rescore | fallback
 struct ProfState {
-  bool on = false;
+  unsigned magic = 0x50524F46u;   // "PROF"
   int max_steps = 0, step = 0;
   hipEvent_t *ev = nullptr;
-} g_prof;
+};
 
-inline void prof_mark(int i, hipStream_t s) {
-  if (g_prof.on && g_prof.step < g_prof.max_steps)
-    (void)hipEventRecord(g_prof.ev[g_prof.step * PROF_MARKS + i], s);
+inline void prof_mark(ProfState *pf, int i, hipStream_t s) {
+  if (pf && pf->step < pf->max_steps) (void)hipEventRecord(pf->ev[pf->step * PROF_MARKS + i], s);
+}
+inline void prof_step(ProfState *pf) {
+  if (pf && pf->step < pf->max_steps) ++pf->step;
 }
 
 // ---- workspace carving -------------------------------------------------------------------------
@@ -1139,7 +1149,7 @@ struct FusedPlan {
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_dense, bytes;
 };
 
-inline FusedPlan make_plan(int T, int d, int N, int k, int shard_C = 0) {
+inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0) {
   FusedPlan p{};
   p.fast = fast_shape_ok(N, d) && T > EXACT_T_MAX && k <= 256 && k >= 1;
   size_t o = 0;
@@ -1157,7 +1167,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int shard_C = 0) {
     // size of the epilogue's LDS queue.
     if (shard_C > 0) { const int rs = shard_C / 8 > 8 ? shard_C / 8 : 8; if (rs < p.r) p.r = rs; }
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
-    p.i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
+    p.i8 = mode == 1 && i8_shape_ok(N, d);
     p.small = p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
     // most rows one token may read before it is handed to the exact path (the needed set is ~k + 10:
     // reaching this means the band is not separating anything); at least k + 4 (first-round minimum)
@@ -1212,7 +1222,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int shard_C = 0) {
 template <int DT>
 int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int d, int N,
                        int k, int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
-                       int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s) {
+                       int32_t *status, unsigned char *ws, const FusedPlan &pl, int detail, hipStream_t s) {
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
   int *n_flagged = flagged + T;
   int *fb_counts = flagged + T + 64;
@@ -1229,7 +1239,7 @@ int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, co
                          set_feature, set_value, zero_feature);
     // the exact results go straight to the flagged tokens' rows of the outputs (row map = the flag list)
     TopkExtra ex;
-    ex.idx64 = idx.i64; ex.row_map = rows; ex.status = status; ex.detail = g_status_detail;
+    ex.idx64 = idx.i64; ex.row_map = rows; ex.status = status; ex.detail = detail;
     rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, vals, idx.i32, s, ex);
     if (rc) return rc;
   }
@@ -1690,8 +1700,8 @@ template <int DT>
 int run_small(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const Prepared &pp,
               const unsigned char *prepared, int T, int d, int N, int k, int set_feature, float set_value,
               int zero_feature, float *vals, IdxOut idx, int32_t *status, unsigned char *ws, const FusedPlan &pl,
-              hipStream_t s) {
-  const float z = guard_z(), zz12 = z * z / 12.f;
+              const CallOpts &co, hipStream_t s) {
+  const float z = co.z, zz12 = z * z / 12.f;
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
   signed char *xhi = reinterpret_cast<signed char *>(ws + pl.off_xhi);
   signed char *xlo = reinterpret_cast<signed char *>(ws + pl.off_xlo);
@@ -1707,12 +1717,12 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   int *n_flagged = flagged + T;
   const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
   const f32x4 *wstat = reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat);
-  prof_mark(0, s);
+  prof_mark(co.prof, 0, s);
   hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, 2 * T,
                      flagged, T + 64 + pl.fb_chunks);
-  prof_mark(1, s);
-  prof_mark(2, s);
-  prof_mark(3, s);
+  prof_mark(co.prof, 1, s);
+  prof_mark(co.prof, 2, s);
+  prof_mark(co.prof, 3, s);
   const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
 #define MSAE_GEMV(DSEG, TT)                                                                                        \
   hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(SMALL_GRID), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, \
@@ -1751,19 +1761,19 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   }
 #undef MSAE_GEMV
   hipLaunchKernelGGL(select_small_kernel, dim3(T), dim3(1024), 0, s, surv, bound, cand, tau, n_surv, n_bound);
-  prof_mark(4, s);
+  prof_mark(co.prof, 4, s);
 #define MSAE_RESCORE(DSEG)                                                                                         \
   hipLaunchKernelGGL(rescore_small_kernel<DSEG>, dim3(SMALL_RMAX, T), dim3(64), 0, s, a32, W_enc, b_enc, k, cand, tau, wstat, \
                      rowc, zz12, z * z, set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
   switch (dseg) { case 1: MSAE_RESCORE(1); break; case 2: MSAE_RESCORE(2); break; case 4: MSAE_RESCORE(4); break;
                   case 8: MSAE_RESCORE(8); break; default: return MSAE_ENOTIMPL; }
 #undef MSAE_RESCORE
-  prof_mark(5, s);
+  prof_mark(co.prof, 5, s);
   int rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
-                                  status, ws, pl, s);
+                                  status, ws, pl, co.detail, s);
   if (rc) return rc;
-  prof_mark(6, s);
-  if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
+  prof_mark(co.prof, 6, s);
+  prof_step(co.prof);
   return msae_launch_status();
 }
 
@@ -1771,7 +1781,7 @@ template <int DT>
 int run_fast(const void *x, const float *W_enc, const float *b_enc, const float *b_dec,
              const Prepared &pp, const unsigned char *prepared, int T, int d, int N, int k,
              int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
-             int32_t *status, unsigned char *ws, const FusedPlan &pl, hipStream_t s,
+             int32_t *status, unsigned char *ws, const FusedPlan &pl, const CallOpts &co, hipStream_t s,
              const ShardOut *shard = nullptr) {
   unsigned short *xb = reinterpret_cast<unsigned short *>(ws + pl.off_xb);
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
@@ -1784,14 +1794,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   int *n_flagged = flagged + T;
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
-  prof_mark(0, s);
+  prof_mark(co.prof, 0, s);
   hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)T + 64 + pl.fb_chunks,
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
   if (!pl.i8)
     hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
   GemmOperands op_main{}, op_samp{};
-  const float z = guard_z(), zz12 = z * z / 12.f;
+  const float z = co.z, zz12 = z * z / 12.f;
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   if (pl.i8) {
@@ -1844,7 +1854,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 
   float *refs = reinterpret_cast<float *>(ws + pl.off_refs);
   hipLaunchKernelGGL(band_refs_kernel, dim3(1), dim3(1024), 0, s, colc_s, pl.S, refs);
-  prof_mark(1, s);
+  prof_mark(co.prof, 1, s);
   {  // sample pass -> dense [T][S]
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
@@ -1857,13 +1867,13 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
     if (grc) return grc;
   }
-  prof_mark(2, s);
+  prof_mark(co.prof, 2, s);
   int rc = 0;
   if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s)) {
     rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);  // generic shapes
     if (rc) return rc;
   }
-  prof_mark(3, s);
+  prof_mark(co.prof, 3, s);
   {  // full pass with the threshold epilogue
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = 1; ep.bias_off = 0;
@@ -1881,7 +1891,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
     if (grc) return grc;
   }
-  prof_mark(4, s);
+  prof_mark(co.prof, 4, s);
   if (shard) {   // feature-sharded group: this shard's best candidates travel, the owner of the token re-scores
     PackArgs pa{};
     pa.cnt = cnt; pa.cand = cand; pa.cap = pl.cap;
@@ -1892,9 +1902,9 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     if (pl.cap <= 64 * 32) hipLaunchKernelGGL(pack_candidates_kernel<32>, dim3(T), dim3(64), 0, s, pa);
     else if (pl.cap <= 64 * 64) hipLaunchKernelGGL(pack_candidates_kernel<64>, dim3(T), dim3(64), 0, s, pa);
     else return MSAE_ENOTIMPL;
-    prof_mark(5, s);
-    prof_mark(6, s);
-    if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
+    prof_mark(co.prof, 5, s);
+    prof_mark(co.prof, 6, s);
+    prof_step(co.prof);
     return msae_launch_status();
   }
   {
@@ -1912,30 +1922,18 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
     if (lrc) return lrc;
   }
-  prof_mark(5, s);
+  prof_mark(co.prof, 5, s);
 #ifndef MSAE_ABL_NOFALLBACK   // tuning builds only: keep the GEMM ablations' stage timings clean
   rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx,
-                              status, ws, pl, s);
+                              status, ws, pl, co.detail, s);
   if (rc) return rc;
 #endif
-  prof_mark(6, s);
-  if (g_prof.on && g_prof.step < g_prof.max_steps) ++g_prof.step;
+  prof_mark(co.prof, 6, s);
+  prof_step(co.prof);
   return msae_launch_status();
 }
 
 }  // namespace
-
-extern "C" int msae_set_coarse_mode(int mode) {
-  if (mode != 0 && mode != 1) return MSAE_EINVAL;
-  g_coarse_mode = mode;
-  return 0;
-}
-
-extern "C" int msae_set_guard_z(float z) {
-  if (!(z >= 0.25f && z <= 64.f)) return MSAE_EINVAL;
-  g_guard_z = z;
-  return 0;
-}
 
 #ifdef MSAE_GEMM_TIMELINE
 extern "C" int msae_debug_timeline(unsigned long long *host_out) {   // tuning builds only (tools/gemm_timeline.py)
@@ -1950,36 +1948,55 @@ extern "C" int msae_debug_rescore_timeline(unsigned long long *host_out) {   // 
 }
 #endif
 
-extern "C" int msae_set_status_detail(int on) {
-  g_status_detail = on ? 1 : 0;
-  return 0;
+extern "C" void msae_options_init(msae_options *opts) {
+  if (!opts) return;
+  opts->size = (uint32_t)sizeof(msae_options);
+  opts->coarse_mode = MSAE_COARSE_DEFAULT;
+  opts->guard_z = 0.f;
+  opts->status_detail = 0;
+  opts->profile = nullptr;
 }
 
-extern "C" int msae_profile_begin(int max_steps) {
-  if (max_steps <= 0 || max_steps > 4096) return MSAE_EINVAL;
-  if (g_prof.ev) {
-    for (int i = 0; i < g_prof.max_steps * PROF_MARKS; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-    delete[] g_prof.ev;
-    g_prof.ev = nullptr;
+extern "C" int msae_profile_create(int max_steps, void **handle) {
+  if (max_steps <= 0 || max_steps > 4096 || !handle) return MSAE_EINVAL;
+  ProfState *pf = new ProfState();
+  pf->ev = new hipEvent_t[(size_t)max_steps * PROF_MARKS];
+  for (int i = 0; i < max_steps * PROF_MARKS; ++i) {
+    const hipError_t e = hipEventCreate(&pf->ev[i]);
+    if (e != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(pf->ev[j]);
+      delete[] pf->ev;
+      delete pf;
+      return (int)e;
+    }
   }
-  g_prof.ev = new hipEvent_t[(size_t)max_steps * PROF_MARKS];
-  for (int i = 0; i < max_steps * PROF_MARKS; ++i) MSAE_HIP_TRY(hipEventCreate(&g_prof.ev[i]));
-  g_prof.max_steps = max_steps;
-  g_prof.step = 0;
-  g_prof.on = true;
+  pf->max_steps = max_steps;
+  *handle = pf;
   return 0;
 }
 
-extern "C" int msae_profile_end(float *stage_ms, int *n_steps) {
-  g_prof.on = false;
-  const int n = g_prof.step;
+extern "C" int msae_profile_read(void *handle, float *stage_ms, int *n_steps) {
+  ProfState *pf = static_cast<ProfState *>(handle);
+  if (!pf || pf->magic != 0x50524F46u || !stage_ms) return MSAE_EINVAL;
+  const int n = pf->step;
   if (n_steps) *n_steps = n;
   for (int st = 0; st < n; ++st) {
-    MSAE_HIP_TRY(hipEventSynchronize(g_prof.ev[st * PROF_MARKS + PROF_MARKS - 1]));
+    MSAE_HIP_TRY(hipEventSynchronize(pf->ev[st * PROF_MARKS + PROF_MARKS - 1]));
     for (int i = 0; i + 1 < PROF_MARKS; ++i)
-      MSAE_HIP_TRY(hipEventElapsedTime(&stage_ms[st * (PROF_MARKS - 1) + i],
-                                       g_prof.ev[st * PROF_MARKS + i], g_prof.ev[st * PROF_MARKS + i + 1]));
+      MSAE_HIP_TRY(hipEventElapsedTime(&stage_ms[st * (PROF_MARKS - 1) + i], pf->ev[st * PROF_MARKS + i],
+                                       pf->ev[st * PROF_MARKS + i + 1]));
   }
+  pf->step = 0;
+  return 0;
+}
+
+extern "C" int msae_profile_destroy(void *handle) {
+  ProfState *pf = static_cast<ProfState *>(handle);
+  if (!pf || pf->magic != 0x50524F46u) return MSAE_EINVAL;
+  for (int i = 0; i < pf->max_steps * PROF_MARKS; ++i) (void)hipEventDestroy(pf->ev[i]);
+  delete[] pf->ev;
+  pf->magic = 0;
+  delete pf;
   return 0;
 }
 
@@ -2021,27 +2038,35 @@ extern "C" int msae_encoder_prepare(const float *W_enc, int N, int d, void *prep
 }
 
 // After a weight update (training): rebuild only the operands the coarse mode in force reads.
-extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, void *stream) {
-  const bool i8 = coarse_mode() == 1 && i8_shape_ok(N, d);
+extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const msae_options *opts,
+                                    void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return MSAE_EINVAL;
+  const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
 }
 
-extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k) {
+extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts) {
   if (T <= 0 || d <= 0 || N <= 0 || k <= 0) return 0;
-  const FusedPlan pl = make_plan(T, d, N, k);
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return 0;
+  const FusedPlan pl = make_plan(T, d, N, k, co.mode);
   return pl.bytes;
 }
 
 static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                             const float *b_dec, const void *prepared, int T, int d, int N, int k,
                             int set_feature, float set_value, int zero_feature, float *vals,
-                            IdxOut idx, int32_t *status, void *ws, size_t ws_bytes, void *stream) {
+                            IdxOut idx, int32_t *status, void *ws, size_t ws_bytes, const msae_options *opts,
+                            void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   if (T < 0 || d <= 0 || N <= 0 || k <= 0 || k > N || k > 4096) return MSAE_EINVAL;
   if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
   if (set_feature >= N || zero_feature >= N) return MSAE_EINVAL;
   if (T == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  FusedPlan pl = make_plan(T, d, N, k);
+  FusedPlan pl = make_plan(T, d, N, k, co.mode);
   if (!prepared && pl.fast) return MSAE_EINVAL;  // the fast path needs msae_encoder_prepare()
   if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
   if (!msae_aligned(ws, 256)) return MSAE_EALIGN;
@@ -2068,15 +2093,15 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
     return MSAE_EALIGN;
   if (pl.small) {
     switch (x_dtype) {
-      case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
-      case MSAE_BF16: return run_small<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
-      default: return run_small<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
+      case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+      case MSAE_BF16: return run_small<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+      default: return run_small<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
     }
   }
   switch (x_dtype) {
-    case MSAE_F32: return run_fast<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
-    case MSAE_BF16: return run_fast<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
-    default: return run_fast<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, s);
+    case MSAE_F32: return run_fast<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+    case MSAE_BF16: return run_fast<MSAE_BF16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+    default: return run_fast<MSAE_F16>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
   }
 }
 
@@ -2084,20 +2109,20 @@ extern "C" int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, 
                                 const float *b_dec, const void *prepared, int T, int d, int N, int k,
                                 int set_feature, float set_value, int zero_feature, float *vals,
                                 int32_t *idx, int32_t *status, void *ws, size_t ws_bytes,
-                                void *stream) {
+                                const msae_options *opts, void *stream) {
   if (!idx) return MSAE_EINVAL;
   return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
-                          zero_feature, vals, IdxOut{idx, nullptr}, status, ws, ws_bytes, stream);
+                          zero_feature, vals, IdxOut{idx, nullptr}, status, ws, ws_bytes, opts, stream);
 }
 
 extern "C" int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                                     const float *b_dec, const void *prepared, int T, int d, int N, int k,
                                     int set_feature, float set_value, int zero_feature, float *vals,
                                     int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
-                                    void *stream) {
+                                    const msae_options *opts, void *stream) {
   if (!idx) return MSAE_EINVAL;
   return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
-                          zero_feature, vals, IdxOut{nullptr, idx}, status, ws, ws_bytes, stream);
+                          zero_feature, vals, IdxOut{nullptr, idx}, status, ws, ws_bytes, opts, stream);
 }
 
 // ---- feature-sharded group: per-shard candidates, owner-side exact re-score ----------------------------
@@ -2124,11 +2149,11 @@ template <int DT>
 int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int T_valid,
                     int d, int N, int k, int G, int C, const unsigned char *recs, int set_feature, float set_value,
                     int zero_feature, float *vals, int64_t *idx, int32_t *status, unsigned char *ws,
-                    const ExtPlan &xp, hipStream_t s) {
+                    const ExtPlan &xp, const CallOpts &co, hipStream_t s) {
   float *a32 = reinterpret_cast<float *>(ws + xp.off_a32);
   int *flagged = reinterpret_cast<int *>(ws + xp.off_flag);
   int *n_flagged = flagged + T;
-  const float z = guard_z();
+  const float z = co.z;
   hipLaunchKernelGGL(zero_i32_kernel, dim3(8), dim3(256), 0, s, flagged, (size_t)T + 64 + xp.fb_chunks);
   hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T_valid, T_valid, d,
                      (unsigned short *)nullptr, a32);
@@ -2148,7 +2173,7 @@ int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const
   FusedPlan pl{};                       // the exact fallback reads only these fields
   pl.off_flag = xp.off_flag; pl.off_fbdense = xp.off_fbdense; pl.fb_cap = xp.fb_cap; pl.fb_chunks = xp.fb_chunks;
   int rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals,
-                                  IdxOut{nullptr, idx}, status, ws, pl, s);
+                                  IdxOut{nullptr, idx}, status, ws, pl, co.detail, s);
   if (rc) return rc;
   return msae_launch_status();
 }
@@ -2159,11 +2184,13 @@ extern "C" size_t msae_shard_record_bytes(int C) { return C > 0 ? (size_t)shard_
 extern "C" int msae_shard_candidates(const void *x, int x_dtype, const float *b_enc, const float *b_dec,
                                      const void *prepared, int T, int d, int N, int k, int row_offset, int C,
                                      int set_feature, int zero_feature, void *records, void *ws, size_t ws_bytes,
-                                     void *stream) {
+                                     const msae_options *opts, void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   if (T < 0 || d <= 0 || N <= 0 || k <= 0 || C <= 0 || row_offset < 0 || !records) return MSAE_EINVAL;
   if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
   if (T == 0) return 0;
-  FusedPlan pl = make_plan(T, d, N, k, C);
+  FusedPlan pl = make_plan(T, d, N, k, co.mode, C);
   if (!pl.fast || !prepared || C > pl.cap) return MSAE_ENOTIMPL;   // shapes without the candidate pass: use msae_encode_topk per shard
   pl.small = false;
   if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
@@ -2178,9 +2205,9 @@ extern "C" int msae_shard_candidates(const void *x, int x_dtype, const float *b_
   const int sf = (set_feature >= row_offset && set_feature < row_offset + N) ? set_feature - row_offset : -1;
   const int zf = (zero_feature >= row_offset && zero_feature < row_offset + N) ? zero_feature - row_offset : -1;
   switch (x_dtype) {
-    case MSAE_F32: return run_fast<MSAE_F32>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
-    case MSAE_BF16: return run_fast<MSAE_BF16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
-    default: return run_fast<MSAE_F16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, s, &so);
+    case MSAE_F32: return run_fast<MSAE_F32>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, co, s, &so);
+    case MSAE_BF16: return run_fast<MSAE_BF16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, co, s, &so);
+    default: return run_fast<MSAE_F16>(x, nullptr, b_enc, b_dec, pp, pb, T, d, N, k, sf, 0.f, zf, nullptr, IdxOut{nullptr, nullptr}, nullptr, wsb, pl, co, s, &so);
   }
 }
 
@@ -2193,7 +2220,9 @@ extern "C" int msae_rescore_candidates(const void *x, int x_dtype, const float *
                                        const float *b_dec, int T, int T_valid, int d, int N, int k, int G, int C,
                                        const void *records, int set_feature, float set_value, int zero_feature,
                                        float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
-                                       void *stream) {
+                                       const msae_options *opts, void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   if (T < 0 || T_valid < 0 || T_valid > T || d <= 0 || N <= 0 || k <= 0 || k > N || k > 256 || G <= 0 || C <= 0 ||
       (long)G * C < k || (long)G * C > 8192 || d % 64 != 0)
     return MSAE_EINVAL;
@@ -2208,8 +2237,8 @@ extern "C" int msae_rescore_candidates(const void *x, int x_dtype, const float *
   const unsigned char *rb = static_cast<const unsigned char *>(records);
   hipStream_t s = (hipStream_t)stream;
   switch (x_dtype) {
-    case MSAE_F32: return run_rescore_ext<MSAE_F32>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
-    case MSAE_BF16: return run_rescore_ext<MSAE_BF16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
-    default: return run_rescore_ext<MSAE_F16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, s);
+    case MSAE_F32: return run_rescore_ext<MSAE_F32>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, co, s);
+    case MSAE_BF16: return run_rescore_ext<MSAE_BF16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, co, s);
+    default: return run_rescore_ext<MSAE_F16>(x, W_enc, b_enc, b_dec, T, T_valid, d, N, k, G, C, rb, set_feature, set_value, zero_feature, vals, idx, status, wsb, xp, co, s);
   }
 }

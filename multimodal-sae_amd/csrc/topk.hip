@@ -216,7 +216,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
     if (ex.idx64) ex.idx64[(size_t)orow * k + j] = ix;
     vals[(size_t)orow * k + j] = row[ix];  // the stored value (keeps -0.0 as stored)
   }
-  // a token the fused encoder could not verify, recomputed here: status 1 (msae_set_status_detail keeps why)
+  // a token the fused encoder could not verify, recomputed here: status 1 (msae_options::status_detail keeps why)
   if (ex.status && threadIdx.x == 0) ex.status[orow] = ex.detail ? (1 | ((ex.status[orow] & ~3) << 8)) : 1;
   __syncthreads();   // sh / keys are reused by the next row
   }
@@ -319,10 +319,16 @@ extern "C" size_t msae_topk_ws_bytes(int T, int N, int k) {
 // ld = row pitch in elements (>= N); exposed to the other translation units of the library.
 int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
                      float *vals, int32_t *idx, hipStream_t s, const TopkExtra &ex) {
-  if (T < 0 || N <= 0 || k <= 0 || k > N || k > 4096 || ld < N) return MSAE_EINVAL;
+  // k winners live in LDS as 64-bit rank keys: 16384 x 8 B + the histograms fit the CU's 160 KB (AuxK asks for
+  // d_in / 2 latents, sae.py:209: residual streams up to 32768 wide)
+  if (T < 0 || N <= 0 || k <= 0 || k > N || k > 16384 || ld < N) return MSAE_EINVAL;
   if (T == 0) return 0;
   const size_t smem = sizeof(TkShared) + (size_t)next_pow2(k) * sizeof(unsigned long long);
   const bool vec = (N % 4 == 0) && (ld % 4 == 0) && msae_aligned(latents, 16);
+  if (smem > 48 * 1024) {
+    if (vec) MSAE_HIP_TRY(hipFuncSetAttribute((const void *)topk_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    else MSAE_HIP_TRY(hipFuncSetAttribute((const void *)topk_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
   const int grid = (n_rows && T > 128) ? 128 : T;   // device-side count: workgroups loop over the rows
   if (vec)
     hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(grid), dim3(TK_THREADS), smem, s, latents, T, N, k, ld,

@@ -18,8 +18,20 @@ LIB_PATH = _LIB_DIR / "libmsae_hip.so"
 c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_size_t, ctypes.c_int64)
 
+ABI_VERSION = 2
+
+
+class MsaeOptions(ctypes.Structure):
+    """struct msae_options of include/msae.h: the per-call options of the fused encoder."""
+    _fields_ = [("size", ctypes.c_uint32), ("coarse_mode", ctypes.c_int32), ("guard_z", ctypes.c_float),
+                ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p)]
+
+
+c_opts_p = ctypes.POINTER(MsaeOptions)
+
 # name -> (restype, argtypes); mirrors include/msae.h one to one
 PROTOTYPES = {
+    "msae_options_init": (None, [c_opts_p]),
     "msae_abi_version": (c_int, []),
     "msae_error_string": (ctypes.c_char_p, [c_int]),
     "msae_target_arch": (ctypes.c_char_p, []),
@@ -30,44 +42,42 @@ PROTOTYPES = {
                               c_void_p]),
     "msae_encoder_prepared_bytes": (c_size_t, [c_int, c_int]),
     "msae_encoder_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "msae_encoder_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "msae_encoder_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
+    "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_opts_p]),
     "msae_encode_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_size_t, c_opts_p, c_void_p]),
     "msae_encode_topk_i64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_size_t, c_void_p]),
+                                     c_void_p, c_size_t, c_opts_p, c_void_p]),
     "msae_shard_record_bytes": (c_size_t, [c_int]),
     "msae_shard_candidates": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_opts_p, c_void_p]),
     "msae_rescore_candidates_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "msae_rescore_candidates": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, c_opts_p, c_void_p]),
     "msae_decode_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "msae_decode_i64_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     "msae_decode_bwd_acts_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                         c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p]),
     "msae_decode_bwd_wdec_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msae_decode_bwd_wdec_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "msae_sparsify_count": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_void_p, c_void_p]),
     "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "msae_set_coarse_mode": (c_int, [c_int]),
-    "msae_set_guard_z": (c_int, [c_float]),
-    "msae_set_status_detail": (c_int, [c_int]),
     "msae_merge_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_unit_norm_rows_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "msae_grad_sumsq_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "msae_adam_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float,
                                    c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
-    "msae_profile_begin": (c_int, [c_int]),
-    "msae_profile_end": (c_int, [c_void_p, c_void_p]),
+    "msae_profile_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "msae_profile_read": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "msae_profile_destroy": (c_int, [c_void_p]),
 }
 
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
@@ -93,8 +103,9 @@ def load() -> ctypes.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.msae_abi_version() != 1:
-        raise RuntimeError("libmsae_hip.so ABI version mismatch")
+    if lib.msae_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmsae_hip.so ABI version {lib.msae_abi_version()} != {ABI_VERSION}: rebuild it "
+                           "(python __graft_entry__.py)")
     _lib = lib
     return lib
 

@@ -14,6 +14,10 @@ int64 back, as ``torch.nonzero`` does), and raise on CPU tensors.
 """
 from __future__ import annotations
 
+import collections
+import contextlib
+import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -21,20 +25,134 @@ from torch import Tensor
 
 from . import _hip
 
-_WS: dict = {}
+_WS: "collections.OrderedDict" = collections.OrderedDict()
+_WS_MAX_STREAMS = 8      # scratch buffers kept alive: the most recently used (device, stream) pairs
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Tensor:
     """Grow-only scratch buffer per (device, stream) -- calls enqueued on different streams may run
-    concurrently and must not share scratch (uint8, 256-B aligned by the caching allocator)."""
+    concurrently and must not share scratch (uint8, 256-B aligned by the caching allocator).  At most
+    _WS_MAX_STREAMS buffers stay alive (least recently used first out; a dropped buffer goes back to the
+    caching allocator, which keeps it valid for the kernels already enqueued on its stream)."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WS.get(key)
+    ws = _WS.pop(key, None)
     if ws is None or ws.numel() < nbytes:
-        if ws is not None:
-            del _WS[key]
+        ws = None
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _WS[key] = ws
+    _WS[key] = ws                      # most recently used last
+    while len(_WS) > _WS_MAX_STREAMS:
+        _WS.popitem(last=False)
     return ws
+
+
+def release_workspaces() -> None:
+    """Drop every cached scratch buffer (they are re-created on demand)."""
+    _WS.clear()
+
+
+# ---- per-call options of the fused encoder (struct msae_options) ------------------------------------------
+# The shared library keeps no state: coarse mode, band width, diagnostics and the stage profile travel with
+# every call.  `Options` is the host-side mirror; `_defaults` is what the ops of THIS Python process use when a
+# call does not bring its own (a convenience of the host layer, set by set_coarse_mode() & co.).
+class StageProfile:
+    """Handle of msae_profile_create: HIP events at the stage boundaries of every fused encode that carries it."""
+
+    STAGES = 6
+
+    def __init__(self, max_steps: int):
+        self.max_steps = max_steps
+        self._h = ctypes.c_void_p()
+        _hip.check(_hip.load().msae_profile_create(max_steps, ctypes.byref(self._h)), "msae_profile_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def read(self):
+        """-> float32 array [n_steps, 6] of stage times in ms; restarts the handle."""
+        import numpy as np
+
+        buf = (ctypes.c_float * (self.max_steps * self.STAGES))()
+        n = ctypes.c_int(0)
+        _hip.check(_hip.load().msae_profile_read(self._h, buf, ctypes.byref(n)), "msae_profile_read")
+        return np.array(buf[:], dtype=np.float32).reshape(self.max_steps, self.STAGES)[: n.value]
+
+    def close(self):
+        if self._h:
+            _hip.load().msae_profile_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Options:
+    COARSE = {"default": -1, "bf16": 0, "int8": 1}
+
+    def __init__(self, coarse: str = "default", guard_z: float = 0.0, status_detail: bool = False,
+                 profile: Optional[StageProfile] = None):
+        self.coarse, self.guard_z, self.status_detail, self.profile = coarse, guard_z, status_detail, profile
+
+    def struct(self) -> "_hip.MsaeOptions":
+        o = _hip.MsaeOptions()
+        o.size = ctypes.sizeof(_hip.MsaeOptions)
+        o.coarse_mode = self.COARSE[self.coarse]
+        o.guard_z = float(self.guard_z)
+        o.status_detail = int(bool(self.status_detail))
+        o.profile = self.profile.handle if self.profile is not None else None
+        return o
+
+    def ref(self):
+        self._keep = self.struct()        # keeps the struct alive for the duration of the call
+        return ctypes.byref(self._keep)
+
+
+_defaults = Options()
+
+
+def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False) -> Options:
+    """Options of one call: explicit arguments win, the process defaults fill the rest."""
+    o = Options(_defaults.coarse, _defaults.guard_z, _defaults.status_detail, _defaults.profile)
+    if coarse_mode >= 0:
+        o.coarse = "int8" if coarse_mode == 1 else "bf16"
+    if guard_z > 0.0:
+        o.guard_z = guard_z
+    if status_detail:
+        o.status_detail = True
+    return o
+
+
+@contextlib.contextmanager
+def profiling(profile: StageProfile):
+    """Fused encodes issued inside the block record their stage boundaries into `profile`."""
+    prev, _defaults.profile = _defaults.profile, profile
+    try:
+        yield profile
+    finally:
+        _defaults.profile = prev
+
+
+_DEBUG_BOUNDS = os.environ.get("MSAE_DEBUG_BOUNDS", "0") not in ("", "0")
+
+
+def set_debug_bounds(on: bool) -> None:
+    """Debug mode (environment MSAE_DEBUG_BOUNDS=1): decode and its backward read the kernels' out-of-range flag
+    back after the call (one host synchronisation per call) and raise IndexError -- the analogue of the reference's
+    tl.device_assert(i < N) (sae/kernels.py:276,389).  Off: out-of-range indices are skipped silently."""
+    global _DEBUG_BOUNDS
+    _DEBUG_BOUNDS = bool(on)
+
+
+def _bounds_flag(dev) -> Optional[Tensor]:
+    return torch.zeros(1, dtype=torch.int32, device=dev) if _DEBUG_BOUNDS else None
+
+
+def _check_bounds(flag: Optional[Tensor], what: str) -> None:
+    if flag is not None and int(flag.item()) != 0:
+        raise IndexError(f"{what}: a latent index lies outside [0, num_latents)")
 
 
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -96,20 +214,25 @@ def _(latents, k):
 
 
 def set_coarse_mode(mode: str) -> None:
-    """Operand type of the fused encoder's candidate pass: "int8" (default) or "bf16".  Outputs do
-    not depend on it (candidates are re-scored exactly); speed does."""
-    _hip.check(_hip.load().msae_set_coarse_mode({"bf16": 0, "int8": 1}[mode]), "msae_set_coarse_mode")
+    """Default operand type of the fused encoder's candidate pass for this process's ops: "int8", "bf16" or
+    "default" (environment MSAE_COARSE, else int8).  Outputs do not depend on it (candidates are re-scored
+    exactly); speed does.  A host-layer default: the library itself takes the mode per call (msae_options)."""
+    if mode not in Options.COARSE:
+        raise ValueError(f"coarse mode {mode!r}: expected one of {sorted(Options.COARSE)}")
+    _defaults.coarse = mode
 
 
 def set_guard_z(z: float) -> None:
-    """Width of the candidate pass's error band in standard deviations of its per-(token, feature)
-    rounding noise (default 7).  Verified results do not depend on it; rows read per token do."""
-    _hip.check(_hip.load().msae_set_guard_z(float(z)), "msae_set_guard_z")
+    """Default width of the candidate pass's error band in standard deviations of its per-(token, feature)
+    rounding noise (library default 7; 0 restores it).  Verified results do not depend on it; rows read per token do."""
+    if z != 0.0 and not (0.25 <= z <= 64.0):
+        raise ValueError("guard z must lie in [0.25, 64] (or 0 for the default)")
+    _defaults.guard_z = float(z)
 
 
 def set_status_detail(on: bool) -> None:
     """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
-    _hip.check(_hip.load().msae_set_status_detail(int(on)), "msae_set_status_detail")
+    _defaults.status_detail = bool(on)
 
 
 def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_only: bool = False) -> Tensor:
@@ -123,9 +246,13 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
     nbytes = lib.msae_encoder_prepared_bytes(N, d)
     if out is None or out.numel() != nbytes or out.device != dev:
         out, active_mode_only = torch.empty(nbytes, dtype=torch.uint8, device=dev), False
-    fn = lib.msae_encoder_refresh if active_mode_only else lib.msae_encoder_prepare
     with torch.cuda.device(dev):
-        _hip.check(fn(_hip.ptr(W), N, d, _hip.ptr(out), _hip.stream_of(W)), "msae_encoder_prepare")
+        if active_mode_only:
+            _hip.check(lib.msae_encoder_refresh(_hip.ptr(W), N, d, _hip.ptr(out), _opts().ref(), _hip.stream_of(W)),
+                       "msae_encoder_refresh")
+        else:
+            _hip.check(lib.msae_encoder_prepare(_hip.ptr(W), N, d, _hip.ptr(out), _hip.stream_of(W)),
+                       "msae_encoder_prepare")
     return out
 
 
@@ -146,8 +273,11 @@ def _refresh_train_operands(W_enc: Tensor) -> Tensor:
 @torch.library.custom_op("msae::encode_topk", mutates_args=())
 def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
                 prepared: Optional[Tensor], k: int, set_feature: int = -1, set_value: float = 0.0,
-                zero_feature: int = -1) -> Tuple[Tensor, Tensor, Tensor]:
-    """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...])."""
+                zero_feature: int = -1, coarse_mode: int = -1, guard_z: float = 0.0,
+                status_detail: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...]).
+    coarse_mode (-1 default / 0 bf16 / 1 int8), guard_z (0 = default) and status_detail are this call's
+    msae_options; what is left at its default comes from the process defaults (set_coarse_mode & co.)."""
     dev = _hip.require_device(x, W_enc, b_enc, b_dec, prepared)
     lib = _hip.load()
     xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
@@ -160,19 +290,21 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     status = torch.empty(xa.shape[:-1], dtype=torch.int32, device=dev)
     if T == 0:
         return vals, idx, status
-    nws = lib.msae_encode_topk_ws_bytes(T, d, N, k)
+    opts = _opts(coarse_mode, guard_z, status_detail)
+    nws = lib.msae_encode_topk_ws_bytes(T, d, N, k, opts.ref())
     ws = _workspace(dev, nws)
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
                                             _hip.ptr(be), _hip.ptr(bd), _hip.ptr(prepared), T, d, N, k,
                                             set_feature, set_value, zero_feature, _hip.ptr(vals),
                                             _hip.ptr(idx), _hip.ptr(status), _hip.ptr(ws), ws.numel(),
-                                            _hip.stream_of(xa)), "msae_encode_topk_i64")
+                                            opts.ref(), _hip.stream_of(xa)), "msae_encode_topk_i64")
     return vals, idx, status
 
 
 @encode_topk.register_fake
-def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1):
+def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1, coarse_mode=-1,
+      guard_z=0.0, status_detail=False):
     return (x.new_empty(*x.shape[:-1], k, dtype=torch.float32),
             x.new_empty(*x.shape[:-1], k, dtype=torch.int64),
             x.new_empty(x.shape[:-1], dtype=torch.int32))
@@ -191,11 +323,12 @@ def shard_candidates(x: Tensor, b_enc_shard: Optional[Tensor], b_dec: Optional[T
     recs = torch.empty(T, stride, dtype=torch.uint8, device=dev)
     if T == 0:
         return recs
-    ws = _workspace(dev, lib.msae_encode_topk_ws_bytes(T, d, N_shard, k))
+    opts = _opts()
+    ws = _workspace(dev, lib.msae_encode_topk_ws_bytes(T, d, N_shard, k, opts.ref()))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_shard_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(be), _hip.ptr(bd),
                                              _hip.ptr(prepared_shard), T, d, N_shard, k, row_offset, C, set_feature,
-                                             zero_feature, _hip.ptr(recs), _hip.ptr(ws), ws.numel(),
+                                             zero_feature, _hip.ptr(recs), _hip.ptr(ws), ws.numel(), opts.ref(),
                                              _hip.stream_of(xa)), "msae_shard_candidates")
     return recs
 
@@ -224,18 +357,10 @@ def rescore_candidates(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec:
         _hip.check(lib.msae_rescore_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W), _hip.ptr(be),
                                                _hip.ptr(bd), T, T_valid, d, N, k, G, C, _hip.ptr(records), set_feature,
                                                set_value, zero_feature, _hip.ptr(vals), _hip.ptr(idx),
-                                               _hip.ptr(status), _hip.ptr(ws), ws.numel(), _hip.stream_of(xa)),
+                                               _hip.ptr(status), _hip.ptr(ws), ws.numel(), _opts().ref(),
+                                               _hip.stream_of(xa)),
                    "msae_rescore_candidates")
     return vals, idx, status
-
-
-def encode_topk_resolved(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
-                         prepared: Optional[Tensor], k: int, set_feature: int = -1,
-                         set_value: float = 0.0, zero_feature: int = -1):
-    """Historic name: the kernel now recomputes EVERY token it cannot verify inside the call (the exact
-    fallback loops over the flagged list on the device), so there is nothing left to resolve on the
-    host and no device->host read.  Same as encode_topk."""
-    return encode_topk(x, W_enc, b_enc, b_dec, prepared, k, set_feature, set_value, zero_feature)
 
 
 # ---- decoder (differentiable, mirrors TritonDecoder: kernels.py:403-429) ---------------------------
@@ -258,9 +383,11 @@ def decode(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, b_dec: Optional
     k = idx.shape[-1]
     A = idx.numel() // k
     out = torch.empty(*idx.shape[:-1], d, dtype=torch.float32, device=dev)
+    flag = _bounds_flag(dev)
     with torch.cuda.device(dev):
-        _hip.check(fn(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(W), _hip.ptr(bd), A, k, N, d, _hip.ptr(out), None,
-                      _hip.stream_of(acts)), "%s" % name)
+        _hip.check(fn(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(W), _hip.ptr(bd), A, k, N, d, _hip.ptr(out),
+                      _hip.ptr(flag), _hip.stream_of(acts)), "%s" % name)
+    _check_bounds(flag, name)
     return out
 
 
@@ -280,16 +407,18 @@ def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: T
     A = idx.numel() // k
     g_acts = torch.empty_like(acts) if need_acts else acts.new_empty(0)
     g_w = torch.empty_like(W) if need_w else W.new_empty(0)   # the kernel writes every row
+    flag = _bounds_flag(dev)
     with torch.cuda.device(dev):
         st = _hip.stream_of(g)
         if need_acts:
             _hip.check(lib.msae_decode_bwd_acts_f32(_hip.ptr(idx), _hip.ptr(g), _hip.ptr(W), A, k, N, d,
-                                                    _hip.ptr(g_acts), st), "msae_decode_bwd_acts_f32")
+                                                    _hip.ptr(g_acts), _hip.ptr(flag), st), "msae_decode_bwd_acts_f32")
         if need_w:
             ws = _workspace(dev, lib.msae_decode_bwd_wdec_ws_bytes(A, k, N))
             _hip.check(lib.msae_decode_bwd_wdec_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(g), A, k, N,
-                                                    d, _hip.ptr(g_w), _hip.ptr(ws), ws.numel(), st),
+                                                    d, _hip.ptr(g_w), _hip.ptr(flag), _hip.ptr(ws), ws.numel(), st),
                        "msae_decode_bwd_wdec_f32")
+    _check_bounds(flag, "msae_decode_bwd")
     return g_acts, g_w
 
 
@@ -405,9 +534,7 @@ class _SparseEncode(torch.autograd.Function):
             vals.append(v); idxs.append(i)
             if k_aux > 0:
                 dead_pre = torch.where(dead_mask[None], pre, -torch.inf)            # sae.py:217-220
-                # the LDS-resident selection kernel holds k <= 4096 (d_in <= 8192 for AuxK's k = d_in / 2);
-                # wider residual streams take the torch selection for this auxiliary term
-                v, i = topk(dead_pre, k_aux) if k_aux <= 4096 else torch.topk(dead_pre, k_aux, dim=-1)
+                v, i = topk(dead_pre, k_aux)        # LDS-resident selection: k_aux <= 16384 (d_in <= 32768)
                 vals.append(v); idxs.append(i)
             if k_multi > 0:
                 v, i = topk(pre, k_multi)                                           # sae.py:233

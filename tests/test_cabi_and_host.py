@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads and exports every symbol include/msae.h declares (no compute),
 and the host-side logic that needs no GPU (config, checkpoint I/O, split naming, error paths)."""
+import ctypes
 import json
 import re
 
@@ -25,13 +26,28 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmsae_hip.so does not export {name}"
     assert set(declared) == set(_hip.PROTOTYPES), set(declared) ^ set(_hip.PROTOTYPES)
-    assert lib.msae_abi_version() == 1
+    assert lib.msae_abi_version() == 2
     assert lib.msae_target_arch() == b"gfx950"
     assert b"workspace" in lib.msae_error_string(-3)
     # pure host-side size queries (no GPU needed)
     assert lib.msae_encoder_prepared_bytes(131072, 4096) >= 131072 * 4096 * 2
-    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32) > 0
-    assert lib.msae_encode_topk_ws_bytes(16, 768, 4096, 32) >= 16 * 4096 * 4
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, None) > 0
+    assert lib.msae_encode_topk_ws_bytes(16, 768, 4096, 32, None) >= 16 * 4096 * 4
+    # per-call options: the coarse mode changes the workspace, nothing in the library remembers it
+    o8, ob = _hip.MsaeOptions(), _hip.MsaeOptions()
+    lib.msae_options_init(ctypes.byref(o8)); lib.msae_options_init(ctypes.byref(ob))
+    assert o8.size == ctypes.sizeof(_hip.MsaeOptions) and o8.coarse_mode == -1 and o8.guard_z == 0.0
+    o8.coarse_mode, ob.coarse_mode = 1, 0
+    w8 = lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8))
+    wb = lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(ob))
+    assert w8 > 0 and wb > 0 and w8 != wb
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == w8   # no hidden state
+    bad = _hip.MsaeOptions()
+    lib.msae_options_init(ctypes.byref(bad))
+    bad.guard_z = 1000.0
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(bad)) == 0
+    bad.guard_z, bad.size = 0.0, 4     # a caller compiled against a shorter struct than this library knows
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(bad)) == 0
 
 
 def test_compute_on_cpu_tensors_raises_instead_of_falling_back():
@@ -270,7 +286,7 @@ def test_shard_helpers_and_argument_checks_without_a_gpu():
     null = ctypes.c_void_p(None)
     # G * C < k, missing records, negative sizes: MSAE_EINVAL (-1); too small a workspace: MSAE_EWS
     einval = lib.msae_rescore_candidates(null, 2, null, null, null, 4, 4, 4096, 131072, 32, 2, 8, null, -1, 0.0, -1, null, null,
-                                         null, null, 0, null)
+                                         null, null, 0, None, null)
     assert einval < 0
-    assert lib.msae_shard_candidates(null, 2, null, null, null, 4, 4096, 16384, 32, 0, 0, -1, -1, null, null, 0, null) < 0
+    assert lib.msae_shard_candidates(null, 2, null, null, null, 4, 4096, 16384, 32, 0, 0, -1, -1, null, null, 0, None, null) < 0
     assert lib.msae_error_string(einval).decode()

@@ -229,7 +229,7 @@ def test_stale_operands_are_caught_by_the_model_check(dev):
     W += 0.05 * torch.randn(N, d, generator=g, device=dev) / d ** 0.5       # 5 % relative noise on every row
     ops.set_status_detail(True)
     try:
-        v, i, status = ops.encode_topk_resolved(x, W, b, bd, prepared, k)
+        v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)
     finally:
         ops.set_status_detail(False)
     ev, ei = _exact(ops, x, W, b, bd, k)

@@ -266,11 +266,11 @@ def test_encode_and_decode_entry_points_of_both_index_widths_agree(dev, T, d, N,
     v32 = torch.empty(T, k, dtype=torch.float32, device=dev)
     i32 = torch.full((T, k), -1, dtype=torch.int32, device=dev)
     st32 = torch.full((T,), -1, dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.msae_encode_topk_ws_bytes(T, d, N, k) + 256, dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.msae_encode_topk_ws_bytes(T, d, N, k, None) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     rc = lib.msae_encode_topk(_hip.ptr(x), _hip.DTYPE_CODE[x.dtype], _hip.ptr(W_enc), _hip.ptr(b_enc), _hip.ptr(b_dec),
                               _hip.ptr(prepared), T, d, N, k, -1, 0.0, -1, _hip.ptr(v32), _hip.ptr(i32), _hip.ptr(st32),
-                              ws.data_ptr() + off, ws.numel() - off, _hip.stream_of(x))
+                              ws.data_ptr() + off, ws.numel() - off, None, _hip.stream_of(x))
     assert rc == 0, rc
     torch.cuda.synchronize()
     assert torch.equal(i32.long(), i64) and torch.equal(v32, v64) and torch.equal(st32, st64)

@@ -13,11 +13,11 @@ for G in (8, 4, 2, 1):
     prep = ops.prepare_encoder(W_enc)
     for _ in range(3): v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, kl)
     torch.cuda.synchronize()
-    lib.msae_profile_begin(10); t0 = time.perf_counter()
-    for _ in range(10): v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, kl)
+    prof = ops.StageProfile(10); t0 = time.perf_counter()
+    with ops.profiling(prof):
+        for _ in range(10): v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, kl)
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10 * 1e3
-    buf = (ctypes.c_float * 60)(); n = ctypes.c_int(0); lib.msae_profile_end(buf, ctypes.byref(n))
-    st = np.array(buf[:]).reshape(10, 6).mean(0)
+    st = prof.read().mean(0); prof.close()
     gathered = torch.stack((v.view(torch.int32), i.to(torch.int32)), 0).repeat(G, 1, 1).contiguous()
     for _ in range(3): ops.merge_topk_gathered(gathered, T, G, kl, k)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -45,11 +45,11 @@ for G in (8, 4, 2):
     def sender():
         return ops.shard_candidates(x, b_full[:nl], b_dec, preps, nl, k, 0, C)
     for _ in range(3): recs = sender()
-    torch.cuda.synchronize(); lib.msae_profile_begin(10); t0 = time.perf_counter()
-    for _ in range(10): recs = sender()
+    torch.cuda.synchronize(); prof = ops.StageProfile(10); t0 = time.perf_counter()
+    with ops.profiling(prof):
+        for _ in range(10): recs = sender()
     torch.cuda.synchronize(); ts = (time.perf_counter() - t0) / 10 * 1e3
-    buf = (ctypes.c_float * 60)(); n = ctypes.c_int(0); lib.msae_profile_end(buf, ctypes.byref(n))
-    st = np.array(buf[:]).reshape(10, 6).mean(0)
+    st = prof.read().mean(0); prof.close()
     # real records of every shard for rank 0's tokens (each shard's candidate pass run here, untimed)
     allr = []
     for g in range(G):
