@@ -670,8 +670,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       keys[i] = kv;
     }
     if (mine) atomicAdd(&s_n, mine);
-    if (lane < p.ext_G) {           // tau = the largest bound of the shards (order keys: +inf dominates, NaN never enters)
-      const unsigned char *rec = p.ext + ((size_t)lane * p.ext_T + t) * p.ext_stride;
+    for (int g = lane; g < p.ext_G; g += NT) {   // tau = the largest bound of ALL shards (order keys: +inf dominates, NaN never enters)
+      const unsigned char *rec = p.ext + ((size_t)g * p.ext_T + t) * p.ext_stride;
       atomicMax(&s_tau, f32_order_key(*reinterpret_cast<const float *>(rec + (size_t)p.ext_C * 12)));
     }
     __syncthreads();

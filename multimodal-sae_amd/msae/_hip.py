@@ -110,10 +110,14 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+class MsaeNotImplemented(RuntimeError):
+    """MSAE_ENOTIMPL: the shape lies outside what this entry point supports (callers with an alternative take it)."""
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().msae_error_string(code).decode()
-        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+        raise (MsaeNotImplemented if code == -4 else RuntimeError)(f"{what} failed: {msg} (code {code})")
 
 
 def ptr(t: torch.Tensor | None):

@@ -54,7 +54,9 @@ def sae_splice_hook(sae_dict: Dict[str, Sae], module_to_name: Dict[torch.nn.Modu
                                             sae._prepared_weights(), sae.cfg.k + extra_k, -1, 0.0, zero)
             if keep_latents is not None:
                 keep_latents[name] = (va, ia)
-        top = sae.encode(flat, zero_feature=zero)
+        # the reference's graph is differentiable wherever autograd is on (the SAE's parameters require grad even under
+        # a frozen LLM): keep that, rather than Sae.encode's default of following x.requires_grad
+        top = sae.encode(flat, zero_feature=zero, differentiable=torch.is_grad_enabled())
         if keep_latents is not None and not extra_k:
             keep_latents[name] = (top.top_acts.detach(), top.top_indices)
         sae_out = sae.decode(top.top_acts, top.top_indices).to(torch.float16).view(bs, seq_len, dim)

@@ -13,7 +13,11 @@ from .hooks import clamp_features_max
 
 
 class SteeringController:
-    def __init__(self, sae: Sae, module_name: str, feature_idx: List[int], model, processor,
+    """`sae`: an `Sae`, or a feature-sharded `msae.parallel.ShardedSae` engine -- then EVERY rank of the engine's
+    group must run the same controller on the same prompt and feature list (they meet in the engine's collectives
+    at every hooked forward)."""
+
+    def __init__(self, sae, module_name: str, feature_idx: List[int], model, processor,
                  prompt: str, image_path: str = None, k: float = 50):
         self.sae, self.feature_idx, self.model, self.k = sae, feature_idx, model, k
         self.module_name, self.processor = module_name, processor
@@ -32,7 +36,7 @@ class SteeringController:
                                                     add_generation_prompt=True)
         self.inputs = processor(images=self.image, text=self.prompt, return_tensors="pt").to(model.device)
 
-    def clamp_features_max(self, sae: Sae, feature: int, hooked_module, k: float = 10):
+    def clamp_features_max(self, sae, feature: int, hooked_module, k: float = 10):
         return clamp_features_max(sae, feature, hooked_module, k=k)
 
     def _generate(self) -> str:

@@ -24,6 +24,12 @@ def parse_argument(argv=None):
     p.add_argument("--clamp-value", "-k", type=float, default=50, help="The clamping value")
     p.add_argument("--save-dir", "-s", default="./results/steering",
                    help="The path to save your steering result")
+    p.add_argument("--shard-sae", "--shard_sae", action="store_true",
+                   help="(new) under torchrun: shard the SAE's feature axis over the ranks instead of the feature "
+                        "list -- every rank runs every generation, each streams N/G rows of the encoder per step "
+                        "(the latency mode for wide SAEs); results are identical")
+    p.add_argument("--shard-mode", default="topk", choices=["topk", "candidates"],
+                   help="exchange scheme of --shard-sae (msae.parallel.ShardedSae)")
     return p.parse_args(argv)
 
 
@@ -35,11 +41,19 @@ def main(argv=None):
     sae_dict = load_saes(args.sae_path, filters, device=f"cuda:{rank}")
     for module_name, sae in sae_dict.items():
         feats = filters[module_name]
-        feature_idx = (feats.tensor_split(world)[rank] if ddp else feats).cpu().tolist()
-        result = SteeringController(sae=sae, module_name=module_name, feature_idx=feature_idx,
+        shard = args.shard_sae and ddp and sae.num_latents % world == 0
+        if shard:       # one SAE over all ranks: every rank walks the whole feature list in step
+            from ...parallel import ShardedSae
+
+            engine = ShardedSae.from_sae(sae, rank=rank, world=world, group=dist.group.WORLD, mode=args.shard_mode)
+            feature_idx = feats.cpu().tolist()
+        else:           # the reference's split: every rank its own slice of the feature list (steering.py:70-75)
+            engine = sae
+            feature_idx = (feats.tensor_split(world)[rank] if ddp else feats).cpu().tolist()
+        result = SteeringController(sae=engine, module_name=module_name, feature_idx=feature_idx,
                                     prompt=args.text, model=model, processor=processor,
                                     image_path=args.image_path, k=args.clamp_value).run()
-        if ddp:
+        if ddp and not shard:
             gathered = [None] * world
             dist.gather_object(result, gathered if rank == 0 else None, dst=0)
             if rank == 0:

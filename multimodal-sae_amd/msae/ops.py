@@ -191,6 +191,51 @@ def _(x, W_enc, b_enc, b_dec):
     return x.new_empty(*x.shape[:-1], W_enc.shape[0], dtype=torch.float32)
 
 
+def _dense_gemm_nt(a: Tensor, b: Tensor) -> Tensor:
+    """a [M, K] @ b[P, K]^T -> [M, P] f32 on the exact f32 MFMA kernel (msae_pre_acts_f32 without bias / ReLU)."""
+    lib = _hip.load()
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    if out.numel():
+        with torch.cuda.device(a.device):
+            _hip.check(lib.msae_pre_acts_f32(_hip.ptr(a), 0, _hip.ptr(b), None, None, a.shape[0], a.shape[1],
+                                             b.shape[0], 0, _hip.ptr(out), _hip.stream_of(a)), "msae_pre_acts_f32")
+    return out
+
+
+def _pre_acts_setup(ctx, inputs, output):
+    x, W_enc, b_enc, b_dec = inputs
+    ctx.save_for_backward(x, W_enc, b_dec, output)
+    ctx.has = (b_enc is not None, b_dec is not None)
+
+
+def _pre_acts_backward(ctx, grad_out):
+    """The dense graph of the reference's nn.Linear + relu (sae.py:172-177): legacy callers that differentiate
+    pre_acts -> [mask] -> select_topk -> decode (features/patching/utils.py:41-49, tools/*.py) get the same
+    gradients as from torch autograd -- two dense GEMMs on the exact f32 MFMA kernel.  (The fused
+    Sae.encode(zero_feature=...) path has the sparse backward and never builds [T, N] gradients.)"""
+    x, W_enc, b_dec, out = ctx.saved_tensors
+    N, d = W_enc.shape
+    g = (grad_out.reshape(-1, N).float() * (out.reshape(-1, N) > 0)).contiguous()       # relu'
+    need_x, need_W, need_be, need_bd = ctx.needs_input_grad
+    g_x = g_W = g_be = g_bd = None
+    if need_x or (need_bd and ctx.has[1]):
+        da = _dense_gemm_nt(g, W_enc.detach().float().t())                 # [T, N] @ [N, d]
+        g_x = da.view(x.shape).to(x.dtype) if need_x else None
+        g_bd = -da.sum(0) if (need_bd and ctx.has[1]) else None
+    if need_W:
+        a = x.detach().reshape(-1, d).float()
+        if ctx.has[1]:
+            a = a - b_dec.detach().float()
+        g_W = _dense_gemm_nt(g.t(), a.t()).to(W_enc.dtype)                 # [N, T] @ [T, d]
+    if need_be and ctx.has[0]:
+        g_be = g.sum(0)
+    return g_x, g_W, g_be, g_bd
+
+
+pre_acts.register_autograd(_pre_acts_backward, setup_context=_pre_acts_setup)
+
+
 @torch.library.custom_op("msae::topk", mutates_args=())
 def topk(latents: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     """Canonical top-k along the last dim: values descending, ties by ascending index; int64 idx."""
@@ -211,6 +256,22 @@ def topk(latents: Tensor, k: int) -> Tuple[Tensor, Tensor]:
 def _(latents, k):
     return (latents.new_empty(*latents.shape[:-1], k, dtype=torch.float32),
             latents.new_empty(*latents.shape[:-1], k, dtype=torch.int64))
+
+
+def _topk_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.in_shape, ctx.in_dtype = inputs[0].shape, inputs[0].dtype
+
+
+def _topk_backward(ctx, g_vals, _g_idx):
+    """Tensor.topk's backward: the values' gradient scattered to the selected positions (sae.py:179-181)."""
+    idx, = ctx.saved_tensors
+    g = torch.zeros(ctx.in_shape, dtype=g_vals.dtype, device=g_vals.device)
+    g.scatter_(-1, idx, g_vals)
+    return g.to(ctx.in_dtype), None
+
+
+topk.register_autograd(_topk_backward, setup_context=_topk_setup)
 
 
 def set_coarse_mode(mode: str) -> None:
@@ -580,8 +641,11 @@ def sparse_encode(x: Tensor, W_enc: Tensor, b_enc: Tensor, b_dec: Tensor, k: int
     """-> [(acts, idx)] for the top-k, (optional) AuxK and (optional) Multi-TopK selections.
     Differentiable w.r.t. x, W_enc, b_enc, b_dec through the selected latents (the graph of the
     reference's pre_acts -> [mask] -> topk, sae.py:172-185, patching/utils.py:43-49)."""
-    out = _SparseEncode.apply(x, W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi, prepared, set_feature,
-                              float(set_value), zero_feature)
+    lead = x.shape[:-1]
+    out = _SparseEncode.apply(x.reshape(-1, x.shape[-1]), W_enc, b_enc, b_dec, k, dead_mask, k_aux, k_multi, prepared,
+                              set_feature, float(set_value), zero_feature)        # the node works on [T, d]
+    if len(lead) != 1:
+        out = tuple(o.reshape(*lead, o.shape[-1]) for o in out)
     return [(out[2 * j], out[2 * j + 1]) for j in range(len(out) // 2)]
 
 

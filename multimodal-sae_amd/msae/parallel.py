@@ -86,9 +86,35 @@ def token_slice(T: int, rank: int, world: int):
     return min(rank * per, T), min((rank + 1) * per, T), per
 
 
+LOCAL_DECODE_MAX_T = 64   # batches this small are decoded by every rank itself (replicated W_dec): no gather
+
+
 class ShardedSae:
     """Inference engine over a feature-sharded encoder.  With world == 1 it is the plain fused
-    encode -> decode pipeline (what bench.py times on one GPU)."""
+    encode -> decode pipeline (what bench.py times on one GPU).
+
+    Memory per rank: its N/G rows of W_enc (+ their coarse-pass operands) and the WHOLE W_dec (2 GiB of 288 GB at
+    C2).  mode="candidates" additionally keeps the WHOLE f32 W_enc / b_enc on every rank (`W_enc_full`): the owner
+    of a token re-scores candidates of every shard, so this mode shards the encoder's COMPUTE, not its memory; shapes
+    without the candidate pass (msae_shard_candidates -> MSAE_ENOTIMPL) fall back to mode="topk" on first use.
+
+    Every rank must see the SAME activations x (each rank runs the same LLM forward, or x is broadcast): the hooks in
+    msae.features.hooks accept an engine wherever they accept an `Sae`."""
+
+    @classmethod
+    def from_sae(cls, sae, rank: int = 0, world: int = 1, group=None, mode: str = "topk", **kw) -> "ShardedSae":
+        """Rank `rank`'s engine of a G-rank group over a (replicated, loaded) `Sae` module: slices of
+        encoder.weight / encoder.bias, the whole W_dec / b_dec."""
+        N = sae.num_latents
+        assert N % world == 0, "the feature axis must divide over the ranks"
+        n_loc = N // world
+        lo, hi = rank * n_loc, (rank + 1) * n_loc
+        W, b = sae.encoder.weight.detach(), sae.encoder.bias.detach()
+        if mode == "candidates":
+            kw.setdefault("W_enc_full", W)
+            kw.setdefault("b_enc_full", b)
+        return cls(W[lo:hi], b[lo:hi], sae.W_dec.detach(), sae.b_dec.detach(), sae.cfg.k, rank=rank, world=world,
+                   group=group, mode=mode, **kw)
 
     def __init__(self, W_enc_shard: Tensor, b_enc_shard: Tensor, W_dec: Tensor, b_dec: Tensor, k: int,
                  rank: int = 0, world: int = 1, group=None,
@@ -96,8 +122,10 @@ class ShardedSae:
                  force_collectives: bool = False, k_loc: Optional[int] = None,
                  row_offset: Optional[int] = None, mode: str = "topk", W_enc_full: Optional[Tensor] = None,
                  b_enc_full: Optional[Tensor] = None, n_cand: Optional[int] = None,
-                 cand_fn: Optional[Callable] = None, rescore_fn: Optional[Callable] = None):
+                 cand_fn: Optional[Callable] = None, rescore_fn: Optional[Callable] = None,
+                 local_decode_max_t: int = LOCAL_DECODE_MAX_T):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
+        self.local_decode_max_t = local_decode_max_t
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
         # global id of this shard's first feature: equal shards unless the caller says otherwise
@@ -113,6 +141,7 @@ class ShardedSae:
             k_loc = default_k_loc(k, world) if self.collective else k
         k_loc = max(k_loc, -(-k // world))      # the union must hold at least k candidates
         self.k_loc = min(k_loc, k, self.n_loc)
+        prepared = None
         if encode_fn is None:
             from . import ops
 
@@ -132,7 +161,7 @@ class ShardedSae:
                 from . import ops
 
                 assert W_enc_full is not None, "mode='candidates' re-scores against the replicated W_enc"
-                prep_c = ops.prepare_encoder(W_enc_shard)
+                prep_c = prepared if prepared is not None else ops.prepare_encoder(W_enc_shard)
                 cand_fn = lambda x, **ed: ops.shard_candidates(x, self.b_enc, self.b_dec, prep_c, self.n_loc, self.k,
                                                                self.row_offset, self.n_cand,
                                                                set_feature=ed.get("set_feature", -1),
@@ -183,9 +212,17 @@ class ShardedSae:
         return self._merge_gathered(flat, T, kk)
 
     def _encode_candidates(self, x: Tensor, **ed):
+        """-> (join, (own vals, own idx), keep-alive), or None when the shape has no candidate pass (the engine then
+        switches to mode="topk" for good: every rank sees the same shapes, so every rank takes the same turn)."""
+        from ._hip import MsaeNotImplemented
+
         T, G = x.shape[0], self.world
         lo, hi, per = token_slice(T, self.rank, G)
-        recs = self._cand(x, **ed)                                      # [T, stride] uint8
+        try:
+            recs = self._cand(x, **ed)                                  # [T, stride] uint8
+        except MsaeNotImplemented:
+            self.mode = "topk"
+            return None
         if per * G != T:
             recs = torch.cat((recs, recs.new_zeros(per * G - T, recs.shape[1])))
         send = recs.view(G, per, recs.shape[1])
@@ -221,8 +258,9 @@ class ShardedSae:
         if not self.collective:
             return self._encode(x, self.k, **ed)
         if self.mode == "candidates":
-            join, _, _keep = self._encode_candidates(x, **ed)
-            return join()
+            got = self._encode_candidates(x, **ed)
+            if got is not None:
+                return got[0]()
         vals, idx, status = self._encode(x, self.k_loc, **ed)
         mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
@@ -279,7 +317,9 @@ class ShardedSae:
             self.decode_event_i += 1
             ev[0].record()
         self.synchronize()                                   # buffers of the previous gather are free
-        if not self.collective:
+        if not self.collective or (gather and vals.shape[0] <= self.local_decode_max_t):
+            # one GPU -- or a handful of tokens (a steering decode step, features/steering.py:86): every rank holds
+            # W_dec and all tokens' latents, a local decode (5 us) beats any collective
             out = self._decode(idx, vals)
         else:
             T = vals.shape[0]
@@ -324,12 +364,46 @@ class ShardedSae:
             self._pending = None
 
     def forward(self, x: Tensor, async_gather: bool = False) -> dict:
-        if self.collective and self.mode == "candidates":
+        if self.collective and self.mode == "candidates" and x.shape[0] > self.local_decode_max_t:
             # the owner already holds its tokens' results: decode them while the result gather is in flight
-            join, (lv, li), _keep = self._encode_candidates(x)
-            recon = self._decode_local(lv, li, x.shape[0], async_gather=async_gather)
-            vals, idx, status = join()
-            return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
+            got = self._encode_candidates(x)
+            if got is not None:
+                join, (lv, li), _keep = got
+                recon = self._decode_local(lv, li, x.shape[0], async_gather=async_gather)
+                vals, idx, status = join()
+                return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
         vals, idx, status = self.encode(x)
         recon = self.decode(vals, idx, async_gather=async_gather)
         return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
+
+
+class EmulatedShardGroup:
+    """The G ranks of a feature-sharded group run one after the other in ONE process on one GPU, behind the engine
+    interface the hooks use (`encode(x, set_feature=, set_value=, zero_feature=)`, `decode(vals, idx)`): the ranks'
+    local kernels, record / pack layouts, merge kernel and truncation check are the real ones, only the transport is
+    a torch.cat (ShardedSae.encode_emulated*).  For tests and per-rank cost studies on single-GPU boxes."""
+
+    def __init__(self, sae, world: int, mode: str = "topk", **kw):
+        self.engines = [ShardedSae.from_sae(sae, rank=r, world=world, mode=mode, **kw) for r in range(world)]
+        self.mode, self.world = mode, world
+        self.second_round_tokens = 0
+
+    def encode(self, x: Tensor, set_feature: int = -1, set_value: float = 0.0, zero_feature: int = -1):
+        ed = {}
+        if set_feature >= 0:
+            ed.update(set_feature=set_feature, set_value=set_value)
+        if zero_feature >= 0:
+            ed.update(zero_feature=zero_feature)
+        if self.mode == "candidates":
+            from ._hip import MsaeNotImplemented
+
+            try:
+                return ShardedSae.encode_emulated_candidates(self.engines, x, **ed)
+            except MsaeNotImplemented:
+                self.mode = "topk"
+        vals, idx, redo = ShardedSae.encode_emulated(self.engines, x, **ed)
+        self.second_round_tokens += redo
+        return vals, idx, torch.zeros(x.shape[0], dtype=torch.int32, device=x.device)
+
+    def decode(self, vals: Tensor, idx: Tensor, **_):
+        return self.engines[0]._decode(idx, vals)

@@ -162,7 +162,8 @@ class Sae(nn.Module):
         return self._prepared
 
     def encode(self, x: Tensor, *, set_feature: int = -1, set_value: float = 0.0,
-               zero_feature: int = -1, return_status: bool = False, resolve: bool = True):
+               zero_feature: int = -1, return_status: bool = False, resolve: bool = True,
+               differentiable: Optional[bool] = None):
         """Fused encode + TopK (sae.py:183-185).  `set_feature/set_value` and `zero_feature` apply
         the steering / attribution hooks' edits of the dense latents (steering.py:113-114,
         patching/utils.py:43-48) inside the kernel, before TopK.
@@ -171,8 +172,17 @@ class Sae(nn.Module):
         activations: all-zero rows, fewer than k positive latents, tokens the error model of the
         candidate pass does not describe ...) exactly inside the call, on the device; nothing is read
         back, so the method is stream-ordered like every other op.  `status` (return_status=True):
-        0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored."""
-        if torch.is_grad_enabled() and (x.requires_grad or self.encoder.weight.requires_grad) and not return_status:
+        0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored.
+
+        Autograd: the call is one differentiable node (sparse backward through the selected latents) when
+        gradients are enabled and `x` requires grad (the attribution hooks: the LLM's hidden states do) or
+        `differentiable=True` is passed (a custom training loop that wants d/dW from a constant input);
+        plain inference on a loaded module -- whose parameters require grad by default -- saves nothing."""
+        want_grad = torch.is_grad_enabled() and (x.requires_grad if differentiable is None else differentiable)
+        if want_grad and return_status:
+            raise RuntimeError("Sae.encode(return_status=True) returns non-differentiable outputs: call it under "
+                               "torch.no_grad(), or without return_status where gradients must flow")
+        if want_grad:
             # autograd must flow (attribution patching: patching/utils.py:33-58, attribution.py:165):
             # same kernel, as one autograd node with the sparse backward
             (acts, idx), = ops.sparse_encode(x, self.encoder.weight, self.encoder.bias, self.b_dec, self.cfg.k,

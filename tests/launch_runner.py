@@ -84,6 +84,8 @@ def main():
                          ctx_len=16, save_dir=str(out / "cache_image")))
     ls.main(["-m", "llava-tiny", "-t", "describe", "--sae-path", str(sae_dir), "--filters", str(out / "filters.json"),
              "-k", "50", "-s", str(out / "steering")])
+    ls.main(["-m", "llava-tiny", "-t", "describe", "--sae-path", str(sae_dir), "--filters", str(out / "filters.json"),
+             "-k", "50", "-s", str(out / "steering_sharded"), "--shard-sae"])
     # attribution: two prompts with images on disk
     from PIL import Image
 

@@ -130,6 +130,102 @@ def test_autograd_flows_through_the_splice_hook(dev, golden_dir):
                                atol=2e-3 * float(hid.grad.abs().max()))
 
 
+def _legacy_forward_cache(model, inputs, sae_dict, module_to_name, off_features=None):
+    """The reference's get_model_forward_cache_with_sae hook body, call for call (patching/utils.py:33-58):
+    sae.pre_acts -> mask multiply -> sae.select_topk -> sae.decode -> fp16 view -- the LEGACY seam an unmodified
+    reference caller uses (tools/*.py do the same)."""
+    cache = {}
+
+    def forward_cache_hook(module, _inputs, outputs):
+        unpack = list(outputs) if isinstance(outputs, tuple) else [outputs]
+        name = module_to_name[module]
+        sae = sae_dict[name]
+        bs, seq_len, dim = unpack[0].shape
+        latents = sae.pre_acts(unpack[0].flatten(0, 1))
+        if off_features is not None:
+            mask = torch.ones_like(latents)
+            mask[:, off_features] = 0
+            latents = latents * mask
+        top_acts, top_indices = sae.select_topk(latents)
+        sae_out = sae.decode(top_acts, top_indices).to(torch.float16).view(bs, seq_len, dim)
+        cache[name] = sae_out
+        return tuple([sae_out] + unpack[1:]) if isinstance(outputs, tuple) else sae_out
+
+    handles = [mod.register_forward_hook(forward_cache_hook) for mod in module_to_name]
+    try:
+        logits = model(**inputs)["logits"]
+    finally:
+        for h in handles:
+            h.remove()
+    return logits, cache
+
+
+def test_legacy_seam_is_differentiable_and_matches_the_reference(dev, golden_dir):
+    """INTEGRATION route A ("swap the module, no reference source changes") for attribution: the reference's own
+    hook body on this `Sae` under enable_grad -- `pre_acts` and `select_topk` are autograd nodes (dense backward
+    on the f32 MFMA kernel / scatter), so `retain_grad()` + `metric.backward()` work and the per-feature maps equal
+    the reference's (g8).  Gradients also equal the fused path's (sparse backward) on every parameter."""
+    from msae.features.patching import get_logit_diff
+
+    g = np.load(golden_dir / "g8_attribution.npz")
+    attr = _attribution(dev, g)
+    name = str(g["module"])
+    with torch.no_grad():
+        _, clean = _legacy_forward_cache(attr.model, attr.inputs, attr.sae_dict, attr.module_to_name)
+    maps = []
+    for idx in g["indices"].tolist():
+        logits, cor = _legacy_forward_cache(attr.model, attr.inputs, attr.sae_dict, attr.module_to_name, off_features=idx)
+        cor[name].retain_grad()
+        get_logit_diff(logits, attr.answer_ids).backward()
+        maps.append(((clean[name] - cor[name]) * cor[name].grad).detach().sum(-1).cpu())
+        attr._zero_param_grads()
+    got = torch.stack(maps).float().numpy()
+    ref = g["attribution"].astype(np.float32)
+    tol = 2e-2 * np.abs(ref).max()
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+    # parameter gradients through the legacy (dense) graph == through the fused node (sparse backward)
+    sae = attr.sae_dict[name]
+    off = int(g["indices"][0])
+    grads = {}
+    for route in ("legacy", "fused"):
+        if route == "legacy":
+            logits, _ = _legacy_forward_cache(attr.model, attr.inputs, attr.sae_dict, attr.module_to_name, off_features=off)
+        else:
+            from msae.features.patching import get_model_forward_cache_with_sae
+
+            logits, _ = get_model_forward_cache_with_sae(attr.model, attr.inputs, attr.sae_dict, attr.module_to_name,
+                                                         off_features=off)
+        get_logit_diff(logits, attr.answer_ids).backward()
+        grads[route] = [p.grad.detach().clone() for p in (sae.encoder.weight, sae.encoder.bias, sae.W_dec, sae.b_dec)]
+        attr._zero_param_grads()
+    for a, b, nm in zip(grads["legacy"], grads["fused"], ("W_enc", "b_enc", "W_dec", "b_dec")):
+        assert a.abs().max() > 0, nm
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item() + 1e-8, nm
+
+
+def test_encode_does_not_build_a_graph_for_plain_inference(dev):
+    """a loaded Sae's parameters require grad by default; `encode` outside no_grad must not save
+    activations per call unless the INPUT requires grad (or the caller asks for it)."""
+    from msae import Sae, SaeConfig
+
+    sae = Sae(256, SaeConfig(num_latents=8192, k=32), device=dev)
+    x = torch.randn(3, 7, 256, device=dev)
+    out = sae.encode(x)
+    assert not out.top_acts.requires_grad and out.top_acts.shape == (3, 7, 32)
+    xg = x.clone().requires_grad_()
+    o2 = sae.encode(xg)                                   # 3-D input through the differentiable node
+    assert o2.top_acts.requires_grad and torch.equal(o2.top_acts, out.top_acts) and torch.equal(o2.top_indices, out.top_indices)
+    o2.top_acts.sum().backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape and sae.encoder.weight.grad is not None
+    o3 = sae.encode(x, differentiable=True)
+    assert o3.top_acts.requires_grad
+    with pytest.raises(RuntimeError, match="return_status"):
+        sae.encode(xg, return_status=True)
+    with torch.no_grad():
+        _, st = sae.encode(xg, return_status=True)
+    assert st.shape == (3, 7)
+
+
 def test_image_cache_matches_reference(dev, golden_dir):
     """FeatureImageCache.run (cache.py:325-429): `<image>` prompts through the processor, LLaVA forward,
     BOS position dropped before the SAE (so `pos` is BOS-relative), rows offset by shard_size."""
@@ -162,6 +258,54 @@ def test_steering_controller_matches_reference(dev, golden_dir):
     for f, ref in zip(feats, g["clamped"]):
         assert res[f"{module}_feature{f}"]["clamped_resps"] == str(ref), f
         assert res[f"{module}_feature{f}"]["idx"] == f
+
+
+@pytest.mark.parametrize("mode", ["topk", "candidates"])
+def test_steering_controller_on_a_feature_sharded_engine(dev, golden_dir, mode):
+    """SURVEY 8f rank 4 ("N-sharded across 8 GPUs"): the steering hook / controller take a feature-sharded engine in
+    place of the `Sae` (features/steering.py:102-128).  Four shards emulated on one GPU reproduce the REFERENCE's
+    generations (g10): prefill clamp by global feature id on the owning shard, S = 1 decode steps, merge.  The
+    fixture's SAE is too narrow for the candidate pass, so mode="candidates" must fall back to per-shard top-k."""
+    from msae.features.steering import SteeringController
+    from msae.parallel import EmulatedShardGroup
+
+    g = np.load(golden_dir / "g10_steering.npz")
+    model = fakes.TinyLlava(vocab=int(g["vocab"]), d=int(g["d"])).to(dev)
+    module, feats = str(g["module"]), [int(f) for f in g["features"]]
+    group = EmulatedShardGroup(_sae(dev, g), 4, mode=mode)
+    ctl = SteeringController(sae=group, module_name=module, feature_idx=feats, model=model,
+                             processor=fakes.FakeProcessor(int(g["vocab"])), prompt="describe", k=float(g["clamp"]))
+    res = ctl.run()
+    assert res[f"{module}_feature{feats[0]}"]["original_resps"] == str(g["original"])
+    for f, ref in zip(feats, g["clamped"]):
+        assert res[f"{module}_feature{f}"]["clamped_resps"] == str(ref), f
+    assert group.mode == "topk"
+
+
+@pytest.mark.parametrize("mode", ["topk", "candidates"])
+@pytest.mark.parametrize("S", [1, 300])
+def test_hook_reconstruction_on_a_sharded_engine_equals_single_gpu(dev, mode, S):
+    """The hook body (hooks.sae_reconstruct) on a 4-shard engine whose shards DO run the fused candidate pass
+    (8192 features each): prefill-sized and S = 1 inputs, the steering clamp and the attribution mask by global
+    feature id -- the same fp16 bits as on the single-GPU `Sae`."""
+    from msae import Sae, SaeConfig
+    from msae.features.hooks import sae_reconstruct
+    from msae.parallel import EmulatedShardGroup
+
+    torch.manual_seed(5)
+    d, N, k = 256, 32768, 32
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)
+    with torch.no_grad():
+        sae.encoder.bias.copy_(torch.randn(N, device=dev) * 0.02)
+        sae.b_dec.copy_(torch.randn(d, device=dev) * 0.1)
+    group = EmulatedShardGroup(sae, 4, mode=mode)
+    h = torch.randn(1, S, d, device=dev).half()
+    with torch.no_grad():
+        for ed in ({}, {"set_feature": 20000, "set_value": 10.0}, {"zero_feature": 8191}, {"set_feature": 3, "set_value": 0.5}):
+            ref = sae_reconstruct(sae, h, out_dtype=torch.float16, **ed)
+            got = sae_reconstruct(group, h, out_dtype=torch.float16, **ed)
+            assert torch.equal(ref, got), (mode, S, ed)
+    assert group.mode == mode        # the candidate pass exists for this shape: no fallback
 
 
 def test_launch_entry_points_run_under_torchrun(dev, tmp_path):
@@ -198,6 +342,7 @@ def test_launch_entry_points_run_under_torchrun(dev, tmp_path):
     st = json.load(open(tmp_path / "steering" / "layers.1.json"))
     assert sorted(st) == ["layers.1_feature3", "layers.1_feature300", "layers.1_feature77"]
     assert set(st["layers.1_feature3"]) == {"original_resps", "clamped_resps", "idx"}
+    assert json.load(open(tmp_path / "steering_sharded" / "layers.1.json")) == st     # --shard-sae: same results
     # attribution: [n_features * B, S] fp16 per module; batched within first-order tolerance of exact
     ex = load_file(str(tmp_path / "attribution_exact" / "llava-tiny_layers_1.safetensors"))["layers.1"].float()
     ba = load_file(str(tmp_path / "attribution_batched" / "llava-tiny_layers_1.safetensors"))["layers.1"].float()

@@ -48,7 +48,8 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False):
 
     eng = ShardedSae(torch.from_numpy(W_enc[lo:hi]), torch.from_numpy(b_enc[lo:hi]),
                      torch.from_numpy(W_dec), torch.from_numpy(b_dec), k, rank=rank, world=world,
-                     group=dist.group.WORLD, encode_fn=encode_fn, decode_fn=decode_fn, k_loc=k_loc)
+                     group=dist.group.WORLD, encode_fn=encode_fn, decode_fn=decode_fn, k_loc=k_loc,
+                     local_decode_max_t=0)      # (a handful of tokens would be decoded locally: exercise the sharded decode)
     out = eng.forward(torch.from_numpy(x))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(),
              i=out["top_indices"].numpy(), r=out["sae_out"].numpy(), redo=eng.second_round_tokens,
@@ -159,7 +160,7 @@ def _cand_worker(rank, world, port, T, d, N, k, C, out_dir, cluster):
     eng = ShardedSae(torch.from_numpy(W_enc[lo:hi]), torch.from_numpy(b_enc[lo:hi]), torch.from_numpy(W_dec),
                      torch.from_numpy(b_dec), k, rank=rank, world=world, group=dist.group.WORLD,
                      encode_fn=lambda *a: None, decode_fn=decode_fn, mode="candidates", n_cand=C,
-                     cand_fn=cand_fn, rescore_fn=rescore_fn)
+                     cand_fn=cand_fn, rescore_fn=rescore_fn, local_decode_max_t=0)
     out = eng.forward(torch.from_numpy(x))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(), i=out["top_indices"].numpy(),
              r=out["sae_out"].numpy(), fallback=stats["fallback"])
