@@ -10,7 +10,9 @@
 
 template <int N> __device__ __forceinline__ void vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BK, int DEPTH, bool COMPUTE = false>
+// PACKED (round 3): tile-major operands -- the BK-byte k-tile of a 256-row tile is ONE contiguous 256 x BK block
+// ([row tile][k-tile][256][BK]), so a 1-KiB piece is 8 consecutive 128-B lines instead of 8 lines 4 KB apart.
+template <int BK, int DEPTH, bool COMPUTE = false, bool PACKED = false>
 __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
                                                      size_t ld, int nM, int nN, int nk) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -29,6 +31,8 @@ __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__rest
       const int pl = isA ? piece : piece - PIECES / 2;
       const unsigned char *src = (isA ? A + (size_t)(tm * 256 + pl * ROWS_PER_PIECE + lrow) * ld
                                       : B + (size_t)(tn * 256 + pl * ROWS_PER_PIECE + lrow) * ld) + (size_t)kt * BK + lcol;
+      if constexpr (PACKED)
+        src = (isA ? A + ((size_t)tm * nk + kt) * (256 * BK) : B + ((size_t)tn * nk + kt) * (256 * BK)) + pl * 1024 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(smem + slot * SLOT + piece * 1024), 16, 0, 0);
     }
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(512) void stream_kernel(const unsigned char *__rest
 
 // Register path for comparison: the same pieces through global_load_dwordx4 -> VGPR (-> ds_write_b128 when WRITE),
 // one k-tile (PPW x 16 B per lane) in flight while the previous one is written / dropped.
-template <int BK, bool WRITE>
+template <int BK, bool WRITE, bool PACKED = false>
 __global__ __launch_bounds__(512) void stream_reg_kernel(const unsigned char *__restrict__ A, const unsigned char *__restrict__ B,
                                                          size_t ld, int nM, int nN, int nk, int *sink) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -96,6 +100,8 @@ __global__ __launch_bounds__(512) void stream_reg_kernel(const unsigned char *__
       const int pl = isA ? piece : piece - PIECES / 2;
       const unsigned char *src = (isA ? A + (size_t)(tm * 256 + pl * ROWS_PER_PIECE + lrow) * ld
                                       : B + (size_t)(tn * 256 + pl * ROWS_PER_PIECE + lrow) * ld) + (size_t)kt * BK + lcol;
+      if constexpr (PACKED)
+        src = (isA ? A + ((size_t)tm * nk + kt) * (256 * BK) : B + ((size_t)tn * nk + kt) * (256 * BK)) + pl * 1024 + lane * 16;
       r[p] = *reinterpret_cast<const i32x4v *>(src);
     }
   };
@@ -124,15 +130,13 @@ __global__ __launch_bounds__(512) void stream_reg_kernel(const unsigned char *__
   }
   if (acc == 0x12345678) sink[0] = acc;
 }
-template <int BK, bool WRITE>
-void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps, int *sink);
 
 static int g_grid = 256;
-template <int BK, int DEPTH, bool COMPUTE = false>
+template <int BK, int DEPTH, bool COMPUTE = false, bool PACKED = false>
 void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps) {
   const int nM = T / 256, nN = N / 256, nk = d / BK;
   const size_t smem = (size_t)DEPTH * 512 * BK;
-  auto kern = stream_kernel<BK, DEPTH, COMPUTE>;
+  auto kern = stream_kernel<BK, DEPTH, COMPUTE, PACKED>;
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk);
@@ -145,16 +149,16 @@ void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, in
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
   }
   const double bytes = (double)nM * nN * nk * 512.0 * BK;
-  printf("%sk-tile %3d B x ring %d (%3zu KB LDS, %3d KB in flight): %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n",
-         COMPUTE ? "+reads+MFMA " : "", BK, DEPTH,
+  printf("%s%sk-tile %3d B x ring %d (%3zu KB LDS, %3d KB in flight): %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n",
+         PACKED ? "tile-major " : "row-major  ", COMPUTE ? "+reads+MFMA " : "", BK, DEPTH,
          smem >> 10, (DEPTH - 1) * 512 * BK >> 10, best, bytes / best / 1e6 / g_grid, bytes / best / 1e9, best * 1e3 / ((double)nM * nN * d / 128 / g_grid));
 }
 
-template <int BK, bool WRITE>
+template <int BK, bool WRITE, bool PACKED = false>
 void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d, int reps, int *sink) {
   const int nM = T / 256, nN = N / 256, nk = d / BK;
   const size_t smem = (size_t)2 * 512 * BK;
-  auto kern = stream_reg_kernel<BK, WRITE>;
+  auto kern = stream_reg_kernel<BK, WRITE, PACKED>;
   CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(g_grid), dim3(512), smem, 0, A, B, (size_t)d, nM, nN, nk, sink);
@@ -167,8 +171,8 @@ void run_reg(const unsigned char *A, const unsigned char *B, int T, int N, int d
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
   }
   const double bytes = (double)nM * nN * nk * 512.0 * BK;
-  printf("k-tile %3d B via VGPRs%s: %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n", BK,
-         WRITE ? " + ds_write_b128 + barrier" : " (dropped)             ", best, bytes / best / 1e6 / g_grid, bytes / best / 1e9,
+  printf("%sk-tile %3d B via VGPRs%s: %7.3f ms  %6.1f GB/s per CU  %5.2f TB/s  = %5.2f us per 64 KB\n",
+         PACKED ? "tile-major " : "row-major  ", BK, WRITE ? " + ds_write_b128 + barrier" : " (dropped)             ", best, bytes / best / 1e6 / g_grid, bytes / best / 1e9,
          best * 1e3 / ((double)nM * nN * d / 128 / g_grid));
 }
 
@@ -179,19 +183,30 @@ int main(int argc, char **argv) {
   unsigned char *A, *B;
   CK(hipMalloc(&A, (size_t)T * d)); CK(hipMalloc(&B, (size_t)N * d));
   CK(hipMemset(A, 1, (size_t)T * d)); CK(hipMemset(B, 2, (size_t)N * d));
-  run<128, 2>(A, B, T, N, d, 5);
-  run<64, 2>(A, B, T, N, d, 5);
-  run<64, 3>(A, B, T, N, d, 5);
-  run<64, 4>(A, B, T, N, d, 5);
-  run<32, 4>(A, B, T, N, d, 5);
-  run<32, 8>(A, B, T, N, d, 5);
-  run<128, 2>(A, B, T, N, d, 5);
-  run<128, 2, true>(A, B, T, N, d, 5);
-  run<64, 4, true>(A, B, T, N, d, 5);
-  run<64, 3, true>(A, B, T, N, d, 5);
-  run<128, 2, true>(A, B, T, N, d, 5);
+  if (argc > 4 && atoi(argv[4]) == 1) {      // random bytes instead of constants (DVFS: constant operands clock higher)
+    unsigned char *h = (unsigned char *)malloc((size_t)N * d);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < (size_t)N * d; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned char)(x >> 24); }
+    CK(hipMemcpy(B, h, (size_t)N * d, hipMemcpyHostToDevice));
+    CK(hipMemcpy(A, h, (size_t)T * d, hipMemcpyHostToDevice));
+    free(h);
+  }
   int *sink; CK(hipMalloc(&sink, 64));
-  run_reg<128, false>(A, B, T, N, d, 5, sink);
-  run_reg<128, true>(A, B, T, N, d, 5, sink);
+  for (int rep = 0; rep < 2; ++rep) {         // A/B interleaved, twice
+    run<128, 2>(A, B, T, N, d, 5);
+    run<128, 2, false, true>(A, B, T, N, d, 5);
+    run<64, 4>(A, B, T, N, d, 5);
+    run<64, 4, false, true>(A, B, T, N, d, 5);
+    run<32, 8>(A, B, T, N, d, 5);
+    run<32, 8, false, true>(A, B, T, N, d, 5);
+    run<128, 2, true>(A, B, T, N, d, 5);
+    run<128, 2, true, true>(A, B, T, N, d, 5);
+    run<64, 4, true>(A, B, T, N, d, 5);
+    run<64, 4, true, true>(A, B, T, N, d, 5);
+    run_reg<128, false>(A, B, T, N, d, 5, sink);
+    run_reg<128, false, true>(A, B, T, N, d, 5, sink);
+    run_reg<128, true>(A, B, T, N, d, 5, sink);
+    run_reg<128, true, true>(A, B, T, N, d, 5, sink);
+  }
   return 0;
 }
