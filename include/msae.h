@@ -127,7 +127,9 @@ int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const
  * scratch of f32[rows][N], 2048 rows at N = 131072, sized on the device -- no host round trip).
  * Values >= 2 exist only between the kernels of one call: 2 | reason bits (4 list overflow, 8
  * threshold <= 0, 16 fewer than k candidates, 32 too many rows inside the band, 64 a re-scored pair
- * was more than 6 sigma from its coarse value: the error model does not describe this token). */
+ * was more than 6 sigma from its coarse value: the error model does not describe this token, 128 the token's
+ * shape is outside the model by a deterministic test -- the dims its int8 scale rounds to zero carry more than 4
+ * bands of energy). */
 size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,

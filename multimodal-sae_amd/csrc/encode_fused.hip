@@ -45,6 +45,7 @@
 
 #include "common.h"
 #include "gemm_mfma.h"
+#include "gemm_mfma64.h"
 
 int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                          const float *b_dec, const int *rows, const int *n_rows, int T, int d, int N,
@@ -76,7 +77,7 @@ constexpr int EXACT_T_MAX = 0;      // fused path for every T (T=1: 1 GiB bf16 s
 struct Prepared {
   unsigned magic;
   int N, d, S;
-  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, bytes;
+  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, off_wqp, off_wqsp, bytes;
 };
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 
@@ -87,6 +88,8 @@ __host__ __device__ inline bool i8_shape_ok(int N, int d) { return fast_shape_ok
 
 // 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | row statistics (sw, Q_i8, |W_n|^2, Q_bf) f32x4 [N]
 // and [S] | bf16-pass column constants (1, Q_bf, 0, 0) f32x4 [N] and [S] | Wq int8 [N][d] | sample int8 [S][d]
+// | Wq tile-major [N/256][d/128][256][128] | sample tile-major (the candidate GEMM's operands, gemm_mfma.h; the
+// row-major copies feed the S = 1 weight streams and the outlier-column gather)
 inline Prepared make_prepared(int N, int d) {
   Prepared p{};
   p.magic = PREP_MAGIC;
@@ -103,6 +106,8 @@ inline Prepared make_prepared(int N, int d) {
   p.off_colbf_s = take((size_t)p.S * 16);
   p.off_wq = take(q ? (size_t)N * d : 0);
   p.off_wqs = take(q ? (size_t)p.S * d : 0);
+  p.off_wqp = take(q ? (size_t)N * d : 0);
+  p.off_wqsp = take(q ? (size_t)p.S * d : 0);
   p.bytes = o;
   return p;
 }
@@ -141,6 +146,16 @@ inline bool resolve_opts(const msae_options *o, CallOpts &c) {
 unsigned long long *g_timeline = nullptr;   // tuning builds only
 #endif
 constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
+// Deterministic per-token guard of the int8 pass.  The x-side residual is modelled as independent rounding
+// noise of variance sx^2 / 12 per dim.  The dims that round to ZERO are the exception: their residual is the
+// activation itself, i.e. structured -- a feature whose weights correlate with that part of the token (cosine c) is off by
+// up to c sqrt(E0) |W_n|, E0 = their energy, against an x-side band of z sx |W_n| / sqrt(12) = 2.02 sx |W_n| at the default
+// z = 7.  For a well-scaled Gaussian token sqrt(E0) = 2.06 sx (one band); a token whose scale is dictated by an isolated
+// large dim that the batch-level outlier list did not take rounds most of its dims to zero and sqrt(E0) approaches the
+// token's whole norm.  Tokens with sqrt(E0) > GUARD_E0_SX * sx (4 default bands: a feature would need a cosine above
+// 0.25 with the zeroed part to leave its band) are not trusted to the statistical model: they are flagged (reason 128)
+// and recomputed by the exact path inside the call.  The test does not move with msae_options::guard_z.
+constexpr float GUARD_E0_SX = 4.f * 7.f * 0.288675f;   // 4 bands of z = 7: 8.08
 #ifndef MSAE_GUARD_ZETA
 #define MSAE_GUARD_ZETA 1.f
 #endif
@@ -200,6 +215,23 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
 }
 
 // ---- per-row statistics + int8 operands ---------------------------------------------------------------
+// Tile-major int8 operand of the candidate GEMM (GemmOperands::packed): byte offset of the 16-B chunk at column c
+// (c % 16 == 0) of row r, with the LDS image's chunk permutation applied (gemm_swz).  d % 128 == 0.
+// layout 1: 128-byte k-tiles (gemm_mfma.h), layout 2: 64-byte k-tiles (gemm_mfma64.h: packed64_off)
+__host__ __device__ __forceinline__ size_t packed_off(size_t r, int c, int d, int layout = 1) {
+  if (layout == 2) return packed64_off(r, c, d);
+  const size_t rt = r >> 8, ri = r & 255;
+  const int kt = c >> 7, ch = (c >> 4) & 7;
+  return ((rt * (size_t)(d >> 7) + kt) * 256 + ri) * 128 + (size_t)((ch ^ (int)((ri >> 1) & 7)) << 4);
+}
+// which operand layout / candidate GEMM this process uses: 1 = tile-major, 128-byte k-tiles in a 2-slot ring (default);
+// 2 = tile-major, 64-byte k-tiles in a 4-slot ring (MSAE_GEMM_RING64=1); 0 = row-major (MSAE_GEMM_ROWMAJOR=1).  Read at
+// every call (an immutable property of the process environment: prepare and encode must agree).
+inline int gemm_layout() {
+  if (getenv("MSAE_GEMM_ROWMAJOR")) return 0;
+  return getenv("MSAE_GEMM_RING64") ? 2 : 1;
+}
+
 // W side (once per weight load), one 256-thread workgroup per row:
 //   sw[n] = max|W[n][:]| / 127,  |W_n|^2,  |W_n|_4^2 = sqrt(sum w^4)   -> wstat[n] = (sw, Q_i8, |W_n|^2, Q_bf)
 //   Wq[n][c] = rint(W[n][c] / sw[n])   (QUANT; d % 128 == 0)
@@ -218,7 +250,9 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
                                                               f32x4 *__restrict__ wstat, f32x4 *__restrict__ wstat_s,
                                                               f32x4 *__restrict__ colbf, f32x4 *__restrict__ colbf_s,
                                                               signed char *__restrict__ wq,
-                                                              signed char *__restrict__ wqs) {
+                                                              signed char *__restrict__ wqs,
+                                                              signed char *__restrict__ wqp,
+                                                              signed char *__restrict__ wqsp, int layout) {
   __shared__ float red[3][4];
   const int n = blockIdx.x;
   const float *row = W + (size_t)n * d;
@@ -274,7 +308,11 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
         packed[q] = (int)w;
       }
       *reinterpret_cast<i32x4 *>(wq + (size_t)n * d + c) = packed;
-      if (samp) *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
+      *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
+      if (samp) {
+        *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
+        *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
+      }
     }
   }
 }
@@ -357,11 +395,12 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
                                                       const unsigned char *__restrict__ is_out,
                                                       signed char *__restrict__ xq,
                                                       signed char *__restrict__ xqo,
-                                                      f32x4 *__restrict__ rowc, float zz12) {
+                                                      f32x4 *__restrict__ rowc, float zz12, int tile_major) {
   __shared__ float red[3][4];
   const int t = blockIdx.x;
+  auto xq_at = [&](int c) { return xq + (tile_major ? packed_off((size_t)t, c, d, tile_major) : (size_t)t * d + c); };
   if (t >= T) {
-    for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(xq + (size_t)t * d + c) = i32x4{0, 0, 0, 0};
+    for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(xq_at(c)) = i32x4{0, 0, 0, 0};
     if (threadIdx.x < 8) *reinterpret_cast<i32x4 *>(xqo + (size_t)t * MAX_OUT + threadIdx.x * 16) = i32x4{0, 0, 0, 0};
     if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
@@ -401,8 +440,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   const float scale = m_in > 0.f ? m_in / 127.f : (m_out > 0.f ? m_out / 127.f : 1.f);
   int m = (int)ceilf(m_out / (127.f * scale));
   m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
-  if (threadIdx.x == 0) rowc[t] = f32x4{scale, (float)m, zz12 * ss, 0.f};
   const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
+  float e0 = 0.f;                              // energy of the non-outlier dims that round to zero (GUARD_E0_BANDS)
   for (int c = threadIdx.x * 16; c < d; c += 4096) {
     i32x4 packed;
 #pragma unroll
@@ -412,13 +451,25 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
       unsigned w = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int iv = ((flags >> (8 * e)) & 0xFFu) ? 0 : (int)rintf(v[e] * inv);
+        const bool outl = ((flags >> (8 * e)) & 0xFFu) != 0;
+        int iv = outl ? 0 : (int)rintf(v[e] * inv);
         iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
+        e0 += (!outl && iv == 0) ? v[e] * v[e] : 0.f;
         w |= ((unsigned)iv & 0xFFu) << (8 * e);
       }
       packed[q] = (int)w;
     }
-    *reinterpret_cast<i32x4 *>(xq + (size_t)t * d + c) = packed;
+    *reinterpret_cast<i32x4 *>(xq_at(c)) = packed;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) e0 += __shfl_xor(e0, off, 64);
+  __syncthreads();                             // red[] of the first reduction has been consumed
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = e0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    e0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float guard = e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale ? 1.f : 0.f;
+    rowc[t] = f32x4{scale, (float)m, zz12 * ss, guard};
   }
   if (threadIdx.x < MAX_OUT) {
     const int dim = odims[threadIdx.x];
@@ -523,6 +574,7 @@ __global__ __launch_bounds__(1024) void band_refs_kernel(const f32x4 *__restrict
 // N=131072): 256x256 tiles of 128-B k-rows, 2-slot ring, 8 waves as 2x4.
 using GemmBf16 = GemmCfg<256, 256, 2, 2, 4, false>;
 using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
+using GemmI8R64 = GemmCfg64<256, 256, 2, 4, true>;
 constexpr int G_BM = GemmBf16::BM;
 
 // ---- candidate select + exact re-score ----------------------------------------------------------
@@ -803,6 +855,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
 
   MSAE_RTL(3);
   const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
+  const bool guarded = !EXT && rc[3] != 0.f;     // the token's shape is outside the noise model (quant_x_kernel): exact path
+  if (guarded) target = 0;                       // (no row is read for it here)
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
   bool ok = false, viol = false;
   int rounds = 0;
@@ -907,8 +961,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     const bool have_k = done + has_set >= p.k;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
     const int needed = have_k ? count_needed(v_k) : n;          // candidates with u >= v_k
-    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f;
-    if (ok || viol || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
+    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f && !guarded;
+    if (ok || viol || guarded || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
     target = needed > done ? needed : done + 1;
     if (target > lim) target = lim;
     __syncthreads();
@@ -930,7 +984,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // 32 more than r_max rows needed / v_k not above tau, 64 a re-scored pair contradicted the error
     // model); the exact fallback rewrites it to 1 once it has recomputed t
     const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
-                       (done + has_set < p.k ? 16 : 0) | (viol ? 64 : 32);
+                       (done + has_set < p.k ? 16 : 0) | (guarded ? 128 : (viol ? 64 : 32));
     if (p.status) p.status[t] = ok ? 0 : reason;
 #ifdef MSAE_RESCORE_DEBUG   // rows / rounds histogram (tools/rescore_stats.py); breaks the status contract
     if (p.status && ok) p.status[t] = (rounds << 24) | (first_target << 12) | done;
@@ -960,7 +1014,8 @@ __global__ __launch_bounds__(64) void pack_candidates_kernel(PackArgs p) {
   const int cnt = p.cnt[t];
   const int n = cnt < p.cap ? cnt : p.cap;
   const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
-  const bool bounded = cnt <= p.cap && tau > 0.f;        // list complete and a real threshold behind it
+  // list complete, a real threshold behind it, and a token the noise model describes (rowc[3]: quant_x_kernel's guard)
+  const bool bounded = cnt <= p.cap && tau > 0.f && p.rowc[t][3] == 0.f;
   const int nj = bounded ? (n + 63) >> 6 : 0;            // key slots in use (wave-uniform)
   unsigned long long kreg[PK];
 #pragma unroll
@@ -1816,6 +1871,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     signed char *wqos = reinterpret_cast<signed char *>(ws + pl.off_wqos);
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
+    // tile-major operands for the candidate GEMM (MSAE_GEMM_ROWMAJOR=1: the row-major copies, for A/B runs)
+    const int tile_major = gemm_layout();
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
       hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
@@ -1825,21 +1882,22 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
-      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12);
+      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
-                         T, d, odims, is_out, xq, xqo, rowc, zz12);
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
                        reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp);
     colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(xq); op_main.ldA = d;
-    op_main.B = reinterpret_cast<const unsigned char *>(wq); op_main.ldB = d;
-    op_main.nk = d / 128;
+    op_main.B = tile_major ? prepared + pp.off_wqp : reinterpret_cast<const unsigned char *>(wq); op_main.ldB = d;
+    op_main.nk = tile_major == 2 ? d / 64 : d / 128;
+    op_main.packed = tile_major;
     op_main.Ao = reinterpret_cast<const unsigned char *>(xqo);
     op_main.Bo = reinterpret_cast<const unsigned char *>(wqo);
     op_main.n_out = odims + MAX_OUT;
     op_samp = op_main;
-    op_samp.B = reinterpret_cast<const unsigned char *>(wqs);
+    op_samp.B = tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
   } else {
     hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z);
@@ -1863,7 +1921,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #ifdef MSAE_GEMM_TIMELINE
     ep.timeline = nullptr;
 #endif
-    const int grc = pl.i8 ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
+    const int grc = pl.i8 ? (op_samp.packed == 2 ? gemm64_launch<GemmI8R64, true>(op_samp, T, pl.Tp, pl.S, ep, s)
+                                                 : gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s))
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
     if (grc) return grc;
   }
@@ -1887,7 +1946,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
     ep.timeline = g_timeline;
 #endif
-    const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s)
+    const int grc = pl.i8 ? (op_main.packed == 2 ? gemm64_launch<GemmI8R64, false>(op_main, T, pl.Tp, N, ep, s)
+                                                 : gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s))
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
     if (grc) return grc;
   }
@@ -2024,10 +2084,11 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
     if ((modes & 2) && i8_shape_ok(N, d))   // row statistics (both passes' error bands) + int8 operands
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
                          colbf_s, reinterpret_cast<signed char *>(base + p.off_wq),
-                         reinterpret_cast<signed char *>(base + p.off_wqs));
+                         reinterpret_cast<signed char *>(base + p.off_wqs), reinterpret_cast<signed char *>(base + p.off_wqp),
+                         reinterpret_cast<signed char *>(base + p.off_wqsp), gemm_layout() == 2 ? 2 : 1);
     else
       hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
-                         colbf_s, (signed char *)nullptr, (signed char *)nullptr);
+                         colbf_s, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, 1);
   }
   return msae_launch_status();
 }

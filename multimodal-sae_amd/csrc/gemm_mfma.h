@@ -101,6 +101,12 @@ struct GemmOperands {
   // multiplied by the token's integer multiplier m (GemmEpilogue::rowc[t][1]) after it
   const unsigned char *Ao, *Bo;
   const int *n_out;              // device: number of outlier dims actually present (the tile is compact from column 0)
+  // Tile-major operands (round 3): A and B are stored [row tile of BM / BN rows][k-tile][row in tile][128 B] with the LDS
+  // image's chunk permutation already applied (position p of row r holds the row's 16-B chunk p ^ swz(r)), so a 1-KiB
+  // staging piece is ONE contiguous kilobyte -- eight consecutive 128-B lines instead of eight lines a leading
+  // dimension apart -- and every lane's source offset is lane * 16.  Measured on the stream alone (tools/dma_depth,
+  // profiles/r03_dma_tile_major.txt): 43.2 -> 47.7 GB/s per CU with the 2 x 128 B ring, 50.6 -> 65.9 with 4 x 64 B.
+  int packed;
 };
 
 // FLAGS:
@@ -127,7 +133,8 @@ struct GemmCfg {
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 2304;
   static constexpr int PF_SINK_BYTES = 256;      // where the L2-warming loads of the k-loop land (never read)
-  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8 + PF_SINK_BYTES;
+  static constexpr int GRP_BYTES = 256;          // integer-prefilter constants of the tile's 16 row groups (MSAE_EPI_INT)
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8 + PF_SINK_BYTES + GRP_BYTES;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
@@ -203,6 +210,24 @@ __device__ __forceinline__ void gemm_put_b(GemmBRegs &br, unsigned char *lds, in
   asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\t"
                "ds_write_b128 %0, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                :: "v"(dst), "v"(br.r[0]), "v"(br.r[1]), "v"(br.r[2]), "v"(br.r[3]) : "memory");
+}
+
+// tile-major operands: tileA / tileB = the 32-KB block of this k-tile of the A / B row tile (wave-uniform)
+template <class C>
+__device__ __forceinline__ void gemm_stage_packed(const unsigned char *__restrict__ tileA,
+                                                  const unsigned char *__restrict__ tileB, unsigned char *lds,
+                                                  int slot, int wave, int lane) {
+  unsigned char *base = lds + slot * C::STAGE_BYTES;
+  const unsigned voff = (unsigned)lane << 4;
+#pragma unroll
+  for (int i = 0; i < C::PPW; ++i) {
+    const int piece = wave * C::PPW + i;               // wave-uniform
+    const bool isA = piece < C::A_PIECES;
+    const unsigned char *sbase = isA ? tileA + piece * 1024 : tileB + (piece - C::A_PIECES) * 1024;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(base + piece * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+  }
 }
 
 // this wave's even share (PPW pieces) of one k-tile
@@ -297,11 +322,16 @@ __device__ __forceinline__ void gemm_read_frags(i32x4 (&a)[C::MI], i32x4 (&b)[C:
   a[2] = lds_read_b128<2 * 4096>(addrA); a[3] = lds_read_b128<3 * 4096>(addrA);
   b[0] = lds_read_b128<0 * 4096>(addrB); b[1] = lds_read_b128<1 * 4096>(addrB);
 }
-// `mid` runs between k-steps 1 and 2 (the reads of k-steps 2 and 3 are in flight across it): the waves that
-// issue the next k-tile's LDS-DMA there instead of before their first MFMA (gemm_kernel: stagger)
+// `mid` runs behind the MFMAs of k-step AT (default: between k-steps 1 and 2, the reads of k-steps 2 and 3 in flight
+// across it): the waves that issue the next k-tile's LDS-DMA there instead of before their first MFMA (gemm_kernel:
+// stagger)
+#ifndef MSAE_GEMM_STAGGER_AT
+#define MSAE_GEMM_STAGGER_AT 1
+#endif
 template <class C, class F>
 __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                                  int wr, int wc, int l31, int kh, F &&mid) {
+  constexpr int AT = MSAE_GEMM_STAGGER_AT;
   static_assert(C::KS == 4, "four k-steps per tile");
   const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
   const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
@@ -316,12 +346,14 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
   gemm_read_frags<C>(a0, b0, rowA + off[2], rowB + off[2]);
+  if constexpr (AT == 0) mid();
   lgkm_wait_tied<6, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
   gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
-  mid();
+  if constexpr (AT == 1) mid();
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
+  if constexpr (AT == 2) mid();
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
 }
@@ -495,6 +527,73 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
         // round trip whenever ANY lane of the wave has one (27 % of the elements): 0.55 ms of the pass.  So
         // the 16 outputs of this lane's column are tested branch-free -- count, last survivor's value and
         // position -- and the lane reserves its queue slots with ONE LDS atomic per 16 outputs.
+#if defined(MSAE_EPI_INT)
+        if constexpr (C::I8) {
+          // Integer prefilter.  The exact test  float(acc) sx_t sw_n + b_n + h_n B_t > tau_t  is, for sx_t, sw_n > 0,
+          //   acc > alpha_t gamma_n - beta_t delta_n - eps_t eta_n     (alpha = tau/sx, beta = 1/sx, eps = B/sx;
+          //                                                              gamma = 1/sw, delta = b/sw, eta = h/sw)
+          // and over the 16 rows this lane holds of block i (one row group) the right side is at least
+          //   I = alpha_min gamma_n - max_t(beta_t delta_n) - eps_max eta_n,
+          // ONE integer per (lane, i, j): the hot loop is one v_cmp_gt_i32 per output plus two bookkeeping
+          // operations (last passing accumulator, 16-bit pass mask) instead of cvt + 2 mul + add + fma + cmp + 3.
+          // The float test itself moves to the queue flush, which sees only what passed (~1 % of the outputs).
+          const f32x4 gc = reinterpret_cast<const f32x4 *>(smem + C::LDS_BYTES - C::GRP_BYTES)[(wr * C::MI + i) * 2 + kh];
+          int I_int = 0x7FFFFFFF;                                   // nothing passes
+          if (c_live[j] && gc[0] < __builtin_inff()) {
+            const float sw = c_sw[j];
+            if (sw > 0.f) {
+              const float gam = 1.f / sw, del = c_bias[j] * gam, eta = c_h[j] * gam;
+              const float t0 = gc[0] * gam, t1 = (del > 0.f ? gc[1] : gc[2]) * del, t2 = gc[3] * eta;
+              const float ir = t0 - t1 - t2;
+              const float safe = ir - (3e-5f * (__builtin_fabsf(t0) + __builtin_fabsf(t1) + __builtin_fabsf(t2)) + 2.f);
+              I_int = (safe == safe) ? (safe >= 2147483520.f ? 0x7FFFFFFF : (safe <= -2147483520.f ? (int)0x80000000 : (int)__builtin_floorf(safe)))
+                                     : (int)0x80000000;            // NaN: let everything through to the exact test
+            } else {
+              // all-zero weight row: the value is the bias whatever the token; passes iff b_n beta_t > alpha_t somewhere
+              I_int = (c_bias[j] > 0.f && c_bias[j] * gc[1] * 1.0001f > gc[0]) ? (int)0x80000000 : 0x7FFFFFFF;
+            }
+          }
+          int hv = 0;
+          unsigned mask = 0u;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int a = __builtin_bit_cast(i32x16, acc[i][j])[e];
+            // mask = 2 mask + (a > I);  hv = (a > I) ? a : hv
+            asm volatile("v_cmp_gt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                         : "+v"(hv), "+v"(mask) : "v"(a), "v"(I_int) : "vcc");
+          }
+          if (mask) {
+            const unsigned cnt = (unsigned)__builtin_popcount(mask);
+            unsigned slot = atomicAdd(q_count, cnt);                          // LDS atomic
+            auto push = [&](int a, int e) {
+              const int row = row_of(e);
+              if (slot < QCAP) {
+                queue[slot] = ((unsigned long long)(unsigned)a << 32) | (unsigned)(row << 16 | col);
+              } else {                                                          // queue full: slow path, exact test here
+                const float v = (float)a * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
+                const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
+                if (u > row_c[row]) {
+                  const int t = m0 + row;
+                  const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+                  const int gslot = atomicAdd(ep.cnt + t, 1);
+                  if (gslot < ep.cap)
+                    ep.cand[(size_t)t * ep.cap + gslot] =
+                        ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+                }
+              }
+              ++slot;
+            };
+            if (cnt == 1) {
+              push(hv, 15 - __builtin_ctz(mask));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                if ((mask >> (15 - e)) & 1u) push(__builtin_bit_cast(i32x16, acc[i][j])[e], e);
+            }
+          }
+          continue;
+        }
+#endif
 #ifdef MSAE_EPI_BALLOT
         // wave-level bookkeeping: the 16 tests leave 16 lane masks in SGPRs; their population counts, the ONE LDS
         // atomic of the wave and the slot of every survivor (mbcnt) come from those masks on the scalar unit, so the
@@ -598,7 +697,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
+#if defined(MSAE_EPI_INT)
+      // the queue holds raw accumulators: the value is formed here with the hot loop's expression (same bits)
+      const float v = C::I8 ? (float)(int)(unsigned)(e >> 32) * (row_c[C::NT + row] * col_c[C::NT + col]) + col_c[col]
+                            : __uint_as_float((unsigned)(e >> 32));
+#else
       const float v = __uint_as_float((unsigned)(e >> 32));
+#endif
       const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));   // the exact upper value
       if (!(u > row_c[row])) continue;
       const int t = m0 + row;
@@ -734,7 +839,11 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 #else
       int kq = tile - lead + krot;                         // (a select, no control flow: see gemm_stage_pieces)
       kq -= kq >= op.nk ? op.nk : 0;
-      gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)kq * C::ROWB, smem, slot, wave, sl_main);
+      if (op.packed)                                       // wave-uniform
+        gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES,
+                             op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES, smem, slot, wave, lane);
+      else
+        gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)kq * C::ROWB, smem, slot, wave, sl_main);
 #endif
     }
   };
@@ -794,7 +903,10 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (kt + 1 < ntiles) { if (!(PRESTAGE && lead && kt == 0)) stage(m0, n0, kt + 1, (seq + 1) & 1); }
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     };
-#ifdef MSAE_GEMM_STAGGER
+#ifndef MSAE_GEMM_STAGGER
+#define MSAE_GEMM_STAGGER 1   // round 3: on by default (-4 % on the main pass together with tile-major operands, two boxes:
+#endif                        // profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt); 0 = off, 2 = odd waves
+#if MSAE_GEMM_STAGGER
     // Waves w and w + 4 share a SIMD.  If both issue their eight LDS-DMA pieces right behind the barrier (~700
     // cycles of issue each) the SIMD's MFMA pipe idles for that long in every k-tile; so the upper four waves
     // start with MFMAs on the data already in LDS and issue their pieces between k-steps 1 and 2, while their
@@ -879,6 +991,25 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       side5 = (q > 0.f || side3 > 0.f || side4 > 0.f) ? __builtin_sqrtf(h2) * 1.00001f : 0.f;
     }
     side[5 * C::NT + tid_] = side5;
+#if defined(MSAE_EPI_INT)
+    if constexpr (C::I8) {
+      // per 16-row group (32-row block b = row >> 5, half kh = (row >> 2) & 1): min tau/sx, max & min 1/sx, max B/sx over
+      // its live rows (a padded / degenerate row has tau = +inf and never passes)
+      float al = __builtin_inff(), bmx = 0.f, bmn = __builtin_inff(), emx = 0.f;
+      if (tid_ < C::BM && side0 < __builtin_inff() && side1 > 0.f) {
+        const float inv = 1.f / side1;
+        al = side0 * inv; bmx = inv; bmn = inv; emx = side5 * inv;
+      }
+#pragma unroll
+      for (int sh = 0; sh < 4; ++sh) {
+        const int off = sh == 0 ? 1 : (sh == 1 ? 2 : (sh == 2 ? 8 : 16));
+        al = fminf(al, __shfl_xor(al, off, 64)); bmx = fmaxf(bmx, __shfl_xor(bmx, off, 64));
+        bmn = fminf(bmn, __shfl_xor(bmn, off, 64)); emx = fmaxf(emx, __shfl_xor(emx, off, 64));
+      }
+      if (tid_ < C::BM && (lane & 27) == 0)
+        reinterpret_cast<f32x4 *>(smem + C::LDS_BYTES - C::GRP_BYTES)[(tid_ >> 5) * 2 + ((tid_ >> 2) & 1)] = f32x4{al, bmx, bmn, emx};
+    }
+#endif
   }
   // behind the epilogue's first barrier every wave is done with the last k-tile's slot: the next tile's first main
   // k-tile lands there while the epilogue runs (its outlier tile is already in the other slot)
@@ -891,7 +1022,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 // Host launcher.  Requires Tp % BM == 0 and N % BN == 0 (checked by the caller's plan).
 template <class C, bool DENSE>
 inline int gemm_launch(const GemmOperands &op, int T, int Tp, int N, const GemmEpilogue &ep, hipStream_t s) {
-  if (Tp % C::BM || N % C::BN || op.nk <= 0 || op.ldA != op.ldB || op.ldA % 128) return MSAE_EINVAL;
+  if (Tp % C::BM || N % C::BN || op.nk <= 0 || op.ldA != op.ldB || op.ldA % 128 || op.packed > 1) return MSAE_EINVAL;
   const int nM = Tp / C::BM, nN = N / C::BN;
   auto kern = gemm_kernel<C, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));

@@ -189,9 +189,10 @@ class Sae(nn.Module):
                                              prepared=self._prepared_weights(), set_feature=set_feature,
                                              set_value=set_value, zero_feature=zero_feature)
             return EncoderOutput(acts, idx)
-        acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
-                                            self._prepared_weights(), self.cfg.k, set_feature,
-                                            float(set_value), zero_feature)
+        with torch.no_grad():      # (a custom op without an autograd formula would hang a raising node on the outputs)
+            acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
+                                                self._prepared_weights(), self.cfg.k, set_feature,
+                                                float(set_value), zero_feature)
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 

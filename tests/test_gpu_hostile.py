@@ -239,6 +239,44 @@ def test_stale_operands_are_caught_by_the_model_check(dev):
     assert torch.equal(i, ei) and torch.equal(v, ev)
 
 
+def test_token_shape_guard_routes_mis_scaled_tokens_to_the_exact_path(dev):
+    """a deterministic per-token guard beside the statistical band.  Every second token carries one isolated
+    huge dim of its own -- 512 distinct dims, too many and too evenly spread for the batch-level outlier list -- so
+    its int8 scale (3.9 sigma per step) rounds 95 % of its dims to zero and the x-side residual is the token itself,
+    not rounding noise: sqrt(E0) = 54 sigma against 4 bands = 32.  Such tokens are flagged by the guard (reason 128) and
+    recomputed exactly; the ordinary tokens of the same batch are not touched; outputs equal the exact path bit for
+    bit either way.  (At d = 1024 the same spike cannot trip it: the token's whole inlier norm is below 4 bands.)"""
+    from msae import ops
+
+    d, N, T, k = 4096, 16384, 1024, 32
+    W, b, bd = hostile.weights("gauss", N, d, dev, seed=15)
+    g = torch.Generator(device=dev).manual_seed(16)
+    x = torch.randn(T, d, generator=g, device=dev)
+    odd = torch.arange(0, T, 2, device=dev)
+    x[odd, (odd * 7 + 3) % d] = 500.0                                # every second token: its own spike
+    x = x.to(torch.bfloat16)
+    prepared = ops.prepare_encoder(W)
+    ops.set_status_detail(True)
+    try:
+        v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)
+    finally:
+        ops.set_status_detail(False)
+    ev, ei = _exact(ops, x, W, b, bd, k)
+    assert torch.equal(i, ei) and torch.equal(v, ev)
+    guarded = ((status >> 8) & 128) != 0
+    print(f"\nshape guard: {int(guarded.sum())} of {T} tokens flagged; plain tokens flagged: {int(guarded[1::2].sum())}")
+    assert int(guarded[0::2].sum()) == T // 2
+    assert int(guarded[1::2].sum()) == 0 and int((status[1::2] != 0).sum()) <= 2
+    # ordinary residual-stream batches never trip it
+    x2 = hostile.activations(4096, d, dev, seed=17)
+    ops.set_status_detail(True)
+    try:
+        _, _, st2 = ops.encode_topk(x2, W, b, bd, prepared, k)
+    finally:
+        ops.set_status_detail(False)
+    assert int((((st2 >> 8) & 128) != 0).sum()) == 0
+
+
 def test_soak_small(dev):
     """64k tokens of the trained-like family at N = 32768 (the 1M-token run is tools/soak_fused.py,
     committed under profiles/): zero verified-but-wrong tokens."""

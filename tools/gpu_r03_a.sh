@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 (nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -8) > $OUT/${R}_host.txt 2>&1
 echo "== pytest -m gpu =="
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x --durations=15 > $OUT/${R}_pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=15 > $OUT/${R}_pytest_gpu.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/${R}_pytest_gpu.log
 grep -E "passed|failed|error" $OUT/${R}_pytest_gpu.log | tail -5
 tail -40 $OUT/${R}_pytest_gpu.log | cut -c1-300

@@ -10,7 +10,7 @@ for p in (REPO, REPO + '/multimodal-sae_amd', REPO + '/tests'):
 import bench, hostile
 from msae import ops
 dev = torch.device('cuda:0')
-T, d, N, k = 8192, 4096, 131072, 32
+T, d, N, k = 8192, 4096, 131072, int(os.environ.get('K', '32'))
 kinds = sys.argv[1:] or ["bench"]
 for kind in kinds:
     if kind == "bench":
@@ -26,7 +26,7 @@ for kind in kinds:
         s = s.cpu()
         ok = s >= (1 << 24)
         rounds, first, rows = s[ok] >> 24, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
-        print(f"{kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
+        print(f"k={k} {kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
               f"mean rows {rows.float().mean():.1f} (first round {first.float().mean():.1f})  "
               f"rows p50/p99/max {int(rows.float().quantile(0.5))}/{int(rows.float().quantile(0.99))}/{int(rows.max())}  "
               f"not verified: {torch.unique(s[~ok], return_counts=True)}", flush=True)
