@@ -45,7 +45,9 @@
 
 #include "common.h"
 #include "gemm_mfma.h"
+#ifdef MSAE_GEMM_RING64   // tuning builds: the 64-byte / 4-slot ring variant of the candidate GEMM (measured slower, kept as a record)
 #include "gemm_mfma64.h"
+#endif
 
 int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                          const float *b_dec, const int *rows, const int *n_rows, int T, int d, int N,
@@ -217,19 +219,25 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
 // ---- per-row statistics + int8 operands ---------------------------------------------------------------
 // Tile-major int8 operand of the candidate GEMM (GemmOperands::packed): byte offset of the 16-B chunk at column c
 // (c % 16 == 0) of row r, with the LDS image's chunk permutation applied (gemm_swz).  d % 128 == 0.
-// layout 1: 128-byte k-tiles (gemm_mfma.h), layout 2: 64-byte k-tiles (gemm_mfma64.h: packed64_off)
+// layout 1: 128-byte k-tiles (gemm_mfma.h), layout 2: 64-byte k-tiles (gemm_mfma64.h: packed64_off; tuning builds)
 __host__ __device__ __forceinline__ size_t packed_off(size_t r, int c, int d, int layout = 1) {
+#ifdef MSAE_GEMM_RING64
   if (layout == 2) return packed64_off(r, c, d);
+#endif
   const size_t rt = r >> 8, ri = r & 255;
   const int kt = c >> 7, ch = (c >> 4) & 7;
   return ((rt * (size_t)(d >> 7) + kt) * 256 + ri) * 128 + (size_t)((ch ^ (int)((ri >> 1) & 7)) << 4);
 }
-// which operand layout / candidate GEMM this process uses: 1 = tile-major, 128-byte k-tiles in a 2-slot ring (default);
-// 2 = tile-major, 64-byte k-tiles in a 4-slot ring (MSAE_GEMM_RING64=1); 0 = row-major (MSAE_GEMM_ROWMAJOR=1).  Read at
-// every call (an immutable property of the process environment: prepare and encode must agree).
+// which operand layout the candidate GEMM reads: 1 = tile-major, 128-byte k-tiles in a 2-slot ring (default); 0 =
+// row-major (environment MSAE_GEMM_ROWMAJOR=1, for A/B runs); 2 = tile-major 64-byte k-tiles in a 4-slot ring (tuning
+// builds with -DMSAE_GEMM_RING64 and MSAE_GEMM_RING64=1 in the environment).  Read at every call: an immutable property
+// of the process environment (prepare and encode must agree).
 inline int gemm_layout() {
   if (getenv("MSAE_GEMM_ROWMAJOR")) return 0;
-  return getenv("MSAE_GEMM_RING64") ? 2 : 1;
+#ifdef MSAE_GEMM_RING64
+  if (getenv("MSAE_GEMM_RING64")) return 2;
+#endif
+  return 1;
 }
 
 // W side (once per weight load), one 256-thread workgroup per row:
@@ -574,7 +582,9 @@ __global__ __launch_bounds__(1024) void band_refs_kernel(const f32x4 *__restrict
 // N=131072): 256x256 tiles of 128-B k-rows, 2-slot ring, 8 waves as 2x4.
 using GemmBf16 = GemmCfg<256, 256, 2, 2, 4, false>;
 using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
+#ifdef MSAE_GEMM_RING64
 using GemmI8R64 = GemmCfg64<256, 256, 2, 4, true>;
+#endif
 constexpr int G_BM = GemmBf16::BM;
 
 // ---- candidate select + exact re-score ----------------------------------------------------------
@@ -1921,9 +1931,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #ifdef MSAE_GEMM_TIMELINE
     ep.timeline = nullptr;
 #endif
+#ifdef MSAE_GEMM_RING64
     const int grc = pl.i8 ? (op_samp.packed == 2 ? gemm64_launch<GemmI8R64, true>(op_samp, T, pl.Tp, pl.S, ep, s)
                                                  : gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s))
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
+#else
+    const int grc = pl.i8 ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
+                          : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
+#endif
     if (grc) return grc;
   }
   prof_mark(co.prof, 2, s);
@@ -1946,9 +1961,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
     ep.timeline = g_timeline;
 #endif
+#ifdef MSAE_GEMM_RING64
     const int grc = pl.i8 ? (op_main.packed == 2 ? gemm64_launch<GemmI8R64, false>(op_main, T, pl.Tp, N, ep, s)
                                                  : gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s))
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
+#else
+    const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s)
+                          : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
+#endif
     if (grc) return grc;
   }
   prof_mark(co.prof, 4, s);

@@ -13,23 +13,45 @@ from ...features import FeatureCache
 from ...utils import ddp_setup, load_filter, load_saes, maybe_load_llava_model, shard_offsets
 
 
-def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "text"):
-    """GPT-style chunking as the reference's sae/data.py:16-100 does it: documents joined with EOS
-    (the stream starts with one), cut into chunks of exactly `max_seq_len` ids, the ragged final chunk
-    dropped.  Returns a `datasets.Dataset` in torch format with the single column `input_ids`, so the
-    caller can `.shard(world, rank, contiguous=True)` it exactly like the reference (cache.py:66)."""
+def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "text", batch_docs: int = 2048,
+                       return_final_batch: bool = False):
+    """GPT-style chunking with the reference's semantics (sae_auto_interp/sae/data.py:16-100), chunk for chunk:
+
+      * documents are taken in batches of 2048 (`Dataset.map(batched=True, batch_size=2048)` there); the texts of a
+        batch are JOINED AS STRINGS with the EOS token (an empty first element, so the batch starts with one) and
+        tokenised in ONE call with `truncation` + `return_overflowing_tokens` at `min(model_max_length, max_seq_len)`;
+      * a slow tokenizer returns one flat id list plus a flat overflow, which is cut into chunks; a fast tokenizer
+        returns one row per chunk (special tokens re-added on every row) -- both taken as they come;
+      * the last chunk of EVERY batch (ragged almost surely) is dropped unless `return_final_batch`.
+
+    So chunk boundaries and therefore the cache's `row` ids equal the reference's on the same dataset (golden
+    fixture g11: 2500 documents, both tokenizer kinds).  Returns a `datasets.Dataset` in torch format with the single
+    column `input_ids`, which the caller shards with `.shard(world, rank, contiguous=True)` like the reference
+    (launch/cache/cache.py:66).  Only the chunk ids are kept in memory (one batch of texts at a time)."""
     from datasets import Dataset
 
-    eos = tokenizer.eos_token_id
-    buf, chunks = [eos], []
-    for row in dataset:
-        buf.extend(tokenizer(row[text_key], add_special_tokens=False)["input_ids"] + [eos])
-        while len(buf) >= max_seq_len:
-            chunks.append(buf[:max_seq_len])
-            buf = buf[max_seq_len:]
-    if not chunks:
-        raise ValueError("Not enough data to create a single complete batch.")   # data.py:80-85
-    return Dataset.from_dict({"input_ids": chunks}).with_format("torch", columns=["input_ids"])
+    chunk = min(tokenizer.model_max_length, max_seq_len)
+    sep = tokenizer.eos_token or "<|endoftext|>"
+    rows = []
+    for start in range(0, len(dataset), batch_docs):
+        texts = dataset[start:start + batch_docs][text_key]
+        enc = tokenizer(sep.join([""] + list(texts)), max_length=chunk, return_attention_mask=False,
+                        return_overflowing_tokens=True, truncation=True)
+        ids = enc["input_ids"]
+        overflow = enc.get("overflowing_tokens") if hasattr(enc, "get") else None
+        if overflow:                                   # slow tokenizer: flat lists
+            pieces = [list(ids)] + [list(overflow[i:i + chunk]) for i in range(0, len(overflow), chunk)]
+        elif len(ids) and isinstance(ids[0], (list, tuple)):
+            pieces = [list(r) for r in ids]            # fast tokenizer: one row per chunk
+        else:
+            pieces = [list(ids)]
+        if not return_final_batch:
+            pieces = pieces[:-1]
+        if not pieces:
+            raise ValueError("Not enough data to create a single complete batch. Either allow the final batch to be "
+                             "returned, or supply more data.")     # data.py:80-85
+        rows.extend(pieces)
+    return Dataset.from_dict({"input_ids": rows}).with_format("torch", columns=["input_ids"])
 
 
 def main(cfg: CacheConfig):

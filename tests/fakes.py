@@ -166,6 +166,60 @@ class FakeTokenizer:
         return {"input_ids": rows[0] if single else rows}
 
 
+class FakeSlowTokenizer(FakeTokenizer):
+    """FakeTokenizer that also splits on the EOS *string* and implements `truncation` / `return_overflowing_tokens`
+    the way transformers' slow (Python) tokenizers do: one flat `input_ids` (BOS + max_length - 1 ids) and the removed
+    tail as a flat `overflowing_tokens` list -- the branch of the reference chunker that re-chunks the overflow
+    (sae_auto_interp/sae/data.py:60-70)."""
+
+    def _ids(self, text: str):
+        out = []
+        for j, seg in enumerate(text.split(self.eos_token)):
+            if j:
+                out.append(self.eos_token_id)
+            out += [self.convert_tokens_to_ids(w) for w in seg.split()]
+        return out
+
+    def __call__(self, text, add_special_tokens=True, max_length=None, truncation=False,
+                 return_overflowing_tokens=False, return_attention_mask=False, **_):
+        assert isinstance(text, str)
+        ids = self._ids(text)
+        n_special = 1 if add_special_tokens else 0
+        out, overflow = ids, []
+        if truncation and max_length is not None and len(ids) + n_special > max_length:
+            out, overflow = ids[: max_length - n_special], ids[max_length - n_special:]
+        import transformers
+
+        enc = transformers.BatchEncoding({"input_ids": ([BOS] if add_special_tokens else []) + out})
+        if return_overflowing_tokens:
+            enc["overflowing_tokens"] = overflow
+        return enc
+
+
+def make_fast_tokenizer(n_words: int = 60):
+    """A real `PreTrainedTokenizerFast` (Rust `tokenizers` WordLevel model, BOS template) built in memory: the fast
+    branch of the reference chunker (`return_overflowing_tokens` gives one row per chunk, BOS re-added on each)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+
+    vocab = {"<s>": 0, "</s>": 1, "<unk>": 2}
+    for i in range(n_words):
+        vocab[f"w{i}"] = 3 + i
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split("</s>", "isolated"), pre_tokenizers.Whitespace()])
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 0)])
+    return PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>",
+                                   model_max_length=1 << 20)
+
+
+def chunker_documents(n_docs: int = 2500, seed: int = 5):
+    """Documents of 1-40 words w0..w59 (more than one 2048-document batch of the reference chunker)."""
+    import random
+
+    rng = random.Random(seed)
+    return [" ".join(f"w{rng.randrange(60)}" for _ in range(rng.randint(1, 40))) for _ in range(n_docs)]
+
+
 class FakeImageDataset:
     """What `load_dataset` hands the image cache: rows {"image": ...}, `.shard(n, i, contiguous=True)`."""
 

@@ -384,6 +384,25 @@ def image_cache_fixture(Sae, SaeConfig, cache_mod):
           "max pos", int(out["locations"][:, 1].max()))
 
 
+def chunker_fixture(Sae=None, SaeConfig=None):
+    """The reference's GPT-style chunker (sae_auto_interp/sae/data.py:16-100) on 2500 documents -- two of its
+    2048-document batches, each of which drops its ragged last chunk -- with a slow-style tokenizer (flat overflow,
+    re-chunked) and a real fast tokenizer (one row per chunk, BOS on each)."""
+    import datasets
+
+    import fakes
+    from sae_auto_interp.sae.data import chunk_and_tokenize
+
+    docs = fakes.chunker_documents()
+    out = {}
+    for name, tok in (("slow", fakes.FakeSlowTokenizer(64)), ("fast", fakes.make_fast_tokenizer())):
+        ds = datasets.Dataset.from_dict({"text": docs})
+        got = chunk_and_tokenize(ds, tok, max_seq_len=48, num_proc=1, load_from_cache_file=False)
+        out[name] = np.asarray(got["input_ids"], dtype=np.int64)
+        print("chunker", name, out[name].shape)
+    np.savez_compressed(HERE / "g11_chunker.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -406,6 +425,7 @@ def main():
     attribution_fixture(Sae, SaeConfig)
     steering_fixture(Sae, SaeConfig)
     image_cache_fixture(Sae, SaeConfig, cache_mod)
+    chunker_fixture()
     if args.full:
         encode_decode_fixture(Sae, SaeConfig, "g2_c2_d4096_n131072", 4096, 131072, [32, 256], 16, 3, 4)
 

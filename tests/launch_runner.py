@@ -43,7 +43,7 @@ def main():
     def fake_model_loader(model_name, rank, dtype, hf_token=None):
         return fakes.TinyLlava(vocab=vocab).to(f"cuda:{rank}"), fakes.FakeProcessor(vocab)
 
-    transformers.AutoTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: fakes.FakeTokenizer(vocab))
+    transformers.AutoTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: fakes.FakeSlowTokenizer(vocab))
 
     def fake_load_dataset(name, split="train", **kw):
         if name == "images":

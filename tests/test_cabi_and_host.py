@@ -290,3 +290,24 @@ def test_shard_helpers_and_argument_checks_without_a_gpu():
     assert einval < 0
     assert lib.msae_shard_candidates(null, 2, null, null, null, 4, 4096, 16384, 32, 0, 0, -1, -1, null, null, 0, None, null) < 0
     assert lib.msae_error_string(einval).decode()
+
+
+def test_chunk_and_tokenize_matches_reference_chunker(golden_dir):
+    """launch.cache's GPT-style chunker == the reference's (sae_auto_interp/sae/data.py:16-100, run by
+    tests/golden/make_golden.py:chunker_fixture) on 2500 documents -- more than one of its 2048-document batches, each of
+    which drops its ragged last chunk -- with a slow-style tokenizer (flat overflow, re-chunked) and a real fast
+    tokenizer (one row per chunk, BOS re-added).  Same chunk boundaries => same cache `row` ids."""
+    import datasets
+
+    import fakes
+    from msae.launch.cache.cache import chunk_and_tokenize
+
+    g = np.load(golden_dir / "g11_chunker.npz")
+    docs = fakes.chunker_documents()
+    for name, tok in (("slow", fakes.FakeSlowTokenizer(64)), ("fast", fakes.make_fast_tokenizer())):
+        got = chunk_and_tokenize(datasets.Dataset.from_dict({"text": docs}), tok, max_seq_len=48)
+        ids = np.asarray(got["input_ids"], dtype=np.int64)
+        assert ids.shape == g[name].shape, (name, ids.shape, g[name].shape)
+        assert np.array_equal(ids, g[name]), name
+    with pytest.raises(ValueError, match="Not enough data"):
+        chunk_and_tokenize(datasets.Dataset.from_dict({"text": ["w1 w2"]}), fakes.FakeSlowTokenizer(64), max_seq_len=48)
