@@ -1093,6 +1093,10 @@ __global__ __launch_bounds__(64) void pack_candidates_kernel(PackArgs p) {
 // waves per token and lanes per row of the first round: k > 64 -> 4 waves (longer lists); batches that cannot fill
 // 256 CUs x 8 waves with a lane per row get 2 or 4 lanes per row (and waves per token) instead
 inline void rescore_shape(int T, int k, int &nw, int &lpr) {
+  // k > 64: 4 waves per token, a lane per row.  k = 256 reads ~350 rows per token (profiles/r03_rescore_stats_k256.txt),
+  // i.e. a second, mostly idle pass -- but 6 waves per token (one pass) measured SLOWER, 9.65 vs 8.0 ms: the kernel's
+  // ~230 VGPRs allow 8 waves per CU, and workgroups of 6 waves leave two of those slots empty
+  // (profiles/r03_k256_nw6.txt); the stage is HBM-bound at 5.8 TB/s either way.
   nw = k <= 64 ? 1 : 4;
   lpr = 1;
   if (k <= 64) {

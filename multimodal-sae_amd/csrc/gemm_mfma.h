@@ -346,21 +346,21 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
   gemm_read_frags<C>(a0, b0, rowA + off[2], rowB + off[2]);
-  if constexpr (AT == 0) mid();
+  if constexpr (AT == 0) mid(0);
   lgkm_wait_tied<6, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
   gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
-  if constexpr (AT == 1) mid();
+  if constexpr (AT == 1 || AT == 0) mid(1);       // (AT == 0 with MSAE_GEMM_STAGGER_SPLIT: second half of the pieces)
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
-  if constexpr (AT == 2) mid();
+  if constexpr (AT == 2) mid(2);
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
 }
 template <class C>
 __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                                  int wr, int wc, int l31, int kh) {
-  gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [] {});
+  gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [](int) {});
 }
 
 // Compact outlier tile (at most 32 outlier dims: one k-step).  The k-loop is bound by the L2 -> LDS delivery, and a
@@ -728,6 +728,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // hidden behind the epilogue.
   int seq = 0;                                   // flat k-tile counter; ring slot = seq & 1
   [[maybe_unused]] int tl_tile = -1;
+#ifdef MSAE_GEMM_PRIO     // tuning: static priority for the second-dispatched half (guide: "two waves per SIMD", item 4)
+  if ((threadIdx.x >> 6) >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(MSAE_GEMM_PRIO);
+#endif
   for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
   ++tl_tile;
   MSAE_TL(0);
@@ -903,6 +906,30 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (kt + 1 < ntiles) { if (!(PRESTAGE && lead && kt == 0)) stage(m0, n0, kt + 1, (seq + 1) & 1); }
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     };
+#ifdef MSAE_GEMM_STAGGER_SPLIT
+    auto stage_half = [&](int half) {           // tile-major main k-tiles only; everything else goes whole, at the second call
+      const bool nxt_tile = !(kt + 1 < ntiles);
+      const int t2 = nxt_tile ? 0 : kt + 1;
+      const int tm0 = nxt_tile ? m0n : m0, tn0 = nxt_tile ? n0n : n0;
+      if (nxt_tile && !has_next) return;
+      if (t2 < lead || !op.packed) { if (half == 1) stage_next(); return; }
+      int kq = t2 - lead + krot;
+      kq -= kq >= op.nk ? op.nk : 0;
+      const unsigned char *tileA = op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES;
+      const unsigned char *tileB = op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES;
+      unsigned char *base = smem + ((seq + 1) & 1) * C::STAGE_BYTES;
+      const unsigned voff = (unsigned)lane << 4;
+#pragma unroll
+      for (int i = 0; i < C::PPW / 2; ++i) {
+        const int piece = wave * C::PPW + half * (C::PPW / 2) + i;
+        const bool isA = piece < C::A_PIECES;
+        const unsigned char *sbase = isA ? tileA + piece * 1024 : tileB + (piece - C::A_PIECES) * 1024;
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(base + piece * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+      }
+    };
+#endif
 #ifndef MSAE_GEMM_STAGGER
 #define MSAE_GEMM_STAGGER 1   // round 3: on by default (-4 % on the main pass together with tile-major operands, two boxes:
 #endif                        // profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt); 0 = off, 2 = odd waves
@@ -932,7 +959,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       else gemm_compute_lead<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, lead_ks);
     }
     else if constexpr (!C::ABL_NOREAD && !C::ABL_NOMFMA && !C::ABL_NOSTAGE)
-      gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [&] { if (late) stage_next(); });
+      gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [&](int pos) {
+#ifdef MSAE_GEMM_STAGGER_SPLIT    // tuning: late waves issue half their pieces behind k-step 0, half behind k-step 1
+        if (late) stage_half(pos == 0 ? 0 : 1);
+#else
+        if (late && pos == MSAE_GEMM_STAGGER_AT) stage_next();
+#endif
+      });
     else gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
     MSAE_TLK(kt == 8, 4);
     ++seq;

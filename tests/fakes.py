@@ -182,7 +182,8 @@ class FakeSlowTokenizer(FakeTokenizer):
 
     def __call__(self, text, add_special_tokens=True, max_length=None, truncation=False,
                  return_overflowing_tokens=False, return_attention_mask=False, **_):
-        assert isinstance(text, str)
+        if not isinstance(text, str) or not truncation:      # batched / plain calls: the whitespace tokenizer above
+            return super().__call__(text, add_special_tokens=add_special_tokens, **_)
         ids = self._ids(text)
         n_special = 1 if add_special_tokens else 0
         out, overflow = ids, []

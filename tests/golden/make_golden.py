@@ -278,7 +278,7 @@ def train_fixture(Sae, SaeConfig):
     print("wrote g7_train", out["fvu"], out["auxk_loss"], out["multi_topk_fvu"])
 
 
-def attribution_fixture(Sae, SaeConfig):
+def attribution_fixture(Sae, SaeConfig, name="g8_attribution", d=64, N=1024, k=8, wseed=9):
     """`Attribution.get_attribution` of the reference itself (features/patching/attribution.py:116-189,
     hooks of patching/utils.py:21-79) on the tiny LLaVA stand-in of tests/fakes.py with an SAE spliced
     into `layers.0`.  The constructor (files, PIL images, tokenizer) is bypassed; every line of the
@@ -291,9 +291,9 @@ def attribution_fixture(Sae, SaeConfig):
     from sae_auto_interp.features.patching.attribution import Attribution
     from sae_auto_interp.features.patching.utils import get_logit_diff
 
-    d, N, k, vocab = 64, 1024, 8, 40
+    vocab = 40
     model = fakes.TinyLlava(vocab=vocab, d=d, n_layers=2, seed=300)
-    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=9)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, k, seed=wseed)
     module = "layers.0"
     inputs = fakes.FakeProcessor(vocab)(text=["<image>"] * 2, images=[fakes.FakeImage(0), fakes.FakeImage(1)])
     answer_ids = torch.tensor([[5, 11], [17, 2]])
@@ -321,14 +321,20 @@ def attribution_fixture(Sae, SaeConfig):
     if not dist.is_initialized():
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
     res = attr.get_attribution(torch.tensor(indices))
-    out = {"d": d, "N": N, "k": k, "vocab": vocab, "wseed": 9, "module": module,
+    out = {"d": d, "N": N, "k": k, "vocab": vocab, "wseed": wseed, "module": module,
            "input_ids": attr.prompt_ids.numpy(), "pixel_values": attr.pixel_values.numpy(),
            "answer_ids": answer_ids.numpy(), "indices": np.array(indices),
            "attribution": torch.stack(res[module]).numpy(),            # [n_idx, B, S] fp16
            "clean_top_idx": act_idx.numpy().astype(np.int32), "clean_top_acts": top.top_acts.numpy()}
-    np.savez_compressed(HERE / "g8_attribution.npz", **out)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
     a = out["attribution"].astype(np.float32)
-    print("wrote g8_attribution", a.shape, "max |attr|", np.abs(a).max(), "nonzero entries", int((a != 0).sum()))
+    print("wrote", name, a.shape, "max |attr|", np.abs(a).max(), "nonzero entries", int((a != 0).sum()))
+
+
+def attribution_wide_fixture(Sae, SaeConfig):
+    """The same reference run on a less pathological stand-in: k = 32 latents of a d = 256 stream (one ablation moves
+    the reconstruction by a few per cent, not 12 %), where the batched one-pass scores must be close to first order."""
+    attribution_fixture(Sae, SaeConfig, name="g12_attribution_wide", d=256, N=4096, k=32, wseed=19)
 
 
 def steering_fixture(Sae, SaeConfig):
@@ -423,6 +429,7 @@ def main():
     hook_fixture(Sae, SaeConfig)
     train_fixture(Sae, SaeConfig)
     attribution_fixture(Sae, SaeConfig)
+    attribution_wide_fixture(Sae, SaeConfig)
     steering_fixture(Sae, SaeConfig)
     image_cache_fixture(Sae, SaeConfig, cache_mod)
     chunker_fixture()
