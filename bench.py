@@ -208,9 +208,6 @@ def main():
             elif x.shape[1] != d:
                 _, _, _, _, x = make_inputs(dev, T, d, 8192, seed=rank)
             data = "user-supplied files: " + ", ".join(f"{n}={v}" for n, v in (("sae", args.sae_path), ("acts", args.acts)) if v)
-        if os.environ.get("MSAE_BENCH_SORT_ROWS"):     # experiment: features ordered by int8 scale (homogeneous GEMM tiles)
-            order = W_enc.abs().amax(dim=1).argsort()
-            W_enc, b_enc, W_dec = W_enc[order].contiguous(), b_enc[order].contiguous(), W_dec[order].contiguous()
         engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
 
     def timed(eng, xin, steps, warmup, profile):

@@ -133,7 +133,7 @@ struct GemmCfg {
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 2304;
   static constexpr int PF_SINK_BYTES = 256;      // where the L2-warming loads of the k-loop land (never read)
-  static constexpr int GRP_BYTES = 1280;         // integer-prefilter constants (MSAE_EPI_INT: 16 row groups; = 2: per-row thresholds)
+  static constexpr int GRP_BYTES = 256;          // (spare)
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8 + PF_SINK_BYTES + GRP_BYTES;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
@@ -477,28 +477,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
   after_barrier();
   if constexpr (!DENSE) {
     if (threadIdx.x == 0) *q_count = 0u;
-#if defined(MSAE_EPI_INT) && MSAE_EPI_INT == 2
-    if constexpr (C::I8) {
-      // tile-level column bounds were left by the column threads' waves (4 partial triples); every row thread folds them
-      const float *part = reinterpret_cast<const float *>(smem + C::LDS_BYTES - C::GRP_BYTES + 192);
-      const int tid = (int)threadIdx.x;
-      if (tid < C::BM) {
-        float gmin = fminf(fminf(part[0], part[3]), fminf(part[6], part[9]));
-        float dmax = fmaxf(fmaxf(part[1], part[4]), fmaxf(part[7], part[10]));
-        float emax = fmaxf(fmaxf(part[2], part[5]), fmaxf(part[8], part[11]));
-        const float tau = side[tid], sx = side[C::NT + tid], bt = side[5 * C::NT + tid];
-        int I = 0x7FFFFFFF;
-        if (tau < __builtin_inff() && sx > 0.f) {
-          const float inv = 1.f / sx;
-          const float t0 = tau * inv * gmin, t1 = inv * dmax, t2 = bt * inv * emax;
-          const float safe = t0 - t1 - t2 - (3e-5f * (__builtin_fabsf(t0) + __builtin_fabsf(t1) + __builtin_fabsf(t2)) + 2.f);
-          I = (safe == safe) ? (safe >= 2147483520.f ? 0x7FFFFFFF : (safe <= -2147483520.f ? (int)0x80000000 : (int)__builtin_floorf(safe)))
-                             : (int)0x80000000;
-        }
-        reinterpret_cast<int *>(smem + C::LDS_BYTES - C::GRP_BYTES + 256)[tid] = I;
-      }
-    }
-#endif
     __syncthreads();
   }
   MSAE_TL(7);
@@ -530,14 +508,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
       rs[e] = C::I8 ? row_c[C::NT + row] : 0.f;
       bt[e] = DENSE ? 0.f : row_c[5 * C::NT + row];
     }
-#if defined(MSAE_EPI_INT) && MSAE_EPI_INT == 2 && MSAE_EPI_INT_C
-    int thr_i[16];
-    if constexpr (C::I8 && !DENSE) {
-      const int *irow_ = reinterpret_cast<const int *>(smem + C::LDS_BYTES - C::GRP_BYTES + 256);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) thr_i[e] = irow_[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-    }
-#endif
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
       const int col = wc * C::TN + j * 32 + l31;
@@ -557,140 +527,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
         // round trip whenever ANY lane of the wave has one (27 % of the elements): 0.55 ms of the pass.  So
         // the 16 outputs of this lane's column are tested branch-free -- count, last survivor's value and
         // position -- and the lane reserves its queue slots with ONE LDS atomic per 16 outputs.
-#ifndef MSAE_EPI_INT_C
-#define MSAE_EPI_INT_C 0
-#endif
-#if defined(MSAE_EPI_INT) && MSAE_EPI_INT == 2
-        if constexpr (C::I8) {
-          // Integer prefilter with PER-ROW thresholds (experiment): I_t = alpha_t gamma_min - beta_t delta_max - eps_t
-          // eta_max over the tile's 256 columns -- tight when the tile's columns are homogeneous (unit-norm random rows;
-          // a trained SAE would need its features sorted by scale in the prepared operand).
-          const int *irow = reinterpret_cast<const int *>(smem + C::LDS_BYTES - C::GRP_BYTES + 256);
-          int hv = 0;
-          unsigned mask = 0u;
-#if MSAE_EPI_INT_C   // compiler-scheduled form: four independent (value, mask) chains, merged at the end
-          int hvq[4] = {0, 0, 0, 0};
-          unsigned mq[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int a = __builtin_bit_cast(i32x16, acc[i][j])[e];
-            const bool hit = a > thr_i[e];
-            hvq[e & 3] = hit ? a : hvq[e & 3];
-            mq[e & 3] |= hit ? (1u << (15 - e)) : 0u;
-          }
-          mask = (mq[0] | mq[1]) | (mq[2] | mq[3]);
-          {   // the LAST hit's value: the chain that holds the lowest set bit
-            const int last = mask ? 15 - __builtin_ctz(mask) : 0;
-            hv = hvq[last & 3];
-          }
-#else
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int a = __builtin_bit_cast(i32x16, acc[i][j])[e];
-            const int I_e = irow[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
-            asm volatile("v_cmp_gt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                         : "+v"(hv), "+v"(mask) : "v"(a), "v"(I_e) : "vcc");
-          }
-#endif
-          if (!c_live[j]) mask = 0u;
-          if (mask) {
-            const unsigned cnt = (unsigned)__builtin_popcount(mask);
-            unsigned slot = atomicAdd(q_count, cnt);
-            auto push = [&](int a, int e) {
-              const int row = row_of(e);
-              if (slot < QCAP) {
-                queue[slot] = ((unsigned long long)(unsigned)a << 32) | (unsigned)(row << 16 | col);
-              } else {
-                const float v = (float)a * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
-                const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-                if (u > row_c[row]) {
-                  const int t = m0 + row;
-                  const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
-                  const int gslot = atomicAdd(ep.cnt + t, 1);
-                  if (gslot < ep.cap)
-                    ep.cand[(size_t)t * ep.cap + gslot] =
-                        ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
-                }
-              }
-              ++slot;
-            };
-            if (cnt == 1) {
-              push(hv, 15 - __builtin_ctz(mask));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 16; ++e)
-                if ((mask >> (15 - e)) & 1u) push(__builtin_bit_cast(i32x16, acc[i][j])[e], e);
-            }
-          }
-          continue;
-        }
-#elif defined(MSAE_EPI_INT)
-        if constexpr (C::I8) {
-          // Integer prefilter.  The exact test  float(acc) sx_t sw_n + b_n + h_n B_t > tau_t  is, for sx_t, sw_n > 0,
-          //   acc > alpha_t gamma_n - beta_t delta_n - eps_t eta_n     (alpha = tau/sx, beta = 1/sx, eps = B/sx;
-          //                                                              gamma = 1/sw, delta = b/sw, eta = h/sw)
-          // and over the 16 rows this lane holds of block i (one row group) the right side is at least
-          //   I = alpha_min gamma_n - max_t(beta_t delta_n) - eps_max eta_n,
-          // ONE integer per (lane, i, j): the hot loop is one v_cmp_gt_i32 per output plus two bookkeeping
-          // operations (last passing accumulator, 16-bit pass mask) instead of cvt + 2 mul + add + fma + cmp + 3.
-          // The float test itself moves to the queue flush, which sees only what passed (~1 % of the outputs).
-          const f32x4 gc = reinterpret_cast<const f32x4 *>(smem + C::LDS_BYTES - C::GRP_BYTES)[(wr * C::MI + i) * 2 + kh];
-          int I_int = 0x7FFFFFFF;                                   // nothing passes
-          if (c_live[j] && gc[0] < __builtin_inff()) {
-            const float sw = c_sw[j];
-            if (sw > 0.f) {
-              const float gam = 1.f / sw, del = c_bias[j] * gam, eta = c_h[j] * gam;
-              const float t0 = gc[0] * gam, t1 = (del > 0.f ? gc[1] : gc[2]) * del, t2 = gc[3] * eta;
-              const float ir = t0 - t1 - t2;
-              const float safe = ir - (3e-5f * (__builtin_fabsf(t0) + __builtin_fabsf(t1) + __builtin_fabsf(t2)) + 2.f);
-              I_int = (safe == safe) ? (safe >= 2147483520.f ? 0x7FFFFFFF : (safe <= -2147483520.f ? (int)0x80000000 : (int)__builtin_floorf(safe)))
-                                     : (int)0x80000000;            // NaN: let everything through to the exact test
-            } else {
-              // all-zero weight row: the value is the bias whatever the token; passes iff b_n beta_t > alpha_t somewhere
-              I_int = (c_bias[j] > 0.f && c_bias[j] * gc[1] * 1.0001f > gc[0]) ? (int)0x80000000 : 0x7FFFFFFF;
-            }
-          }
-          int hv = 0;
-          unsigned mask = 0u;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int a = __builtin_bit_cast(i32x16, acc[i][j])[e];
-            // mask = 2 mask + (a > I);  hv = (a > I) ? a : hv
-            asm volatile("v_cmp_gt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                         : "+v"(hv), "+v"(mask) : "v"(a), "v"(I_int) : "vcc");
-          }
-          if (mask) {
-            const unsigned cnt = (unsigned)__builtin_popcount(mask);
-            unsigned slot = atomicAdd(q_count, cnt);                          // LDS atomic
-            auto push = [&](int a, int e) {
-              const int row = row_of(e);
-              if (slot < QCAP) {
-                queue[slot] = ((unsigned long long)(unsigned)a << 32) | (unsigned)(row << 16 | col);
-              } else {                                                          // queue full: slow path, exact test here
-                const float v = (float)a * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
-                const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-                if (u > row_c[row]) {
-                  const int t = m0 + row;
-                  const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
-                  const int gslot = atomicAdd(ep.cnt + t, 1);
-                  if (gslot < ep.cap)
-                    ep.cand[(size_t)t * ep.cap + gslot] =
-                        ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
-                }
-              }
-              ++slot;
-            };
-            if (cnt == 1) {
-              push(hv, 15 - __builtin_ctz(mask));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 16; ++e)
-                if ((mask >> (15 - e)) & 1u) push(__builtin_bit_cast(i32x16, acc[i][j])[e], e);
-            }
-          }
-          continue;
-        }
-#endif
 #ifdef MSAE_EPI_BALLOT
         // wave-level bookkeeping: the 16 tests leave 16 lane masks in SGPRs; their population counts, the ONE LDS
         // atomic of the wave and the slot of every survivor (mbcnt) come from those masks on the scalar unit, so the
@@ -794,13 +630,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
-#if defined(MSAE_EPI_INT)
-      // the queue holds raw accumulators: the value is formed here with the hot loop's expression (same bits)
-      const float v = C::I8 ? (float)(int)(unsigned)(e >> 32) * (row_c[C::NT + row] * col_c[C::NT + col]) + col_c[col]
-                            : __uint_as_float((unsigned)(e >> 32));
-#else
       const float v = __uint_as_float((unsigned)(e >> 32));
-#endif
       const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));   // the exact upper value
       if (!(u > row_c[row])) continue;
       const int t = m0 + row;
@@ -1121,42 +951,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       side5 = (q > 0.f || side3 > 0.f || side4 > 0.f) ? __builtin_sqrtf(h2) * 1.00001f : 0.f;
     }
     side[5 * C::NT + tid_] = side5;
-#if defined(MSAE_EPI_INT) && MSAE_EPI_INT == 2
-    if constexpr (C::I8) {
-      // column threads (waves 4-7): gamma = 1 / sw, delta = b / sw, eta = h / sw -> per-wave min / max / max
-      float gam = __builtin_inff(), del = -__builtin_inff(), eta = 0.f;
-      if (tid_ >= C::BM && tid_ < C::BM + C::BN && side1 > 0.f) {
-        gam = 1.f / side1; del = side0 * gam; eta = side5 * gam;
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        gam = fminf(gam, __shfl_xor(gam, off, 64)); del = fmaxf(del, __shfl_xor(del, off, 64));
-        eta = fmaxf(eta, __shfl_xor(eta, off, 64));
-      }
-      if (tid_ >= C::BM && lane == 0) {
-        float *part = reinterpret_cast<float *>(smem + C::LDS_BYTES - C::GRP_BYTES + 192) + ((tid_ - C::BM) >> 6) * 3;
-        part[0] = gam; part[1] = del; part[2] = eta;
-      }
-    }
-#elif defined(MSAE_EPI_INT)
-    if constexpr (C::I8) {
-      // per 16-row group (32-row block b = row >> 5, half kh = (row >> 2) & 1): min tau/sx, max & min 1/sx, max B/sx over
-      // its live rows (a padded / degenerate row has tau = +inf and never passes)
-      float al = __builtin_inff(), bmx = 0.f, bmn = __builtin_inff(), emx = 0.f;
-      if (tid_ < C::BM && side0 < __builtin_inff() && side1 > 0.f) {
-        const float inv = 1.f / side1;
-        al = side0 * inv; bmx = inv; bmn = inv; emx = side5 * inv;
-      }
-#pragma unroll
-      for (int sh = 0; sh < 4; ++sh) {
-        const int off = sh == 0 ? 1 : (sh == 1 ? 2 : (sh == 2 ? 8 : 16));
-        al = fminf(al, __shfl_xor(al, off, 64)); bmx = fmaxf(bmx, __shfl_xor(bmx, off, 64));
-        bmn = fminf(bmn, __shfl_xor(bmn, off, 64)); emx = fmaxf(emx, __shfl_xor(emx, off, 64));
-      }
-      if (tid_ < C::BM && (lane & 27) == 0)
-        reinterpret_cast<f32x4 *>(smem + C::LDS_BYTES - C::GRP_BYTES)[(tid_ >> 5) * 2 + ((tid_ >> 2) & 1)] = f32x4{al, bmx, bmn, emx};
-    }
-#endif
   }
   // behind the epilogue's first barrier every wave is done with the last k-tile's slot: the next tile's first main
   // k-tile lands there while the epilogue runs (its outlier tile is already in the other slot)
