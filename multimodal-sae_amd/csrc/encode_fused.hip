@@ -1886,7 +1886,9 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
     const signed char *wqs = reinterpret_cast<const signed char *>(prepared + pp.off_wqs);
     // tile-major operands for the candidate GEMM (MSAE_GEMM_ROWMAJOR=1: the row-major copies, for A/B runs)
-    const int tile_major = gemm_layout();
+    // one row of output tiles (T <= 256) streams Wq from HBM once and keeps round 2's row-major operands + unstaggered
+    // issue: tile-major + stagger measured 2-3 % slower there (profiles/r03_ab_small_T.txt)
+    const int tile_major = pl.Tp > G_BM ? gemm_layout() : 0;
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
       hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,

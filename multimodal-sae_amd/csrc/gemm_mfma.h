@@ -866,7 +866,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     // start with MFMAs on the data already in LDS and issue their pieces between k-steps 1 and 2, while their
     // partners -- done issuing -- keep the pipe busy.  ONE copy of the MFMA code: the two roles differ only in
     // which of the two stage_next() call sites is taken.
-    const bool late = (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m;
+    const bool late = (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m && nM > 1;
 #else
     constexpr bool late = false;
 #endif

@@ -113,16 +113,47 @@ class Options:
 _defaults = Options()
 
 
-def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False) -> Options:
+class _OptsRef:
+    """A filled msae_options struct and its byref, built once per distinct content (the S = 1 latency path is
+    host-bound: two ctypes structs per call showed up as +10 us per decode step)."""
+    __slots__ = ("struct", "_ref", "profile")
+
+    def __init__(self, o: Options):
+        self.struct, self.profile = o.struct(), o.profile          # (keeps the profile handle alive)
+        self._ref = ctypes.byref(self.struct)
+
+    def ref(self):
+        return self._ref
+
+
+_OPTS_CACHE: dict = {}
+_WS_BYTES_CACHE: dict = {}
+
+
+def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False) -> _OptsRef:
     """Options of one call: explicit arguments win, the process defaults fill the rest."""
-    o = Options(_defaults.coarse, _defaults.guard_z, _defaults.status_detail, _defaults.profile)
-    if coarse_mode >= 0:
-        o.coarse = "int8" if coarse_mode == 1 else "bf16"
-    if guard_z > 0.0:
-        o.guard_z = guard_z
-    if status_detail:
-        o.status_detail = True
-    return o
+    coarse = _defaults.coarse if coarse_mode < 0 else ("int8" if coarse_mode == 1 else "bf16")
+    z = guard_z if guard_z > 0.0 else _defaults.guard_z
+    detail = bool(status_detail or _defaults.status_detail)
+    prof = _defaults.profile
+    key = (coarse, z, detail, id(prof) if prof is not None else 0)
+    ref = _OPTS_CACHE.get(key)
+    if ref is None or ref.profile is not prof:
+        if len(_OPTS_CACHE) > 64:
+            _OPTS_CACHE.clear()
+        ref = _OPTS_CACHE[key] = _OptsRef(Options(coarse, z, detail, prof))
+    return ref
+
+
+def _encode_ws_bytes(lib, T: int, d: int, N: int, k: int, opts: _OptsRef) -> int:
+    """msae_encode_topk_ws_bytes, memoised (a pure function of the shape and the coarse mode)."""
+    key = (T, d, N, k, opts.struct.coarse_mode, os.environ.get("MSAE_COARSE") if opts.struct.coarse_mode < 0 else None)
+    n = _WS_BYTES_CACHE.get(key)
+    if n is None:
+        if len(_WS_BYTES_CACHE) > 4096:
+            _WS_BYTES_CACHE.clear()
+        n = _WS_BYTES_CACHE[key] = lib.msae_encode_topk_ws_bytes(T, d, N, k, opts.ref())
+    return n
 
 
 @contextlib.contextmanager
@@ -352,8 +383,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     if T == 0:
         return vals, idx, status
     opts = _opts(coarse_mode, guard_z, status_detail)
-    nws = lib.msae_encode_topk_ws_bytes(T, d, N, k, opts.ref())
-    ws = _workspace(dev, nws)
+    ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
                                             _hip.ptr(be), _hip.ptr(bd), _hip.ptr(prepared), T, d, N, k,
@@ -385,7 +415,7 @@ def shard_candidates(x: Tensor, b_enc_shard: Optional[Tensor], b_dec: Optional[T
     if T == 0:
         return recs
     opts = _opts()
-    ws = _workspace(dev, lib.msae_encode_topk_ws_bytes(T, d, N_shard, k, opts.ref()))
+    ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N_shard, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_shard_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(be), _hip.ptr(bd),
                                              _hip.ptr(prepared_shard), T, d, N_shard, k, row_offset, C, set_feature,
