@@ -448,11 +448,15 @@ __device__ __forceinline__ void gemm_compute(f32x16 (&acc)[C::MI][C::NI], const 
 }
 
 // Epilogue.  DENSE stores every value.  THRESH compares with the per-token threshold; survivors are
-// rare (~1 per 500 outputs) but each needs a slot in its token's candidate list, i.e. a RETURNING
-// global atomic (~2 us round trip).  Doing that inline serialises ~30 round trips per wave -- as
-// long as the whole k-loop.  So survivors are first queued in LDS (its own region behind the ring;
-// an LDS atomic returns in ~100 cycles) and then flushed, one queue entry per lane: the
-// global atomics of the whole workgroup are in flight together.
+// rare (~1 per 200 outputs pass the hot loop's separable bound) but each needs a slot in its token's
+// candidate list, i.e. a RETURNING global atomic (~2 us round trip).  Doing that inline serialises ~30
+// round trips per wave -- as long as the whole k-loop.  So survivors are first queued in LDS (its own
+// region behind the ring) and then flushed, one queue entry per lane: the global atomics of the whole
+// workgroup are in flight together.  The hot loop itself touches no LDS queue: hit masks per 32x32
+// block first (4.5 VALU per output), then ONE queue reservation per lane and tile, then the pushes
+// (round 3; 15.4k -> 7.8k cycles per tile on the tile timeline, profiles/r03_epilogue_batch.txt --
+// worth 0-1 % of wall time only, because the kernel runs at the package power limit: the clock drops
+// as the cycle count does, profiles/r03_power.txt).
 // z^2 sigma^2 of pair (row, col) from the side buffer (same expression as band_sq in encode_fused.hip)
 template <class C>
 __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int col, float zz12) {
@@ -498,101 +502,83 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
 #ifdef MSAE_ABL_NOEPI      // tuning builds only (tools/build_dbg.sh): skip the element loop
   if (!DENSE && ep.cap != -12345) { asm volatile("" ::"v"(acc[0][0][0])); } else
 #endif
+  // THRESH.  One pass over the wave's MI x NI blocks without any LDS round trip: the value v replaces the accumulator in its register,
+  // the sign of (v + h_n B_t) - tau goes through a 1-instruction shift register (v_alignbit) into a 16-bit hit mask per block.
+  // Then ONE queue reservation per lane for all its hits of this tile, then the pushes (v picked out of the 16 registers
+  // by a select tree on the hit's position).
+  if constexpr (!DENSE) {
+    unsigned hits[C::MI][C::NI];
 #pragma unroll
-  for (int i = 0; i < C::MI; ++i) {
-    float tau[16], rs[16], bt[16];
+    for (int i = 0; i < C::MI; ++i) {
+      float tau[16], rs[16], bt[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      tau[e] = DENSE ? 0.f : row_c[row];
-      rs[e] = C::I8 ? row_c[C::NT + row] : 0.f;
-      bt[e] = DENSE ? 0.f : row_c[5 * C::NT + row];
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        tau[e] = row_c[row];
+        rs[e] = C::I8 ? row_c[C::NT + row] : 0.f;
+        bt[e] = row_c[5 * C::NT + row];
+      }
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) {
-      const int col = wc * C::TN + j * 32 + l31;
-      auto value = [&](int e) {
-        if constexpr (C::I8) return (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (rs[e] * c_sw[j]) + c_bias[j];
-        else return acc[i][j][e] + c_bias[j];
-      };
-      auto row_of = [&](int e) { return wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh; };   // row inside the tile
-      if constexpr (DENSE) {
+      for (int j = 0; j < C::NI; ++j) {
+        unsigned m = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = row_of(e), t = m0 + row;
-          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = value(e) + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-        }
-      } else {
-        // Survivors are rare (~0.5 % of the outputs) but a per-element branch + LDS atomic costs a ~150-cycle
-        // round trip whenever ANY lane of the wave has one (27 % of the elements): 0.55 ms of the pass.  So
-        // the 16 outputs of this lane's column are tested branch-free -- count, last survivor's value and
-        // position -- and the lane reserves its queue slots with ONE LDS atomic per 16 outputs.
-#ifdef MSAE_EPI_BALLOT
-        // wave-level bookkeeping: the 16 tests leave 16 lane masks in SGPRs; their population counts, the ONE LDS
-        // atomic of the wave and the slot of every survivor (mbcnt) come from those masks on the scalar unit, so the
-        // hot loop carries no per-lane counters at all
-        float v[16];
-        bool hit[16];
-        unsigned long long m[16], any = 0ull;
-        const unsigned long long live_m = __builtin_amdgcn_ballot_w64(c_live[j]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          v[e] = value(e);
-          hit[e] = __builtin_fmaf(c_h[j], bt[e], v[e]) > tau[e];
-          m[e] = __builtin_amdgcn_ballot_w64(hit[e]) & live_m;               // the compare's own lane mask
-          any |= m[e];
-        }
-        if (any) {                                                            // wave-uniform
-          unsigned total = 0;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) total += (unsigned)__builtin_popcountll(m[e]);
-          unsigned base = 0;
-          if (lane == 0) base = atomicAdd(q_count, total);                    // LDS atomic, one per wave and column block
-          base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            if (m[e]) {                                                       // wave-uniform
-              if (hit[e] && c_live[j]) {
-                unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[e], 0u));
-                const int row = row_of(e);
-                if (slot < QCAP) {
-                  queue[slot] = ((unsigned long long)__float_as_uint(v[e]) << 32) | (unsigned)(row << 16 | col);
-                } else {                                                      // queue full: slow path
-                  const float u = v[e] + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
-                  if (u > row_c[row]) {
-                    const int t = m0 + row;
-                    const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
-                    const int gslot = atomicAdd(ep.cnt + t, 1);
-                    if (gslot < ep.cap)
-                      ep.cand[(size_t)t * ep.cap + gslot] =
-                          ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
-                  }
-                }
-              }
-              base += (unsigned)__builtin_popcountll(m[e]);
-            }
+        for (int e = 0; e < 16; e += 2) {                                      // two outputs per packed-f32 instruction
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 tau2 = {tau[e], tau[e + 1]}, rs2 = {rs[e], rs[e + 1]}, bt2 = {bt[e], bt[e + 1]};
+          f32x2 v;
+          if constexpr (C::I8) {
+            const f32x2 a = {(float)__builtin_bit_cast(i32x16, acc[i][j])[e], (float)__builtin_bit_cast(i32x16, acc[i][j])[e + 1]};
+            v = a * (rs2 * c_sw[j]) + c_bias[j];
+          } else {
+            v = f32x2{acc[i][j][e], acc[i][j][e + 1]} + c_bias[j];
           }
+          acc[i][j][e] = v.x;
+          acc[i][j][e + 1] = v.y;
+          const f32x2 ch2 = {c_h[j], c_h[j]};
+          const f32x2 dlt = __builtin_elementwise_fma(ch2, bt2, v) - tau2;      // >= +0 iff the bound reaches tau (NaN: either)
+          m = __builtin_amdgcn_alignbit(m, __float_as_uint(dlt.x), 31);        // m = m << 1 | sign(dlt)
+          m = __builtin_amdgcn_alignbit(m, __float_as_uint(dlt.y), 31);
         }
-#else
-        unsigned cnt = 0;
-        float hv = 0.f;
-        int he = 0;
+        hits[i][j] = c_live[j] ? (~m & 0xFFFFu) : 0u;                          // bit 15 - e: output e is a hit
+      }
+    }
+    unsigned total = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = value(e);
-          const bool hit = __builtin_fmaf(c_h[j], bt[e], v) > tau[e];     // upper bound of u reaches tau
-          cnt += hit ? 1u : 0u;
-          hv = hit ? v : hv;
-          he = hit ? e : he;
-        }
-        if (!c_live[j]) cnt = 0;
-        if (cnt) {
-          unsigned slot = atomicAdd(q_count, cnt);                          // LDS atomic
-          auto push = [&](float v, int e) {
-            const int row = row_of(e);
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) total += (unsigned)__builtin_popcount(hits[i][j]);
+    if (total) {
+      unsigned slot;
+      {  // the hardware serialises the lanes of one LDS atomic on one address (asm: the compiler would turn atomicAdd into
+         // a scalar loop over the active lanes)
+        const unsigned qa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)q_count;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(qa), "v"(total) : "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < C::NI; ++j) {
+          unsigned h = hits[i][j];
+          const int col = wc * C::TN + j * 32 + l31;
+          while (h) {
+            const int p = 31 - __builtin_clz(h);                                // highest set bit first = lowest e first
+            h &= ~(1u << p);
+            const int e = 15 - p;
+            // v = acc[i][j][e] by a bit-select tree (a ?: tree is turned into a scratch array indexed by e)
+            const unsigned b0 = 0u - (e & 1), b1 = 0u - ((e >> 1) & 1), b2 = 0u - ((e >> 2) & 1), b3 = 0u - ((e >> 3) & 1);
+            auto sel = [](unsigned mk, unsigned hi, unsigned lo) { return (hi & mk) | (lo & ~mk); };
+            unsigned s8[8], s4[4], s2[2];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s8[q] = sel(b0, __float_as_uint(acc[i][j][2 * q + 1]), __float_as_uint(acc[i][j][2 * q]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] = sel(b1, s8[2 * q + 1], s8[2 * q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) s2[q] = sel(b2, s4[2 * q + 1], s4[2 * q]);
+            const float v = __uint_as_float(sel(b3, s2[1], s2[0]));
+            const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
             if (slot < QCAP) {
               queue[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(row << 16 | col);
-            } else {                                                          // queue full: slow path
+            } else {                                                            // queue full: slow path
               const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
               if (u > row_c[row]) {
                 const int t = m0 + row;
@@ -604,18 +590,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
               }
             }
             ++slot;
-          };
-          if (cnt == 1) {
-            push(hv, he);
-          } else {                                                            // several survivors in one column block
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const float v = value(e);
-              if (__builtin_fmaf(c_h[j], bt[e], v) > tau[e]) push(v, e);
-            }
           }
         }
-#endif
+      }
+    }
+  } else {
+    // DENSE: every value + its band, C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) {
+        const int col = wc * C::TN + j * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, t = m0 + row;
+          float v;
+          if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
+          else v = acc[i][j][e] + c_bias[j];
+          if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
+        }
       }
     }
   }

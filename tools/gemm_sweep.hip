@@ -17,6 +17,21 @@ __global__ void fill_bf16(unsigned short *p, size_t n, unsigned seed) {
     p[i] = f32_to_bf16_bits(f);
   }
 }
+// int8 operands with a chosen distribution (power / clock against switching activity): sigma > 0: round(N(0, sigma)) clamped to
+// +-127 (sum of 4 uniforms); mode 1: |.| of it (non-negative); mode 2: multiples of 2 (7-bit values in the 8-bit grid)
+__global__ void fill_i8(signed char *p, size_t n, unsigned seed, float sigma, int mode) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    float g = 0.f;
+    for (int q = 0; q < 4; ++q) g += (float)((z >> (16 * q)) & 0xFFFF) / 65536.f - 0.5f;   // variance 4/12
+    int v = (int)rintf(g * 1.7320508f * sigma);
+    v = v > 127 ? 127 : (v < -127 ? -127 : v);
+    if (mode == 1) v = v < 0 ? -v : v;
+    if (mode == 2) v &= ~1;
+    p[i] = (signed char)v;
+  }
+}
 __global__ void ref_dense(const unsigned short *A, const unsigned short *B, int T, int d, int N, float *out) {
   int n = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
   if (n >= N) return;
@@ -79,16 +94,26 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&c.dense, (size_t)c.T * c.Ns * 4)); CK(hipMalloc(&c.ref, (size_t)512 * c.Ns * 4)); CK(hipMalloc(&c.res, 4));
   if (getenv("SWEEP_ZERO")) { CK(hipMemset(c.A, 0, (size_t)c.T * c.d * 2)); CK(hipMemset(c.B, 0, (size_t)c.N * c.d * 2)); printf("ZERO-FILLED operands\n"); }
   else { fill_bf16<<<4096, 256>>>(c.A, (size_t)c.T * c.d, 1); fill_bf16<<<4096, 256>>>(c.B, (size_t)c.N * c.d, 2); }
+  if (getenv("SWEEP_SIGMA")) {   // "sigmaA,sigmaB[,modeA,modeB]"
+    float sa = 32.f, sb = 32.f; int ma = 0, mb = 0;
+    sscanf(getenv("SWEEP_SIGMA"), "%f,%f,%d,%d", &sa, &sb, &ma, &mb);
+    fill_i8<<<4096, 256>>>((signed char *)c.A, (size_t)c.T * c.d * 2, 1, sa, ma);
+    fill_i8<<<4096, 256>>>((signed char *)c.B, (size_t)c.N * c.d * 2, 2, sb, mb);
+    printf("int8 operands: sigma %.0f / %.0f, mode %d / %d\n", sa, sb, ma, mb);
+  }
   ref_dense<<<dim3(c.Ns / 256, 512), 256>>>(c.A, c.B, 512, c.d, c.Ns, c.ref);
   CK(hipDeviceSynchronize());
 #define RUN(...) run<GemmCfg<__VA_ARGS__>>(#__VA_ARGS__, c, reps)
   const char *only = getenv("SWEEP_ONLY");   // "pp": just the schedule comparison
-  RUN(256, 256, 2, 2, 4, false);
-  RUN(256, 256, 2, 2, 4, true);
+  const int which = getenv("SWEEP_CFG") ? atoi(getenv("SWEEP_CFG")) : -1;   // one configuration only (power sampling: tools/smi_sample.sh)
+  if (which < 0 || which == 0) RUN(256, 256, 2, 2, 4, false);
+  if (which < 0 || which == 1) RUN(256, 256, 2, 2, 4, true);
   if (!only) {
-    RUN(256, 256, 2, 2, 4, false, 24);     // staging only, 8 waves
-    RUN(256, 256, 2, 2, 4, true, 24);      // staging only, int8 byte layout
-    RUN(256, 256, 2, 2, 4, true, 4);       // no staging (MFMA + reads + barriers)
+    if (which < 0 || which == 2) RUN(256, 256, 2, 2, 4, false, 24);     // staging only, 8 waves
+    if (which < 0 || which == 3) RUN(256, 256, 2, 2, 4, true, 24);      // staging only, int8 byte layout
+    if (which < 0 || which == 4) RUN(256, 256, 2, 2, 4, true, 4);       // no staging (MFMA + reads + barriers)
+    if (which == 5) RUN(256, 256, 2, 2, 4, true, 8);                    // no fragment reads (staging + MFMA on constant registers)
+    if (which == 6) RUN(256, 256, 2, 2, 4, true, 16);                   // no MFMA (staging + fragment reads)
   }
   return 0;
 }

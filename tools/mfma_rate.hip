@@ -52,7 +52,8 @@ void run(const char *name, const int *src, float *out, double ops_per_mfma) {
   const int grid = 256, iters = 20000;    // one 8-wave workgroup per CU: 2 waves per SIMD
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
-  for (int rep = 0; rep < 4; ++rep) {
+  const int reps = getenv("MFMA_RATE_REPS") ? atoi(getenv("MFMA_RATE_REPS")) : 4;   // many: long enough for the SMU's power average
+  for (int rep = 0; rep < reps; ++rep) {
     CK(hipEventRecord(e0, 0));
     rate_kernel<FMT><<<grid, 512>>>(src, out, iters);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -68,6 +69,7 @@ int main() {
     CK(hipMemcpy(src, h, 65536 * 4, hipMemcpyHostToDevice)); free(h); }
   float *out; CK(hipMalloc(&out, 256 * 512 * 4));
   run<-1>("int8 32x32x32", src, out, 2.0 * 32 * 32 * 32);
+  if (getenv("MFMA_RATE_ONLY_I8")) return 0;
   run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64);
   run<2>("f8f6f4 32x32x64, fp6 e2m3", src, out, 2.0 * 32 * 32 * 64);
   run<4>("f8f6f4 32x32x64, fp4 e2m1", src, out, 2.0 * 32 * 32 * 64);
