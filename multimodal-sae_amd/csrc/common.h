@@ -95,6 +95,14 @@ struct TopkExtra {
   int detail = 0;
 };
 
+// optional second output of the threshold select (msae_kth_value_launch): every value of the row ABOVE the threshold found is
+// appended to its row's candidate list as (order key << 32 | 0x7FFFFFFF - feature), feature of column j = j*stride + off
+struct KthPush {
+  int *cnt = nullptr;                // [T] list lengths (atomically advanced); null: no push
+  unsigned long long *cand = nullptr;
+  int cap = 0, stride = 1, off = 0;
+};
+
 // Bitonic sort of n (power of two) 64-bit keys in LDS, DESCENDING; all threads of the block call.
 __device__ __forceinline__ void bitonic_sort_desc_u64(unsigned long long *s, int n) {
   for (int size = 2; size <= n; size <<= 1) {

@@ -55,7 +55,7 @@ int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const f
 int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const int *n_rows,
                      float *vals, int32_t *idx, hipStream_t s, const TopkExtra &ex = TopkExtra());
 bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float *out, int out_ld,
-                           int out_col, hipStream_t s);
+                           int out_col, hipStream_t s, const KthPush &push = KthPush());
 
 namespace {
 
@@ -87,6 +87,17 @@ __host__ __device__ inline bool fast_shape_ok(int N, int d) {
   return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/32 must tile by BN = 256
 }
 __host__ __device__ inline bool i8_shape_ok(int N, int d) { return fast_shape_ok(N, d) && d % 128 == 0; }
+
+// The tile-major operand of the main candidate pass leaves the sample rows out (the sample pass has scored them: their
+// candidates are taken from its output, sample_push_kernel): -1/32 of the pass's matrix work and operand traffic.  Row n of W
+// (n not a sample row) is row main_row(n) of that operand; column c of the pass is feature gemm_feature(c).  31/32 N tiles by
+// 256 whenever the sample width does (fast_shape_ok).  -DMSAE_FULL_MAIN_PASS (tuning builds) keeps all rows in.
+#ifdef MSAE_FULL_MAIN_PASS
+constexpr bool MAIN_SKIPS_SAMPLE = false;
+#else
+constexpr bool MAIN_SKIPS_SAMPLE = true;
+#endif
+__host__ __device__ inline int main_row(int n) { return n - n / SAMPLE_STRIDE - ((n % SAMPLE_STRIDE) > SAMPLE_OFF ? 1 : 0); }
 
 // 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | row statistics (sw, Q_i8, |W_n|^2, Q_bf) f32x4 [N]
 // and [S] | bf16-pass column constants (1, Q_bf, 0, 0) f32x4 [N] and [S] | Wq int8 [N][d] | sample int8 [S][d]
@@ -316,7 +327,11 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
         packed[q] = (int)w;
       }
       *reinterpret_cast<i32x4 *>(wq + (size_t)n * d + c) = packed;
-      *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
+      if (layout == 1 && MAIN_SKIPS_SAMPLE) {
+        if (!samp) *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)main_row(n), c, d, 1)) = packed;
+      } else {
+        *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
+      }
       if (samp) {
         *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
         *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
@@ -514,13 +529,14 @@ __global__ __launch_bounds__(256) void row_p4_kernel(const float *__restrict__ a
 
 // Wq_o[n][j] = Wq[n][odims[j]] (0 where odims[j] < 0) for every feature row, and for the sample rows;
 // with it the column constants of the error band for THIS batch's outlier dims:
-//   colc[n] = (sw, Q, Si = |W_n|^2 - So, So = sum over outlier dims of (sw Wq)^2)
+//   colc[n] = (sw, Q, Si = |W_n|^2 - So, So = sum over outlier dims of (sw Wq)^2)   (colc_p: the same in main_row order)
 __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__restrict__ wq, int N, int d,
                                                         const int *__restrict__ odims,
                                                         const f32x4 *__restrict__ wstat,
                                                         signed char *__restrict__ wqo,
                                                         signed char *__restrict__ wqos,
-                                                        f32x4 *__restrict__ colc, f32x4 *__restrict__ colc_s) {
+                                                        f32x4 *__restrict__ colc, f32x4 *__restrict__ colc_s,
+                                                        f32x4 *__restrict__ colc_p, int skip) {
   __shared__ int s_dims[MAX_OUT];
   if (threadIdx.x < MAX_OUT) s_dims[threadIdx.x] = odims[threadIdx.x];
   __syncthreads();
@@ -544,7 +560,9 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
   sq += __shfl_xor(sq, 2, 64);
   sq += __shfl_xor(sq, 4, 64);
   const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
-  *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
+  // skip: the main pass runs over the non-sample rows only (main_row); its outlier operand and column constants in that order
+  if (!skip) *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
+  else if (!samp) *reinterpret_cast<i32x4 *>(wqo + (size_t)main_row(n) * MAX_OUT + j0) = packed;
   if (samp) *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
   if ((threadIdx.x & 7) == 0) {
     const f32x4 st = wstat[n];
@@ -552,6 +570,30 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
     const f32x4 cc = {st[0], st[1], fmaxf(st[2] - so, 0.f), so};
     colc[n] = cc;
     if (samp) colc_s[n / SAMPLE_STRIDE] = cc;
+    else if (skip) colc_p[main_row(n)] = cc;
+  }
+}
+
+// The main pass leaves the sample features out (main_row): their candidates are the sample pass's own upper values above the
+// token's threshold -- the entries the main pass's flush would have written for them (same u, same key).  One workgroup per token.
+__global__ __launch_bounds__(256) void sample_push_kernel(const float *__restrict__ sample, int S,
+                                                          const float *__restrict__ tau_vals, int tau_ld, int tau_col,
+                                                          int skip_a, int skip_b, int *__restrict__ cnt,
+                                                          unsigned long long *__restrict__ cand, int cap) {
+  const int t = blockIdx.x;
+  const float tv = tau_vals[(size_t)t * tau_ld + tau_col];
+  if (!(tv > 0.f)) return;                               // degenerate token: the main pass emits nothing either
+  const float *row = sample + (size_t)t * S;
+  for (int j = threadIdx.x * 4; j < S; j += 1024) {      // S % 256 == 0
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(row + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!(u[e] > tv)) continue;
+      const int feat = (j + e) * SAMPLE_STRIDE + SAMPLE_OFF;
+      if (feat == skip_a || feat == skip_b) continue;
+      const int slot = atomicAdd(cnt + t, 1);
+      if (slot < cap) cand[(size_t)t * cap + slot] = ((unsigned long long)f32_order_key(u[e]) << 32) | (unsigned)(0x7FFFFFFF - feat);
+    }
   }
 }
 
@@ -1214,7 +1256,7 @@ struct FusedPlan {
   bool fast, i8, small;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
-  size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
+  size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_dense, bytes;
 };
 
@@ -1248,6 +1290,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_xqo = take((size_t)p.Tp * MAX_OUT);
       p.off_colc = take((size_t)N * 16);
       p.off_colc_s = take((size_t)p.S * 16);
+      p.off_colc_p = take((size_t)N * 16);
       p.off_colmax = take((size_t)d * 4);
       p.off_odims = take((size_t)(MAX_OUT + 1) * 4);
       p.off_isout = take((size_t)d);
@@ -1873,6 +1916,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const float z = co.z, zz12 = z * z / 12.f;
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
+  f32x4 *cc_perm = nullptr;        // ... of the main pass in its own column order when it leaves the sample rows out
+  bool skip_sample = false;
   if (pl.i8) {
     signed char *xq = reinterpret_cast<signed char *>(ws + pl.off_xq);
     signed char *xqo = reinterpret_cast<signed char *>(ws + pl.off_xqo);
@@ -1902,8 +1947,11 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
                          T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
+    skip_sample = MAIN_SKIPS_SAMPLE && tile_major == 1;   // the tile-major main operand holds the non-sample rows only
+    cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
-                       reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp);
+                       reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp, cc_perm,
+                       skip_sample ? 1 : 0);
     colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(xq); op_main.ldA = d;
     op_main.B = tile_major ? prepared + pp.off_wqp : reinterpret_cast<const unsigned char *>(wq); op_main.ldB = d;
@@ -1949,19 +1997,34 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   }
   prof_mark(co.prof, 2, s);
   int rc = 0;
-  if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s)) {
+  // the sample features' own candidates, when the main pass leaves them out: from the threshold select itself (it holds
+  // the row in registers), or by sample_push_kernel for the shapes / calls it does not cover (hook edits: features to skip)
+  const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
+  KthPush push{};
+  bool pushed = false;
+  if (skip_sample && skip_a < 0 && skip_b < 0) {
+    push.cnt = cnt; push.cand = cand; push.cap = pl.cap; push.stride = SAMPLE_STRIDE; push.off = SAMPLE_OFF;
+    pushed = true;
+  }
+  if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s, push)) {
     rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);  // generic shapes
     if (rc) return rc;
+    pushed = false;
   }
+  if (skip_sample && !pushed)
+    hipLaunchKernelGGL(sample_push_kernel, dim3(T), dim3(256), 0, s, sample, pl.S, tauv, pl.r, pl.r - 1, skip_a, skip_b, cnt,
+                       cand, pl.cap);
   prof_mark(co.prof, 3, s);
+  const int N_main = skip_sample ? N - pl.S : N;
   {  // full pass with the threshold epilogue
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = 1; ep.bias_off = 0;
+    if (skip_sample) { ep.skip_stride = SAMPLE_STRIDE; ep.skip_off = SAMPLE_OFF; }
     ep.tau_vals = tauv; ep.tau_ld = pl.r; ep.tau_col = pl.r - 1;
     ep.cnt = cnt; ep.cand = cand; ep.cap = pl.cap;
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
-    ep.rowc = rowc; ep.colc = colc; ep.refs = refs; ep.zz12 = zz12;
+    ep.rowc = rowc; ep.colc = skip_sample ? cc_perm : colc; ep.refs = refs; ep.zz12 = zz12;
 #ifdef MSAE_GEMM_TIMELINE
     if (!g_timeline) (void)hipMalloc(&g_timeline, 64 * 8 * 8);
     (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
@@ -1969,10 +2032,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #endif
 #ifdef MSAE_GEMM_RING64
     const int grc = pl.i8 ? (op_main.packed == 2 ? gemm64_launch<GemmI8R64, false>(op_main, T, pl.Tp, N, ep, s)
-                                                 : gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s))
+                                                 : gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s))
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
 #else
-    const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N, ep, s)
+    const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s)
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
 #endif
     if (grc) return grc;

@@ -62,7 +62,8 @@ typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 struct GemmEpilogue {
   const float *bias;             // b_enc
-  int bias_stride, bias_off;     // feature of column n is n*bias_stride + bias_off
+  int bias_stride, bias_off;     // feature of column n is n*bias_stride + bias_off ...
+  int skip_stride, skip_off;     // ... or, with skip_stride = S > 0, the n-th feature f with f % S != skip_off (gemm_feature)
   float *dense; int ld_dense;    // DENSE
   const float *tau_vals; int tau_ld, tau_col;   // THRESH: tau[t] = tau_vals[t*tau_ld + tau_col]
   int *cnt; unsigned long long *cand; int cap;  // candidate lists
@@ -468,6 +469,15 @@ __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int co
   return __builtin_fmaf(pz, col_c[2 * C::NT + col], __builtin_fmaf(rz * mf * mf, col_c[4 * C::NT + col], rz * col_c[3 * C::NT + col]));
 }
 
+// feature id of column n of this launch
+__device__ __forceinline__ int gemm_feature(const GemmEpilogue &ep, int n) {
+  if (ep.skip_stride) {
+    const int g = n / (ep.skip_stride - 1), p = n - g * (ep.skip_stride - 1);
+    return g * ep.skip_stride + p + (p >= ep.skip_off ? 1 : 0);
+  }
+  return n * ep.bias_stride + ep.bias_off;
+}
+
 template <class C, bool DENSE, class F>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const GemmEpilogue &ep, int T,
                                               int m0, int n0, int wr, int wc, int lane,
@@ -495,7 +505,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     c_bias[j] = col_c[col];
     c_sw[j] = col_c[C::NT + col];
     c_h[j] = col_c[5 * C::NT + col];
-    const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+    const int feat = gemm_feature(ep, n0 + col);
     c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
   }
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -582,7 +592,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
               const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
               if (u > row_c[row]) {
                 const int t = m0 + row;
-                const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+                const int feat = gemm_feature(ep, n0 + col);
                 const int gslot = atomicAdd(ep.cnt + t, 1);
                 if (gslot < ep.cap)
                   ep.cand[(size_t)t * ep.cap + gslot] =
@@ -627,7 +637,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
       const float u = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));   // the exact upper value
       if (!(u > row_c[row])) continue;
       const int t = m0 + row;
-      const int feat = (n0 + col) * ep.bias_stride + ep.bias_off;
+      const int feat = gemm_feature(ep, n0 + col);
       const int gslot = atomicAdd(ep.cnt + t, 1);
       if (gslot < ep.cap)
         ep.cand[(size_t)t * ep.cap + gslot] =
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
-      const int feat = n * ep.bias_stride + ep.bias_off;
+      const int feat = gemm_feature(ep, n);
       side0 = ep.bias ? ep.bias[feat] : 0.f;
       const f32x4 cc = ep.colc[n];
       side1 = cc[0];

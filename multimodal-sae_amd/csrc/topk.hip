@@ -233,7 +233,7 @@ constexpr int KTH_LOW_BIT = 14;
 template <int VPL>
 __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict__ rows, int T, int S,
                                                         int ld, int r, float *__restrict__ out,
-                                                        int out_ld, int out_col) {
+                                                        int out_ld, int out_col, KthPush push) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -257,6 +257,40 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     if (c >= r) lo = mid;
   }
   if (lane == 0) out[(size_t)t * out_ld + out_col] = f32_from_order_key(lo);
+  if (push.cnt && f32_from_order_key(lo) > 0.f) {      // the row's values above the threshold -> its candidate list
+    // one list reservation per row (a returning atomic per hit would chain ~r round trips per wave);
+    // lane masks of the compares on the scalar unit (the keys fill the registers: no per-lane counters or addresses)
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[i] > lo));
+      if ((i & 7) == 7) asm volatile("" : "+s"(total));   // at most 8 lane masks in flight (64 pairs would spill SGPRs into VGPRs)
+    }
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(push.cnt + t, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    unsigned long long *list = push.cand + (size_t)t * push.cap;
+    unsigned lo2 = lo;
+    asm volatile("" : "+v"(lo2));                      // the masks are recomputed here, not kept (64 SGPR pairs would spill into VGPRs)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const bool hit = key[i] > lo2;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+      if (m == 0ull) continue;                         // wave-uniform
+      if (hit) {
+        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const int j = ((i >> 2) * 64 + lane) * 4 + (i & 3);
+        // the key goes through a real move: otherwise every key lives in the high half of a register PAIR reserved for this
+        // 64-bit store for the whole kernel (2 x VPL VGPRs: half the occupancy)
+        unsigned kk;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kk) : "v"(key[i]));
+        if (slot < push.cap) list[slot] = ((unsigned long long)kk << 32) | (unsigned)(0x7FFFFFFF - (j * push.stride + push.off));
+      }
+      base += __builtin_popcountll(m);
+      if ((i & 7) == 7) asm volatile("" : "+s"(base));
+    }
+  }
 }
 
 // ---- merge of per-shard top-k_loc lists (feature-sharded encode, msae/parallel.py) ---------------
@@ -340,13 +374,14 @@ int msae_topk_launch(const float *latents, int T, int N, int k, int ld, const in
 }
 
 // out[t*out_ld + out_col] = a threshold with >= r values of rows[t][0..S) at or above it (the r-th
-// largest rounded down by < 0.2 %); false when the shape has no fast kernel.
+// largest rounded down by < 0.2 %), and optionally the values above it into the rows' candidate lists (KthPush); false when
+// the shape has no fast kernel.
 bool msae_kth_value_launch(const float *rows, int T, int S, int ld, int r, float *out, int out_ld,
-                           int out_col, hipStream_t s) {
+                           int out_col, hipStream_t s, const KthPush &push) {
   if (S % 256 || ld % 4 || !msae_aligned(rows, 16) || r < 1 || r > S) return false;
   const dim3 grid((T + 3) / 4), block(256);
   switch (S / 64) {
-#define KTH_CASE(V) case V: hipLaunchKernelGGL(kth_value_kernel<V>, grid, block, 0, s, rows, T, S, ld, r, out, out_ld, out_col); return true;
+#define KTH_CASE(V) case V: hipLaunchKernelGGL(kth_value_kernel<V>, grid, block, 0, s, rows, T, S, ld, r, out, out_ld, out_col, push); return true;
     KTH_CASE(4) KTH_CASE(8) KTH_CASE(16) KTH_CASE(32) KTH_CASE(64) KTH_CASE(128)
 #undef KTH_CASE
     default: return false;

@@ -234,7 +234,8 @@ def coarse(request, dev):
 
 
 @pytest.mark.parametrize("T,d,N,k", [(384, 4096, 16384, 32), (300, 1024, 8192, 64), (130, 192, 8192, 32), (70, 448, 16384, 16),
-                                     (260, 512, 8192, 1), (260, 512, 8192, 2), (1, 1024, 8192, 32)])
+                                     (260, 512, 8192, 1), (260, 512, 8192, 2), (1, 1024, 8192, 32),
+                                     (300, 512, 24576, 32)])   # sample width 768: generic threshold select + sample_push_kernel
 def test_fused_encode_bit_exact_vs_oracle(dev, coarse, T, d, N, k):
     from msae import ops
 
@@ -321,8 +322,10 @@ def test_fused_encode_hook_edits(dev, coarse):
     prepared = ops.prepare_encoder(W_enc)
     pre = ops.pre_acts(x, W_enc, b_enc, b_dec)
     hot = int(pre[0].argmax())
+    hot_s = 13 + 32 * int(pre[0, 13::32].argmax())     # a hot feature of the 1/32 sample (its candidates come from the sample pass)
     for kw in (dict(set_feature=77, set_value=10.0), dict(zero_feature=hot),
-               dict(set_feature=5, set_value=0.25, zero_feature=hot)):
+               dict(set_feature=5, set_value=0.25, zero_feature=hot), dict(zero_feature=hot_s),
+               dict(set_feature=hot_s, set_value=0.5, zero_feature=hot)):
         lat = pre.clone()
         if kw.get("set_feature", -1) >= 0:
             lat[:, kw["set_feature"]] = kw["set_value"]
