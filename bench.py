@@ -281,8 +281,11 @@ def main():
 
     def roofline_fields(stage, dec_ms, out, rows, tokens_decoded, with_traffic):
         mean = stage.mean(0)
-        ach = 2.0 * T * d * rows / (float(mean[3]) * 1e-3) / 1e12
         i8 = os.environ.get("MSAE_COARSE", "int8")[0] != "b"
+        # the int8 main pass of a batch of more than 256 tokens runs over 31/32 of the features (the sample pass has
+        # scored the rest, encode_fused.hip: main_row): count the work the launch does, not the width
+        width = rows - rows // 32 if (i8 and T > 256 and not os.environ.get("MSAE_GEMM_ROWMAJOR")) else rows
+        ach = 2.0 * T * d * width / (float(mean[3]) * 1e-3) / 1e12
         peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
         kname = "gemm_kernel<int8,THRESH>" if i8 else "gemm_kernel<bf16,THRESH>"
         sustained = SUSTAINED_I8_TOPS if i8 else SUSTAINED_BF16_TFLOPS
@@ -290,8 +293,9 @@ def main():
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak,
                            "sustained_peak": sustained, "sustained_frac": ach / sustained,
-                           "ops": "2*T*d*N_rank multiply-adds counted as 2 ops each (int8 MACs on the int8 path), "
-                                  "rank 0's launch; sustained_peak = the guide's measured MFMA micro-benchmark ceiling",
+                           "ops": "2*T*d*W multiply-adds counted as 2 ops each (int8 MACs on the int8 path), W = %d columns of "
+                                  "rank 0's launch (N_rank %d); sustained_peak = the guide's measured MFMA micro-benchmark "
+                                  "ceiling; the kernel runs at the package power limit (profiles/r03_power.txt)" % (width, rows),
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": float(mean[3])}
         res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
         res["stage_ms"]["decode"] = dec_ms
