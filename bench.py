@@ -158,6 +158,11 @@ def main():
     ap.add_argument("--acts", default=None, help="N = 1: safetensors file with one [T, d] activation tensor")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: whatever a library prints there (RCCL's version banner at
+    # communicator creation, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,7 +264,7 @@ def main():
     def emit():
         if rank == 0 and not emitted.is_set():
             emitted.set()
-            print(json.dumps(res), flush=True)
+            print(json.dumps(res), file=json_out, flush=True)
 
     def on_stall():
         res["error"] = f"a collective leg did not finish within {SHARDED_LEG_TIMEOUT_S} s"
