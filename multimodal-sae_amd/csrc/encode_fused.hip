@@ -9,10 +9,13 @@
 //                    outlier dims in their own 128-wide k-tile at scale m[t]*sx[t]; the matching
 //                    columns of Wq are gathered into an outlier tile.  (bf16 pass: xb = bf16(a32).)
 //   2. gemm<DENSE>   coarse pre-acts of a 1/32 strided SAMPLE of the features -> [T][S] f32
-//   3. kth value     tau[t] = r-th largest sample value: ~32*r features of the full width exceed it
-//   4. gemm<THRESH>  THE DOMINANT KERNEL (gemm_mfma.h): [T][d] x [d][N] on the matrix cores;
+//   3. kth value     tau[t] = r-th largest sample value: ~32*r features of the full width exceed it; the sample
+//                    features above tau start the token's candidate list (KthPush / sample_push_kernel)
+//   4. gemm<THRESH>  THE DOMINANT KERNEL (gemm_mfma.h): [T][d] x [d][N] on the matrix cores -- for batches of more
+//                    than 256 tokens over the 31/32 of the features the sample pass has not scored (main_row);
 //                    epilogue: scales, +b_enc, compare with tau[t], append (feature, coarse) of the
-//                    rare survivors to a per-token candidate list.  Roofline: MFMA, 2*d*N op/token.
+//                    rare survivors to a per-token candidate list.  Roofline: MFMA, 2*d*N op/token (in practice the
+//                    package power limit: DESIGN.md section 5).
 //   5. select_rescore per token: order candidates by their UPPER value u, re-score the best ones
 //                    with the exact ascending-k f32 fma chain over the f32 W_enc rows, take the
 //                    canonical top-k, and verify that EVERY feature whose u reaches the exact
