@@ -48,6 +48,7 @@
 
 #include "common.h"
 #include "gemm_mfma.h"
+#include "gemm_skinny.h"
 #ifdef MSAE_GEMM_RING64   // tuning builds: the 64-byte / 4-slot ring variant of the candidate GEMM (measured slower, kept as a record)
 #include "gemm_mfma64.h"
 #endif
@@ -82,7 +83,7 @@ constexpr int EXACT_T_MAX = 0;      // fused path for every T (T=1: 1 GiB bf16 s
 struct Prepared {
   unsigned magic;
   int N, d, S;
-  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, off_wqp, off_wqsp, bytes;
+  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, off_wqp, off_wqsp, off_wqf, off_wqsf, bytes;
 };
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 
@@ -104,6 +105,7 @@ __host__ __device__ inline int main_row(int n) { return n - n / SAMPLE_STRIDE - 
 
 // 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | row statistics (sw, Q_i8, |W_n|^2, Q_bf) f32x4 [N]
 // and [S] | bf16-pass column constants (1, Q_bf, 0, 0) f32x4 [N] and [S] | Wq int8 [N][d] | sample int8 [S][d]
+// | Wq fragment-major [N/16][d/64][64 lanes][16 B] | sample fragment-major (the weight-stream kernel's operand, gemm_skinny.h)
 // | Wq tile-major [N/256][d/128][256][128] | sample tile-major (the candidate GEMM's operands, gemm_mfma.h; the
 // row-major copies feed the S = 1 weight streams and the outlier-column gather)
 inline Prepared make_prepared(int N, int d) {
@@ -124,6 +126,8 @@ inline Prepared make_prepared(int N, int d) {
   p.off_wqs = take(q ? (size_t)p.S * d : 0);
   p.off_wqp = take(q ? (size_t)N * d : 0);
   p.off_wqsp = take(q ? (size_t)p.S * d : 0);
+  p.off_wqf = take(q ? (size_t)N * d : 0);
+  p.off_wqsf = take(q ? (size_t)p.S * d : 0);
   p.bytes = o;
   return p;
 }
@@ -242,6 +246,12 @@ __host__ __device__ __forceinline__ size_t packed_off(size_t r, int c, int d, in
   const int kt = c >> 7, ch = (c >> 4) & 7;
   return ((rt * (size_t)(d >> 7) + kt) * 256 + ri) * 128 + (size_t)((ch ^ (int)((ri >> 1) & 7)) << 4);
 }
+// Fragment-major int8 operand of the weight-stream kernel (gemm_skinny.h): the 16 B at column c (c % 16 == 0) of row r sit where
+// lane 16 ((c % 64) / 16) + r % 16 of a v_mfma_i32_16x16x64_i8 B fragment reads them -- one k-step of a 16-row block is ONE
+// contiguous kilobyte, lane l at byte 16 l.
+__host__ __device__ __forceinline__ size_t frag_off(size_t r, int c, int d) {
+  return ((((r >> 4) * (size_t)(d >> 6) + (size_t)(c >> 6)) << 6) + (size_t)((((c >> 4) & 3) << 4) + (int)(r & 15))) << 4;
+}
 // which operand layout the candidate GEMM reads: 1 = tile-major, 128-byte k-tiles in a 2-slot ring (default); 0 =
 // row-major (environment MSAE_GEMM_ROWMAJOR=1, for A/B runs); 2 = tile-major 64-byte k-tiles in a 4-slot ring (tuning
 // builds with -DMSAE_GEMM_RING64 and MSAE_GEMM_RING64=1 in the environment).  Read at every call: an immutable property
@@ -274,7 +284,9 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
                                                               signed char *__restrict__ wq,
                                                               signed char *__restrict__ wqs,
                                                               signed char *__restrict__ wqp,
-                                                              signed char *__restrict__ wqsp, int layout) {
+                                                              signed char *__restrict__ wqsp,
+                                                              signed char *__restrict__ wqf,
+                                                              signed char *__restrict__ wqsf, int layout) {
   __shared__ float red[3][4];
   const int n = blockIdx.x;
   const float *row = W + (size_t)n * d;
@@ -335,9 +347,12 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
       } else {
         *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
       }
+      if (MAIN_SKIPS_SAMPLE) { if (!samp) *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)main_row(n), c, d)) = packed; }
+      else *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)n, c, d)) = packed;
       if (samp) {
         *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
         *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
+        *reinterpret_cast<i32x4 *>(wqsf + frag_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
       }
     }
   }
@@ -1921,6 +1936,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   f32x4 *cc_perm = nullptr;        // ... of the main pass in its own column order when it leaves the sample rows out
   bool skip_sample = false;
+  int skinny = 0;                  // 64 / 128: token rows of the weight-stream kernel's tile (gemm_skinny.h); 0: gemm_mfma.h
   if (pl.i8) {
     signed char *xq = reinterpret_cast<signed char *>(ws + pl.off_xq);
     signed char *xqo = reinterpret_cast<signed char *>(ws + pl.off_xqo);
@@ -1937,6 +1953,11 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     // one row of output tiles (T <= 256) streams Wq from HBM once and keeps round 2's row-major operands + unstaggered
     // issue: tile-major + stagger measured 2-3 % slower there (profiles/r03_ab_small_T.txt)
     const int tile_major = pl.Tp > G_BM ? gemm_layout() : 0;
+    // up to 128 tokens: the weight-stream kernel (gemm_skinny.h) runs both candidate passes: xq row-major, Wq fragment-major
+    if (T <= 128 && tile_major == 0 && gemm_layout() == 1 && d % 1024 == 0 && N % (SAMPLE_STRIDE * 256) == 0 &&
+        getenv("MSAE_NO_SKINNY") == nullptr)
+      skinny = T <= 64 ? 64 : 128;
+    const bool w_packed = tile_major == 1 || skinny != 0;   // the W side of the candidate passes reads the tile-major copies
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
       hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
@@ -1950,21 +1971,22 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
                          T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
-    skip_sample = MAIN_SKIPS_SAMPLE && tile_major == 1;   // the tile-major main operand holds the non-sample rows only
+    skip_sample = MAIN_SKIPS_SAMPLE && w_packed;   // the tile-major main operand holds the non-sample rows only
     cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
                        reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp, cc_perm,
                        skip_sample ? 1 : 0);
     colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(xq); op_main.ldA = d;
-    op_main.B = tile_major ? prepared + pp.off_wqp : reinterpret_cast<const unsigned char *>(wq); op_main.ldB = d;
+    op_main.B = skinny ? prepared + pp.off_wqf : tile_major ? prepared + pp.off_wqp : reinterpret_cast<const unsigned char *>(wq);
+    op_main.ldB = d;
     op_main.nk = tile_major == 2 ? d / 64 : d / 128;
-    op_main.packed = tile_major;
+    op_main.packed = skinny ? 3 : tile_major;
     op_main.Ao = reinterpret_cast<const unsigned char *>(xqo);
     op_main.Bo = reinterpret_cast<const unsigned char *>(wqo);
     op_main.n_out = odims + MAX_OUT;
     op_samp = op_main;
-    op_samp.B = tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
+    op_samp.B = skinny ? prepared + pp.off_wqsf : tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
   } else {
     hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z);
@@ -1993,8 +2015,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                                                  : gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s))
                           : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
 #else
-    const int grc = pl.i8 ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
-                          : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
+    const int grc = skinny == 64    ? gemm_skinny_launch<64, true>(op_samp, T, d, pl.S, ep, s)
+                    : skinny == 128 ? gemm_skinny_launch<128, true>(op_samp, T, d, pl.S, ep, s)
+                    : pl.i8         ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
+                                    : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
 #endif
     if (grc) return grc;
   }
@@ -2038,8 +2062,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                                                  : gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s))
                           : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
 #else
-    const int grc = pl.i8 ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s)
-                          : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
+    const int grc = skinny == 64    ? gemm_skinny_launch<64, false>(op_main, T, d, N_main, ep, s)
+                    : skinny == 128 ? gemm_skinny_launch<128, false>(op_main, T, d, N_main, ep, s)
+                    : pl.i8         ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s)
+                                    : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
 #endif
     if (grc) return grc;
   }
@@ -2177,10 +2203,12 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
                          colbf_s, reinterpret_cast<signed char *>(base + p.off_wq),
                          reinterpret_cast<signed char *>(base + p.off_wqs), reinterpret_cast<signed char *>(base + p.off_wqp),
-                         reinterpret_cast<signed char *>(base + p.off_wqsp), gemm_layout() == 2 ? 2 : 1);
+                         reinterpret_cast<signed char *>(base + p.off_wqsp), reinterpret_cast<signed char *>(base + p.off_wqf),
+                         reinterpret_cast<signed char *>(base + p.off_wqsf), gemm_layout() == 2 ? 2 : 1);
     else
       hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
-                         colbf_s, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, 1);
+                         colbf_s, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr,
+                         (signed char *)nullptr, (signed char *)nullptr, 1);
   }
   return msae_launch_status();
 }

@@ -342,6 +342,33 @@ def test_fused_encode_hook_edits(dev, coarse):
     assert torch.equal(i, ei) and torch.equal(v, ev)
 
 
+@pytest.mark.parametrize("T", [17, 40, 64, 65, 100, 128, 129])
+def test_weight_stream_kernel_batches(dev, T):
+    """17 ... 128 tokens: both candidate passes run on the weight-stream kernel (csrc/gemm_skinny.h: 64- / 128-token tiles,
+    fragment-major Wq, the sample features' candidates from the sample pass); 129 is the first batch back on the 256-row
+    tiles.  Outputs == the exact path, with and without hook edits (a hot sample feature included)."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 31)
+    x = _rand_x(dev, T, d, 32 + T)
+    prepared = ops.prepare_encoder(W_enc)
+    pre = ops.pre_acts(x, W_enc, b_enc, b_dec)
+    hot = int(pre[T // 2].argmax())
+    hot_s = 13 + 32 * int(pre[T // 3, 13::32].argmax())
+    for kw in (dict(), dict(set_feature=hot_s, set_value=7.5), dict(zero_feature=hot), dict(set_feature=5, set_value=0.25, zero_feature=hot_s)):
+        lat = pre.clone()
+        if kw.get("set_feature", -1) >= 0:
+            lat[:, kw["set_feature"]] = kw["set_value"]
+        if kw.get("zero_feature", -1) >= 0:
+            lat[:, kw["zero_feature"]] = 0.0
+        ev, ei = ops.topk(lat, k)
+        v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k, **kw)
+        assert (status != 2).all()
+        assert (status == 0).float().mean() > 0.9, f"fast path verified only {(status == 0).float().mean():.2%} of the tokens"
+        assert torch.equal(i, ei) and torch.equal(v, ev), (T, kw)
+
+
 def test_fused_encode_degenerate_tokens_take_exact_path(dev, coarse):
     """Tokens with (almost) no positive pre-activation cannot pass the guard band: they must come
     back from the in-call exact fallback (status 1) with the canonical zero-filled top-k."""

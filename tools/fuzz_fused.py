@@ -17,7 +17,7 @@ prepared_cache = {}
 for c in range(cases):
     N = rng.choice([8192, 16384, 24576, 32768, 65536])
     d = rng.choice([256, 512, 1024, 2048])
-    T = rng.choice([1, 7, 16, 17, 64, 255, 256, 257, 300, 511, 512, 513, 1000, 2049])
+    T = rng.choice([1, 7, 16, 17, 33, 64, 65, 100, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1000, 2049])
     k = rng.choice([1, 2, 8, 32, 64, 100, 256])
     kind = rng.choice(["gauss", "trained_like", "spiky1x20n", "lognorm", "dup"])
     coarse = rng.choice(["int8", "int8", "bf16"])
