@@ -1529,7 +1529,8 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const signed char *__re
 #define MSAE_MF_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 template <int DSEG>
-__global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__restrict__ wq, const f32x4 *__restrict__ wstat,
+__global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__restrict__ wqf, const signed char *__restrict__ wqsf,
+                                                        const f32x4 *__restrict__ wstat,
                                                         const float *__restrict__ b_enc, int N, int T,
                                                         const signed char *__restrict__ xhi,
                                                         const signed char *__restrict__ xlo,
@@ -1562,18 +1563,22 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__res
   __syncthreads();
   const signed char *ah_p = xs + (size_t)l15 * PITCH + lg * 16;          // this lane's A fragment: token l15, k quarter lg
   const signed char *al_p = ah_p + (size_t)16 * PITCH;
+  // B fragments from the FRAGMENT-major copies (frag_off: one k-step of a 16-row block = one contiguous kilobyte, this lane's 16 B
+  // at byte 16 lane; the row-major copy's 16 rows x 64 B per instruction are half-line requests: 0.13 -> 0.09 ms of stream).  The
+  // main copy holds the non-sample rows in main_row order, the sample rows have their own: blocks [0, n_main) | [n_main, N / 16).
   const int n_blocks = N / 16, wave_g = blockIdx.x * 8 + wv, n_waves = gridDim.x * 8;
+  const int n_main = MAIN_SKIPS_SAMPLE ? (N - N / SAMPLE_STRIDE) / 16 : n_blocks;
   for (int blk = wave_g; blk < n_blocks; blk += n_waves) {
-    const int n0 = blk * 16;
-    const signed char *bp = wq + (size_t)(n0 + l15) * d + lg * 16;
+    const bool samp_blk = blk >= n_main;
+    const signed char *bp = (samp_blk ? wqsf + ((size_t)(blk - n_main) * (d / 64) << 10) : wqf + ((size_t)blk * (d / 64) << 10)) + lane * 16;
     i32x4 acc_h = {0, 0, 0, 0}, acc_l = {0, 0, 0, 0};
     i32x4 ba[UN], bb[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + u * 64));
+    for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (size_t)u * 1024));
 #pragma nounroll
     for (int ks = 0; ks < KS; ks += 2 * UN) {                            // KS % (2 UN) == 0 (d % 1024 == 0)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) bb[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (ks + UN + u) * 64));
+      for (int u = 0; u < UN; ++u) bb[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (size_t)(ks + UN + u) * 1024));
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const i32x4 ah = *reinterpret_cast<const i32x4 *>(ah_p + (ks + u) * 64);
@@ -1583,7 +1588,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__res
       }
       if (ks + 2 * UN < KS) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (ks + 2 * UN + u) * 64));
+        for (int u = 0; u < UN; ++u) ba[u] = MSAE_MF_LOAD(reinterpret_cast<const i32x4 *>(bp + (size_t)(ks + 2 * UN + u) * 1024));
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -1593,7 +1598,10 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const signed char *__res
         acc_l = __builtin_amdgcn_mfma_i32_16x16x64_i8(al, bb[u], acc_l, 0, 0, 0);
       }
     }
-    const int n = n0 + l15;
+    int n;                                               // feature of this lane's column
+    if (samp_blk) n = ((blk - n_main) * 16 + l15) * SAMPLE_STRIDE + SAMPLE_OFF;
+    else if (MAIN_SKIPS_SAMPLE) { const int c = blk * 16 + l15, g = c / (SAMPLE_STRIDE - 1), q = c - g * (SAMPLE_STRIDE - 1); n = g * SAMPLE_STRIDE + q + (q >= SAMPLE_OFF ? 1 : 0); }
+    else n = blk * 16 + l15;
     const f32x4 st = wstat[n];
     const float bias = b_enc ? b_enc[n] : 0.f;
 #pragma unroll
@@ -1846,6 +1854,8 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
   int *n_flagged = flagged + T;
   const signed char *wq = reinterpret_cast<const signed char *>(prepared + pp.off_wq);
+  const signed char *wqf = reinterpret_cast<const signed char *>(prepared + pp.off_wqf);     // fragment-major copies (MFMA stream)
+  const signed char *wqsf = reinterpret_cast<const signed char *>(prepared + pp.off_wqsf);
   const f32x4 *wstat = reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat);
   prof_mark(co.prof, 0, s);
   hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, 2 * T,
@@ -1873,7 +1883,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   do {                                                                                                             \
     MSAE_HIP_TRY(hipFuncSetAttribute((const void *)gemv_mfma_kernel<DSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)smem_m));                                                                \
-    hipLaunchKernelGGL(gemv_mfma_kernel<DSEG>, dim3(grid_m), dim3(512), smem_m, s, wq, wstat, b_enc, N, T, xhi, xlo, rowc, \
+    hipLaunchKernelGGL(gemv_mfma_kernel<DSEG>, dim3(grid_m), dim3(512), smem_m, s, wqf, wqsf, wstat, b_enc, N, T, xhi, xlo, rowc, \
                        zz12, skip_a, skip_b, surv, bound);                                                         \
   } while (0)
     switch (dseg) { case 1: MSAE_GEMV_M(1); break; case 2: MSAE_GEMV_M(2); break; case 4: MSAE_GEMV_M(4); break;
