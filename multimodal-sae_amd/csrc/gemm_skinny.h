@@ -148,41 +148,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   auto ks_of = [&](int c, int b) { const int bq = b + rot_b; return chunk_of(c) * KSC + (bq >= BPC ? bq - BPC : bq) * 2 * UN; };
   fetch_a(chunk_of(0));
 
-  // this lane's B fragment streams: feature groups 0 / 1 of the wave (rows 16 apart), 64 B of a row per k-step.
-  //   op.packed == 3: FRAGMENT-major Wq (encode_fused.hip: frag_off) -- [16-row block][k-step][lane][16 B]: the fragment of a
-  //     k-step is one contiguous kilobyte, lane l at byte 16 l, i.e. eight full 128-B lines per instruction;
-  //   op.packed == 0: row-major -- 16 rows x 64 B per instruction.  Half-line requests: the stream then runs at 3.3-4 TB/s
-  //     whatever is in flight, and the same with the tile-major copy (op.packed == 1: the wave's rows of a k-tile are 4 KB of
-  //     contiguous memory, but still fetched as 64-B pieces).
-  const int row0 = (n0 & 255) + wave * 32 + l15;         // row inside the 256-row tile; row0 + 16 has the same swizzle
-  const unsigned char *brow0, *brow1;
-  unsigned poff = 0;
-  size_t kstep = 64, kt_stride = 0;
-  if (op.packed == 3) {
-    brow0 = op.B + ((size_t)((n0 >> 4) + wave * 2) * (size_t)(d >> 6) << 10) + lane * 16;
-    brow1 = brow0 + ((size_t)(d >> 6) << 10);
-    kstep = 1024;
-  } else if (op.packed) {
-    brow0 = op.B + (size_t)(n0 >> 8) * (size_t)(d / 128) * 32768 + (size_t)row0 * 128;
-    brow1 = brow0 + 16 * 128;
-    poff = (unsigned)((lg ^ gemm_swz(row0)) << 4);
-    kt_stride = 32768;
-  } else {
-    brow0 = op.B + (size_t)(n0 + wave * 32 + l15) * op.ldB + lg * 16;
-    brow1 = brow0 + (size_t)16 * op.ldB;
-  }
+  // this lane's B fragment streams: feature groups 0 / 1 of the wave (rows 16 apart), 64 B of a row per k-step, from the
+  // FRAGMENT-major Wq copy (encode_fused.hip: frag_off) -- [16-row block][k-step][lane][16 B]: the fragment of a k-step is one
+  // contiguous kilobyte, lane l at byte 16 l, i.e. eight full 128-B lines per instruction.  (Fragments read from the row-major
+  // copy -- 16 rows x 64 B per instruction -- are half-line requests: that stream ran at 3.3-4 TB/s whatever was in flight, and
+  // the same from the tile-major copy, where the wave's rows of a k-tile are 4 KB of contiguous memory.  NOTEBOOK.md.)
+  const unsigned char *brow0 = op.B + ((size_t)((n0 >> 4) + wave * 2) * (size_t)(d >> 6) << 10) + lane * 16;
+  const unsigned char *brow1 = brow0 + ((size_t)(d >> 6) << 10);
   i32x4 ba[UN][2], bb[UN][2];
   auto load_b = [&](i32x4 (&dst)[UN][2], int ks) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int k = ks + u;
-      const size_t off = op.packed == 1 ? (size_t)(k >> 1) * kt_stride + (poff ^ ((unsigned)(k & 1) << 6)) : (size_t)k * kstep;
-      dst[u][0] = MSAE_SK_LOAD(reinterpret_cast<const i32x4 *>(brow0 + off));
-#ifndef MSAE_SK_ONE_STREAM   // tuning builds (results invalid): only the first feature group's rows are streamed
-      dst[u][1] = MSAE_SK_LOAD(reinterpret_cast<const i32x4 *>(brow1 + off));
-#else
-      dst[u][1] = dst[u][0];
-#endif
+      dst[u][0] = MSAE_SK_LOAD(reinterpret_cast<const i32x4 *>(brow0 + ((size_t)(ks + u) << 10)));
+      dst[u][1] = MSAE_SK_LOAD(reinterpret_cast<const i32x4 *>(brow1 + ((size_t)(ks + u) << 10)));
     }
     MSAE_SK_FENCE();
   };
@@ -302,12 +280,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   gemm_epilogue<C, DENSE>(acc, ep, T, 0, n0, 0, wave, lane, smem, side, [] {});
 }
 
-// Host launcher: A = xq row-major [>= BM rows][d]; B = Wq fragment-major (op.packed = 3; 0 / 1: row- / tile-major, slower); optional
+// Host launcher: A = xq row-major [>= BM rows][d]; B = Wq fragment-major (op.packed = 3); optional
 // outlier tiles [rows][128] row-major.
 template <int BM, int NW, bool DENSE>
 inline int gemm_skinny_launch_nw(const GemmOperands &op, int T, int d, int N, const GemmEpilogue &ep, hipStream_t s) {
   using C = SkinnyCfg<BM, NW>;
-  if (T > BM || N % C::BN || d % C::KC || (op.packed != 0 && op.packed != 1 && op.packed != 3) || op.ldA != (size_t)d || op.ldB != (size_t)d) return MSAE_EINVAL;
+  if (T > BM || N % C::BN || d % C::KC || op.packed != 3 || op.ldA != (size_t)d) return MSAE_EINVAL;
   auto kern = gemm_skinny_kernel<BM, NW, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
   hipLaunchKernelGGL(kern, dim3(N / C::BN), dim3(C::NT), C::LDS_BYTES, s, op, T, d, ep);
