@@ -101,6 +101,8 @@ struct KthPush {
   int *cnt = nullptr;                // [T] list lengths (atomically advanced); null: no push
   unsigned long long *cand = nullptr;
   int cap = 0, stride = 1, off = 0;
+  int cnt_stride = 1;                // row t's counter is cnt[t * cnt_stride] ...
+  int row_stride = 0;                // ... and its list starts at cand[t * row_stride] (0: cap) -- segmented lists: segment 0
 };
 
 // Bitonic sort of n (power of two) 64-bit keys in LDS, DESCENDING; all threads of the block call.

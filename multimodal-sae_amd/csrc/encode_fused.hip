@@ -597,7 +597,8 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
 __global__ __launch_bounds__(256) void sample_push_kernel(const float *__restrict__ sample, int S,
                                                           const float *__restrict__ tau_vals, int tau_ld, int tau_col,
                                                           int skip_a, int skip_b, int *__restrict__ cnt,
-                                                          unsigned long long *__restrict__ cand, int cap) {
+                                                          unsigned long long *__restrict__ cand, int cap, int cnt_stride,
+                                                          int row_stride) {
   const int t = blockIdx.x;
   const float tv = tau_vals[(size_t)t * tau_ld + tau_col];
   if (!(tv > 0.f)) return;                               // degenerate token: the main pass emits nothing either
@@ -609,10 +610,29 @@ __global__ __launch_bounds__(256) void sample_push_kernel(const float *__restric
       if (!(u[e] > tv)) continue;
       const int feat = (j + e) * SAMPLE_STRIDE + SAMPLE_OFF;
       if (feat == skip_a || feat == skip_b) continue;
-      const int slot = atomicAdd(cnt + t, 1);
-      if (slot < cap) cand[(size_t)t * cap + slot] = ((unsigned long long)f32_order_key(u[e]) << 32) | (unsigned)(0x7FFFFFFF - feat);
+      const int slot = atomicAdd(cnt + (size_t)t * cnt_stride, 1);
+      if (slot < cap) cand[(size_t)t * row_stride + slot] = ((unsigned long long)f32_order_key(u[e]) << 32) | (unsigned)(0x7FFFFFFF - feat);
     }
   }
+}
+
+// Segmented candidate lists (GemmEpilogue::segs, batches of few tokens) -> the contiguous list the consumers read.  One wave per
+// token; a segment that overflowed reports cap + 1 (the consumers' "list overflow").
+__global__ __launch_bounds__(64) void compact_candidates_kernel(const int *__restrict__ seg_cnt,
+                                                                const unsigned long long *__restrict__ seg_cand, int segs,
+                                                                int cap, int *__restrict__ cnt,
+                                                                unsigned long long *__restrict__ cand) {
+  const int t = blockIdx.x, lane = threadIdx.x, scap = cap / segs;
+  int at = 0;
+  bool over = false;
+  for (int sg = 0; sg < segs; ++sg) {
+    const int c = seg_cnt[(size_t)t * segs + sg];
+    over |= c > scap;
+    const int n = c < scap ? c : scap;
+    for (int i = lane; i < n; i += 64) cand[(size_t)t * cap + at + i] = seg_cand[(size_t)t * cap + (size_t)sg * scap + i];
+    at += n;
+  }
+  if (lane == 0) cnt[t] = over ? cap + 1 : at;
 }
 
 // Reference feature of the GEMM's separable band bound: refs = mean (Q, Si, So) over the sample rows'
@@ -1275,7 +1295,8 @@ struct FusedPlan {
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
-  size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_flag, off_fbdense, off_dense, bytes;
+  size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_segcnt, off_segcand, off_flag, off_fbdense, off_dense, bytes;
+  int segs;   // > 1: the candidate passes append to segmented lists (compact_candidates_kernel joins them)
 };
 
 inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0) {
@@ -1334,7 +1355,10 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     p.off_tauv = take(tau_n * 4);
     p.off_taui = take(tau_n * 4);
     p.off_cnt = take((size_t)T * 4);
+    p.segs = (T <= 256 && p.cap >= 1024) ? 8 : 1;      // few tokens: hundreds of appends per list counter (GemmEpilogue::segs)
+    p.off_segcnt = take(p.segs > 1 ? (size_t)T * p.segs * 4 : 0);   // right behind cnt: zeroed with it
     p.off_cand = take((size_t)T * p.cap * 8);
+    p.off_segcand = take(p.segs > 1 ? (size_t)T * p.cap * 8 : 0);
     p.fb_cap = fallback_capacity(T, N);
     p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
     p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);   // token list [T] | count | per-pass counts
@@ -1935,7 +1959,12 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
   prof_mark(co.prof, 0, s);
-  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, (size_t)T, flagged, (size_t)T + 64 + pl.fb_chunks,
+  // producers of the candidate lists write the segmented lists when the plan has them (compact_candidates_kernel joins them)
+  int *pcnt = pl.segs > 1 ? reinterpret_cast<int *>(ws + pl.off_segcnt) : cnt;
+  unsigned long long *pcand = pl.segs > 1 ? reinterpret_cast<unsigned long long *>(ws + pl.off_segcand) : cand;
+  const int seg_cap = pl.cap / pl.segs;
+  const size_t n_cnt = pl.segs > 1 ? (pl.off_segcnt - pl.off_cnt) / 4 + (size_t)T * pl.segs : (size_t)T;
+  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, n_cnt, flagged, (size_t)T + 64 + pl.fb_chunks,
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
   if (!pl.i8)
     hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
@@ -2040,7 +2069,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   KthPush push{};
   bool pushed = false;
   if (skip_sample && skip_a < 0 && skip_b < 0) {
-    push.cnt = cnt; push.cand = cand; push.cap = pl.cap; push.stride = SAMPLE_STRIDE; push.off = SAMPLE_OFF;
+    push.cnt = pcnt; push.cand = pcand; push.cap = seg_cap; push.stride = SAMPLE_STRIDE; push.off = SAMPLE_OFF;
+    push.cnt_stride = pl.segs; push.row_stride = pl.cap;
     pushed = true;
   }
   if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s, push)) {
@@ -2049,8 +2079,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     pushed = false;
   }
   if (skip_sample && !pushed)
-    hipLaunchKernelGGL(sample_push_kernel, dim3(T), dim3(256), 0, s, sample, pl.S, tauv, pl.r, pl.r - 1, skip_a, skip_b, cnt,
-                       cand, pl.cap);
+    hipLaunchKernelGGL(sample_push_kernel, dim3(T), dim3(256), 0, s, sample, pl.S, tauv, pl.r, pl.r - 1, skip_a, skip_b, pcnt,
+                       pcand, seg_cap, pl.segs, pl.cap);
   prof_mark(co.prof, 3, s);
   const int N_main = skip_sample ? N - pl.S : N;
   {  // full pass with the threshold epilogue
@@ -2058,7 +2088,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.bias = b_enc; ep.bias_stride = 1; ep.bias_off = 0;
     if (skip_sample) { ep.skip_stride = SAMPLE_STRIDE; ep.skip_off = SAMPLE_OFF; }
     ep.tau_vals = tauv; ep.tau_ld = pl.r; ep.tau_col = pl.r - 1;
-    ep.cnt = cnt; ep.cand = cand; ep.cap = pl.cap;
+    ep.cnt = pcnt; ep.cand = pcand; ep.cap = pl.cap; ep.segs = pl.segs;
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
     ep.rowc = rowc; ep.colc = skip_sample ? cc_perm : colc; ep.refs = refs; ep.zz12 = zz12;
@@ -2079,6 +2109,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #endif
     if (grc) return grc;
   }
+  if (pl.segs > 1)
+    hipLaunchKernelGGL(compact_candidates_kernel, dim3(T), dim3(64), 0, s, pcnt, pcand, pl.segs, pl.cap, cnt, cand);
   prof_mark(co.prof, 4, s);
   if (shard) {   // feature-sharded group: this shard's best candidates travel, the owner of the token re-scores
     PackArgs pa{};

@@ -67,6 +67,10 @@ struct GemmEpilogue {
   float *dense; int ld_dense;    // DENSE
   const float *tau_vals; int tau_ld, tau_col;   // THRESH: tau[t] = tau_vals[t*tau_ld + tau_col]
   int *cnt; unsigned long long *cand; int cap;  // candidate lists
+  // A token's list can be split into `segs` (0 / 1: one) equal segments with their own counters cnt[t*segs + s]: workgroup b
+  // appends to segment b % segs.  A batch of few tokens has hundreds of appends per counter (~650 per token, all of the launch's
+  // workgroups on <= 256 addresses); same-address atomics serialise in L2, ~45 ns each: 0.03 ms of a 0.13 ms pass.
+  int segs;
   int skip_a, skip_b;            // features never emitted (hook edits replace their latents)
   // error-band constants (encode_fused.hip): per token (sx, m as float, P, -), per COLUMN of this
   // launch (sw, Q, Si, So).  int8: value = float(acc) * sx[t] * sw[n]; bf16 ignores sx, sw, Si, So.
@@ -469,6 +473,18 @@ __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int co
   return __builtin_fmaf(pz, col_c[2 * C::NT + col], __builtin_fmaf(rz * mf * mf, col_c[4 * C::NT + col], rz * col_c[3 * C::NT + col]));
 }
 
+// append one candidate key to token t's list (segment of this workgroup)
+__device__ __forceinline__ void gemm_push_candidate(const GemmEpilogue &ep, int t, unsigned long long key) {
+  if (ep.segs > 1) {
+    const int sg = (int)(blockIdx.x % (unsigned)ep.segs), scap = ep.cap / ep.segs;
+    const int gslot = atomicAdd(ep.cnt + (size_t)t * ep.segs + sg, 1);
+    if (gslot < scap) ep.cand[(size_t)t * ep.cap + (size_t)sg * scap + gslot] = key;
+  } else {
+    const int gslot = atomicAdd(ep.cnt + t, 1);
+    if (gslot < ep.cap) ep.cand[(size_t)t * ep.cap + gslot] = key;
+  }
+}
+
 // feature id of column n of this launch
 __device__ __forceinline__ int gemm_feature(const GemmEpilogue &ep, int n) {
   if (ep.skip_stride) {
@@ -593,10 +609,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
               if (u > row_c[row]) {
                 const int t = m0 + row;
                 const int feat = gemm_feature(ep, n0 + col);
-                const int gslot = atomicAdd(ep.cnt + t, 1);
-                if (gslot < ep.cap)
-                  ep.cand[(size_t)t * ep.cap + gslot] =
-                      ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+                gemm_push_candidate(ep, t, ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat));
               }
             }
             ++slot;
@@ -638,10 +651,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
       if (!(u > row_c[row])) continue;
       const int t = m0 + row;
       const int feat = gemm_feature(ep, n0 + col);
-      const int gslot = atomicAdd(ep.cnt + t, 1);
-      if (gslot < ep.cap)
-        ep.cand[(size_t)t * ep.cap + gslot] =
-            ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat);
+      gemm_push_candidate(ep, t, ((unsigned long long)f32_order_key(u) << 32) | (unsigned)(0x7FFFFFFF - feat));
     }
   }
   MSAE_TL(5);

@@ -268,9 +268,9 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     }
     if (total == 0) return;
     int base = 0;
-    if (lane == 0) base = atomicAdd(push.cnt + t, total);
+    if (lane == 0) base = atomicAdd(push.cnt + (size_t)t * push.cnt_stride, total);
     base = __builtin_amdgcn_readfirstlane(base);
-    unsigned long long *list = push.cand + (size_t)t * push.cap;
+    unsigned long long *list = push.cand + (size_t)t * (push.row_stride ? push.row_stride : push.cap);
     unsigned lo2 = lo;
     asm volatile("" : "+v"(lo2));                      // the masks are recomputed here, not kept (64 SGPR pairs would spill into VGPRs)
 #pragma unroll
