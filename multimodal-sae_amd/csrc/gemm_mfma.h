@@ -137,9 +137,7 @@ struct GemmCfg {
   static constexpr int SIDE_SLOTS = 6;
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 2304;
-  static constexpr int PF_SINK_BYTES = 256;      // where the L2-warming loads of the k-loop land (never read)
-  static constexpr int GRP_BYTES = 256;          // (spare)
-  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8 + PF_SINK_BYTES + GRP_BYTES;
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static constexpr int PIECES = STAGE_BYTES / 1024, PPW = PIECES / NWAVES;  // 1-KiB pieces per wave
@@ -191,32 +189,6 @@ __device__ __forceinline__ void gemm_stage_pieces(const unsigned char *__restric
                  :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
   }
 }
-// Hybrid staging (tuning builds, -DMSAE_GEMM_HYBRID): the LDS-DMA instruction delivers 43.5 GB/s per CU, the same pieces
-// through VGPRs 58 (tools/dma_depth.hip) -- but 8 waves x 128 accumulators leave room for 16 staging registers at
-// most.  So a wave moves its four A pieces by LDS-DMA and its four B pieces through registers: global_load_dwordx4
-// when the k-tile is staged, ds_write_b128 into the slot right before the barrier that publishes it.
-struct GemmBRegs { i32x4 r[4]; };
-template <class C>
-__device__ __forceinline__ void gemm_fetch_b(GemmBRegs &br, const unsigned char *__restrict__ B, size_t ld, int n0,
-                                             size_t kbyte, int wave, const GemmStageLane &sl) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pl = wave * 4 + i;
-    const unsigned voff = sl.off ^ ((unsigned)(pl & 1) << 6);
-    const unsigned char *sbase = B + (size_t)(n0 + pl * 8) * ld + kbyte;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(br.r[i]) : "v"(voff), "s"(sbase) : "memory");
-  }
-}
-template <class C>
-__device__ __forceinline__ void gemm_put_b(GemmBRegs &br, unsigned char *lds, int slot, int wave, int lane) {
-  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-      lds + slot * C::STAGE_BYTES + C::A_BYTES + wave * 4096 + lane * 16);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(br.r[0]), "+v"(br.r[1]), "+v"(br.r[2]), "+v"(br.r[3]) :: "memory");
-  asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\t"
-               "ds_write_b128 %0, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-               :: "v"(dst), "v"(br.r[0]), "v"(br.r[1]), "v"(br.r[2]), "v"(br.r[3]) : "memory");
-}
-
 // tile-major operands: tileA / tileB = the 32-KB block of this k-tile of the A / B row tile (wave-uniform)
 template <class C>
 __device__ __forceinline__ void gemm_stage_packed(const unsigned char *__restrict__ tileA,
@@ -242,19 +214,6 @@ __device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A,
                                            int n0, size_t kbyte, unsigned char *lds, int slot, int wave,
                                            const GemmStageLane &sl) {
   gemm_stage_pieces<C, C::PPW>(A, B, ld, m0, n0, kbyte, lds, slot, wave * C::PPW, sl);
-}
-
-// L2 warming (tuning builds, -DMSAE_GEMM_WARM; measured 4.41 ms against 4.22 without: NOT the default -- the
-// k-loop is not waiting on L2 misses).  The 32 workgroups of an XCD walk an 8 x 4 super-tile in step, so every operand line of a k-tile
-// is requested by 4 (A) or 8 (B) CUs at almost the same time -- and ALL of them wait for the one miss.  Each CU
-// therefore touches its 1/4 of the A tile's lines and 1/8 of the B tile's lines two k-tiles ahead (96 lines:
-// waves 0-3 sixteen A rows each, waves 4-7 eight B rows each), with one 4-byte LDS-DMA load per wave into a
-// sink nobody reads: no VGPR, nothing to wait for -- the k-loop's vmcnt leaves this youngest load outstanding.
-__device__ __forceinline__ void gemm_warm_l2(const unsigned char *sbase, unsigned voff, unsigned sink) {
-#ifdef MSAE_GEMM_WARM
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
-               :: "v"(voff), "s"(sbase), "s"(sink) : "memory", "m0");
-#endif
 }
 
 __device__ __forceinline__ i32x4 gemm_frag(const unsigned char *tile, int row, int chunk) {
@@ -355,7 +314,7 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   lgkm_wait_tied<6, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
   gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
-  if constexpr (AT == 1 || AT == 0) mid(1);       // (AT == 0 with MSAE_GEMM_STAGGER_SPLIT: second half of the pieces)
+  if constexpr (AT == 1) mid(1);
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
   if constexpr (AT == 2) mid(2);
@@ -668,9 +627,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // hidden behind the epilogue.
   int seq = 0;                                   // flat k-tile counter; ring slot = seq & 1
   [[maybe_unused]] int tl_tile = -1;
-#ifdef MSAE_GEMM_PRIO     // tuning: static priority for the second-dispatched half (guide: "two waves per SIMD", item 4)
-  if ((threadIdx.x >> 6) >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(MSAE_GEMM_PRIO);
-#endif
   for (int tile_id = blockIdx.x; tile_id < nM * nN; tile_id += gridDim.x) {
   ++tl_tile;
   MSAE_TL(0);
@@ -752,23 +708,12 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   const int lead = has_out ? 1 : 0;
   const int ntiles = op.nk + lead;
   const GemmStageLane sl_main = gemm_stage_lane(lane, (unsigned)op.ldA);   // ldA == ldB (launcher)
-#ifdef MSAE_GEMM_HYBRID
-  GemmBRegs bregs;
-#endif
   const GemmStageLane sl_lead = gemm_stage_lane(lane, 128u);
-#ifndef MSAE_GEMM_FULL_LEAD
   const bool lead_compact = lead_ks <= 1;                  // wave-uniform (device-side count of outlier dims)
-#else
-  const bool lead_compact = false;
-#endif
   // ONE row of output tiles (T <= BM): all workgroups read the SAME A tile, and walking its k-tiles in step they ask
   // the same few L2 lines at the same moment.  Integer accumulation does not depend on the order, so each workgroup
   // starts its k-walk at its own k-tile (the 32 workgroups of an XCD at 32 different ones) and wraps around.
-#ifndef MSAE_GEMM_NO_KROT
   const int krot = (C::I8 && nM == 1) ? (int)(gridDim.x >= 64 ? blockIdx.x >> 3 : blockIdx.x) % op.nk : 0;   // (few tiles: the sample pass)
-#else
-  const int krot = 0;
-#endif
   auto stage = [&](int tm0, int tn0, int tile, int slot) {
     if (tile < lead) {
       if constexpr (C::I8) {
@@ -776,10 +721,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       }
       gemm_stage<C>(op.Ao, op.Bo, 128, tm0, tn0, 0, smem, slot, wave, sl_lead);
     } else {
-#ifdef MSAE_GEMM_HYBRID
-      gemm_stage_pieces<C, 4>(op.A, op.B, op.ldA, tm0, tn0, (size_t)(tile - lead) * C::ROWB, smem, slot, wave * 4, sl_main);
-      gemm_fetch_b<C>(bregs, op.B, op.ldB, tn0, (size_t)(tile - lead) * C::ROWB, wave, sl_main);
-#else
       int kq = tile - lead + krot;                         // (a select, no control flow: see gemm_stage_pieces)
       kq -= kq >= op.nk ? op.nk : 0;
       if (op.packed)                                       // wave-uniform
@@ -787,89 +728,30 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
                              op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES, smem, slot, wave, lane);
       else
         gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)kq * C::ROWB, smem, slot, wave, sl_main);
-#endif
     }
   };
-  // L2 warming two k-tiles ahead (gemm_warm_l2): this wave's rows of the shared operand tiles
-  const bool pf_a = wave < 4;
-  const int pf_wi = (m0 / C::BM) & 7, pf_wj = (n0 / C::BN) & 3;         // position inside the XCD's 8 x 4 super-tile
-  const int pf_row = pf_a ? pf_wj * 64 + wave * 16 : pf_wi * 32 + (wave - 4) * 8;   // first row inside the tile
-  const unsigned pf_voff = (unsigned)(lane & (pf_a ? 15 : 7)) * (unsigned)op.ldA;
-#ifdef MSAE_GEMM_WARM   // (the pointer is made opaque first: the cast of a KNOWN LDS global folds into an instruction the backend
-  unsigned char *sink_p = smem + C::LDS_BYTES - C::PF_SINK_BYTES;        // rejects, "V_CMP_NE_U32 0, src_shared_base")
-  asm volatile("" : "+s"(sink_p));
-  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)sink_p;
-#else
-  const unsigned pf_sink = 0;
-#endif
-  auto warm = [&](int tm0, int tn0, int kmain) {         // main k-tile index (>= 0) of the tile at (tm0, tn0)
-    const unsigned char *base = pf_a ? op.A + (size_t)(tm0 + pf_row) * op.ldA : op.B + (size_t)(tn0 + pf_row) * op.ldB;
-    gemm_warm_l2(base + (size_t)kmain * C::ROWB, pf_voff, pf_sink);
-  };
-  // Tuning option (-DMSAE_GEMM_PRESTAGE; measured 4.22 ms against 4.17-4.18 without, NOT the default): with an outlier
-  // tile in front, stage the tile's first MAIN k-tile one step early -- in the predecessor's epilogue (the prologue
-  // for the workgroup's first tile) -- because the outlier iteration (one k-step of MFMAs) cannot hide a DMA issued
-  // inside it.  The wait it removes is cheaper than the DMA issue it moves into the VALU-bound epilogue.
-#ifdef MSAE_GEMM_PRESTAGE
-  constexpr bool PRESTAGE = true;
-#else
-  constexpr bool PRESTAGE = false;
-#endif
   if (tile_id == (int)blockIdx.x) {   // later tiles: staged by their predecessor
     stage(m0, n0, 0, 0);
-    if (PRESTAGE && lead) stage(m0, n0, 1, 1);
-    warm(m0, n0, 1 < op.nk ? 1 : 0);  // keeps "the youngest load is a warming load" true from the first wait on
   }
 
   int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
   auto iteration = [&](int kt, bool park_m = false) {
     MSAE_TLK(kt == 8, 0);
     MSAE_TLK(kt == 9, 5);
-#ifndef MSAE_GEMM_WARM
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
-#else
-    wait_vmcnt<1>();               // ... all but the youngest load: the L2-warming one issued behind them
-#endif
     if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
       if (tid_ < C::BM) side_m[tid_] = side2;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#ifdef MSAE_GEMM_HYBRID
-    if (kt >= lead) gemm_put_b<C>(bregs, smem, seq & 1, wave, lane);   // this k-tile's B pieces: registers -> its slot
-#endif
     MSAE_TLK(kt == 8, 1);
     __builtin_amdgcn_s_barrier();  // ... and everybody's; the other slot is free again
     MSAE_TLK(kt == 8, 2);
     if (kt == 0) MSAE_TL(1);
     if (kt == 1) MSAE_TL(2);
     auto stage_next = [&]() {
-      if (kt + 1 < ntiles) { if (!(PRESTAGE && lead && kt == 0)) stage(m0, n0, kt + 1, (seq + 1) & 1); }
+      if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     };
-#ifdef MSAE_GEMM_STAGGER_SPLIT
-    auto stage_half = [&](int half) {           // tile-major main k-tiles only; everything else goes whole, at the second call
-      const bool nxt_tile = !(kt + 1 < ntiles);
-      const int t2 = nxt_tile ? 0 : kt + 1;
-      const int tm0 = nxt_tile ? m0n : m0, tn0 = nxt_tile ? n0n : n0;
-      if (nxt_tile && !has_next) return;
-      if (t2 < lead || !op.packed) { if (half == 1) stage_next(); return; }
-      int kq = t2 - lead + krot;
-      kq -= kq >= op.nk ? op.nk : 0;
-      const unsigned char *tileA = op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES;
-      const unsigned char *tileB = op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES;
-      unsigned char *base = smem + ((seq + 1) & 1) * C::STAGE_BYTES;
-      const unsigned voff = (unsigned)lane << 4;
-#pragma unroll
-      for (int i = 0; i < C::PPW / 2; ++i) {
-        const int piece = wave * C::PPW + half * (C::PPW / 2) + i;
-        const bool isA = piece < C::A_PIECES;
-        const unsigned char *sbase = isA ? tileA + piece * 1024 : tileB + (piece - C::A_PIECES) * 1024;
-        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(base + piece * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
-      }
-    };
-#endif
 #ifndef MSAE_GEMM_STAGGER
 #define MSAE_GEMM_STAGGER 1   // round 3: on by default (-4 % on the main pass together with tile-major operands, two boxes:
 #endif                        // profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt); 0 = off, 2 = odd waves
@@ -885,12 +767,6 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 #endif
     if constexpr (!C::ABL_NOSTAGE) {
       if (!late) stage_next();
-      {   // one warming load per wave and iteration, always (the wait above counts on it)
-        const int k2 = kt + 2 - lead;                    // main k-tile two ahead: this tile's, else the next tile's
-        const bool cur = k2 < op.nk, nxt = !cur && has_next;      // (selects, no control flow: see gemm_stage_pieces)
-        const int kn = k2 - op.nk < op.nk ? k2 - op.nk : 0;
-        warm(nxt ? m0n : m0, nxt ? n0n : n0, cur ? k2 : (nxt ? kn : op.nk - 1));
-      }
     }
     MSAE_TLK(kt == 8, 3);
     const unsigned char *sA = smem + (seq & 1) * C::STAGE_BYTES;
@@ -900,11 +776,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     }
     else if constexpr (!C::ABL_NOREAD && !C::ABL_NOMFMA && !C::ABL_NOSTAGE)
       gemm_compute_asm<C>(acc, sA, wr, wc, l31, kh, [&](int pos) {
-#ifdef MSAE_GEMM_STAGGER_SPLIT    // tuning: late waves issue half their pieces behind k-step 0, half behind k-step 1
-        if (late) stage_half(pos == 0 ? 0 : 1);
-#else
         if (late && pos == MSAE_GEMM_STAGGER_AT) stage_next();
-#endif
       });
     else gemm_compute<C>(acc, sA, sA + C::A_BYTES, wr, wc, l31, kh, abl_a, abl_b);
     MSAE_TLK(kt == 8, 4);
@@ -968,7 +840,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // behind the epilogue's first barrier every wave is done with the last k-tile's slot: the next tile's first main
   // k-tile lands there while the epilogue runs (its outlier tile is already in the other slot)
   gemm_epilogue<C, DENSE>(acc, ep, T, m0, n0, wr, wc, lane, smem, side,
-                          [&] { if (PRESTAGE && lead && has_next) stage(m0n, n0n, 1, (seq + 1) & 1); }, tl_tile);
+                          [] {}, tl_tile);
   MSAE_TL(6);
   }
 }
