@@ -560,10 +560,13 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
   __syncthreads();
   const int n = blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads per row, 16 bytes each (N % 32 == 0)
   const int j0 = (threadIdx.x & 7) * 16;
+  // the tile is compact from column 0 and its readers stop after the k-steps that hold dims (32-B steps in gemm_mfma.h,
+  // 64-B steps in gemm_skinny.h): columns from ceil(n_out / 64) * 64 on are neither gathered nor written
+  const bool used = j0 < ((odims[MAX_OUT] + 63) & ~63);
   i32x4 packed = {0, 0, 0, 0};
   int sq = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 4 && used; ++q) {
     unsigned w = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -579,9 +582,11 @@ __global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__res
   sq += __shfl_xor(sq, 4, 64);
   const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
   // skip: the main pass runs over the non-sample rows only (main_row); its outlier operand and column constants in that order
-  if (!skip) *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
-  else if (!samp) *reinterpret_cast<i32x4 *>(wqo + (size_t)main_row(n) * MAX_OUT + j0) = packed;
-  if (samp) *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
+  if (used) {
+    if (!skip) *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
+    else if (!samp) *reinterpret_cast<i32x4 *>(wqo + (size_t)main_row(n) * MAX_OUT + j0) = packed;
+    if (samp) *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
+  }
   if ((threadIdx.x & 7) == 0) {
     const f32x4 st = wstat[n];
     const float so = st[0] * st[0] * (float)sq;
