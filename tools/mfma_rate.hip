@@ -13,7 +13,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int FMT>   // -1: int8 32x32x32;  0 fp8 (e4m3), 2 fp6 (e2m3), 4 fp4 (e2m1) through v_mfma_scale_f32_32x32x64_f8f6f4
-__global__ __launch_bounds__(512) void rate_kernel(const int *__restrict__ src, float *__restrict__ out, int iters) {
+__global__ __launch_bounds__(512) void rate_kernel(const int *__restrict__ src, float *__restrict__ out, int iters, int rot) {
   const int tid = blockIdx.x * 512 + threadIdx.x;
   i32x8 a, b;
 #pragma unroll
@@ -22,10 +22,18 @@ __global__ __launch_bounds__(512) void rate_kernel(const int *__restrict__ src, 
     i32x16 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = i32x16{};
-    const i32x4 a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[0], b[1], b[2], b[3]};
+    // MFMA_RATE_VARY (rot != 0): consecutive MFMAs read DIFFERENT operand registers (4 sets), as a GEMM's do; otherwise all of
+    // them read the same two registers and only the accumulators toggle
+    i32x4 a4[4], b4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = rot ? q : 0;
+      a4[q] = i32x4{a[o & 7], a[(o + 1) & 7], a[(o + 2) & 7], a[(o + 3) & 7]};
+      b4[q] = i32x4{b[(o + 4) & 7], b[(o + 5) & 7], b[(o + 6) & 7], b[(o + 7) & 7]};
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a4, b4, acc[j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a4[j & 3], b4[j & 3], acc[j], 0, 0, 0);
     }
     int s = 0;
 #pragma unroll
@@ -35,10 +43,17 @@ __global__ __launch_bounds__(512) void rate_kernel(const int *__restrict__ src, 
     f32x16 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x16{};
+    i32x8 av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = rot ? 2 * q : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { av[q][e] = a[(e + o) & 7]; bv[q][e] = b[(e + o + 1) & 7]; }
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[j], FMT, FMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[j & 3], bv[j & 3], acc[j], FMT, FMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
     }
     float s = 0.f;
 #pragma unroll
@@ -55,7 +70,7 @@ void run(const char *name, const int *src, float *out, double ops_per_mfma) {
   const int reps = getenv("MFMA_RATE_REPS") ? atoi(getenv("MFMA_RATE_REPS")) : 4;   // many: long enough for the SMU's power average
   for (int rep = 0; rep < reps; ++rep) {
     CK(hipEventRecord(e0, 0));
-    rate_kernel<FMT><<<grid, 512>>>(src, out, iters);
+    rate_kernel<FMT><<<grid, 512>>>(src, out, iters, getenv("MFMA_RATE_VARY") ? 1 : 0);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
   }
@@ -65,11 +80,21 @@ void run(const char *name, const int *src, float *out, double ops_per_mfma) {
 
 int main() {
   int *src; CK(hipMalloc(&src, 65536 * 4));
-  { int *h = (int *)malloc(65536 * 4); unsigned z = 12345u; for (int i = 0; i < 65536; ++i) { z = z * 1664525u + 1013904223u; h[i] = (int)(z & 0x3F3F3F3Fu); }   // small magnitudes: finite in every format
+  // small magnitudes: finite in every format.  MFMA_RATE_SIGNED=i8: random signs in two's complement (what the int8 pass sees);
+  // MFMA_RATE_SIGNED=fp: random sign BITS (sign-magnitude: what an fp8 / fp6 / fp4 pass would see)
+  const char *sg = getenv("MFMA_RATE_SIGNED");
+  { unsigned char *h = (unsigned char *)malloc(65536 * 4); unsigned z = 12345u;
+    for (int i = 0; i < 65536 * 4; ++i) {
+      z = z * 1664525u + 1013904223u;
+      const unsigned m = (z >> 8) & 0x3Fu, sign = (z >> 20) & 1u;
+      h[i] = !sg ? (unsigned char)m : (sg[0] == 'i' ? (unsigned char)(sign ? (unsigned char)(0u - m) : m) : (unsigned char)(sign << 7 | m));
+    }
     CK(hipMemcpy(src, h, 65536 * 4, hipMemcpyHostToDevice)); free(h); }
+  if (sg) printf("operands: random signs, %s\n", sg[0] == 'i' ? "two's complement" : "sign bit");
   float *out; CK(hipMalloc(&out, 256 * 512 * 4));
   run<-1>("int8 32x32x32", src, out, 2.0 * 32 * 32 * 32);
   if (getenv("MFMA_RATE_ONLY_I8")) return 0;
+  if (getenv("MFMA_RATE_ONLY_FP8")) { run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64); return 0; }
   run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64);
   run<2>("f8f6f4 32x32x64, fp6 e2m3", src, out, 2.0 * 32 * 32 * 64);
   run<4>("f8f6f4 32x32x64, fp4 e2m1", src, out, 2.0 * 32 * 32 * 64);
