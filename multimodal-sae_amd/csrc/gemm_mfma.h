@@ -246,6 +246,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <class C>
 __device__ __forceinline__ void gemm_mfma_step(f32x16 (&acc)[C::MI][C::NI], const i32x4 (&a)[C::MI],
                                                const i32x4 (&b)[C::NI]) {
+  // (issue order: i outer -- consecutive MFMAs share the A fragment; j outer, four in a row on one B fragment, measured the same:
+  // 3.84-3.86 vs 3.82-3.87 ms, NOTEBOOK.md)
 #pragma unroll
   for (int i = 0; i < C::MI; ++i)
 #pragma unroll
