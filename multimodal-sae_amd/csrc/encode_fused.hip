@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
 // per-token quantisation with the outliers in their own 128-wide k-tile at scale m[t]*sx[t].
 // int8 pass: prep_x and colmax in one sweep -- a thread owns four columns (b_dec in registers) and walks its
 // rows: a32 = x - b_dec is written once and never read back for the maxima.
+constexpr int COLMAX_PARTS = 8;   // copies of the column maxima (see prep_colmax_kernel)
 template <int DT, bool WRITE_A32>
 __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
                                                           int T, int d, float *__restrict__ a32,
@@ -381,18 +382,27 @@ __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict
     m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
     m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
   }
+  // (blockIdx.y % COLMAX_PARTS: one copy of the maxima for all row chunks means T / 16 atomics on every column's word -- hundreds of
+  // same-address atomics, ~45 ns each: 20 us of this 60 us kernel at T = 8192; pick_outliers_kernel folds the copies)
+  unsigned *cm = colmax_bits + (size_t)(blockIdx.y % COLMAX_PARTS) * d;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) atomicMax(colmax_bits + c + e, __float_as_uint(m[e]));  // values >= 0
+  for (int e = 0; e < 4; ++e) atomicMax(cm + c + e, __float_as_uint(m[e]));  // values >= 0
 }
 
 constexpr int MAX_OUT = 128;   // outlier dims fit one int8 k-tile
 // single workgroup: dims whose column max exceeds 8x the mean column max (threshold raised until
 // at most MAX_OUT qualify).  odims[0..MAX_OUT) = dim or -1, is_out[d] byte flags.
-__global__ __launch_bounds__(1024) void pick_outliers_kernel(const unsigned *__restrict__ colmax_bits, int d,
+__global__ __launch_bounds__(1024) void pick_outliers_kernel(unsigned *__restrict__ colmax_bits, int d,
                                                              int *__restrict__ odims,
                                                              unsigned char *__restrict__ is_out) {
   __shared__ float red[16];
   __shared__ int s_cnt;
+  for (int c = threadIdx.x; c < d; c += 1024) {          // fold the COLMAX_PARTS copies into the first (same thread reads it below)
+    unsigned m = colmax_bits[c];
+#pragma unroll
+    for (int q = 1; q < COLMAX_PARTS; ++q) { const unsigned v = colmax_bits[(size_t)q * d + c]; m = v > m ? v : m; }
+    colmax_bits[c] = m;
+  }
   float sum = 0.f;
   for (int c = threadIdx.x; c < d; c += 1024) sum += __uint_as_float(colmax_bits[c]);
 #pragma unroll
@@ -1335,7 +1345,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_colc = take((size_t)N * 16);
       p.off_colc_s = take((size_t)p.S * 16);
       p.off_colc_p = take((size_t)N * 16);
-      p.off_colmax = take((size_t)d * 4);
+      p.off_colmax = take((size_t)d * 4 * COLMAX_PARTS);
       p.off_odims = take((size_t)(MAX_OUT + 1) * 4);
       p.off_isout = take((size_t)d);
       p.off_wqo = take((size_t)N * MAX_OUT);
@@ -1970,7 +1980,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const int seg_cap = pl.cap / pl.segs;
   const size_t n_cnt = pl.segs > 1 ? (pl.off_segcnt - pl.off_cnt) / 4 + (size_t)T * pl.segs : (size_t)T;
   hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, n_cnt, flagged, (size_t)T + 64 + pl.fb_chunks,
-                     pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d : (size_t)0);
+                     pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d * COLMAX_PARTS : (size_t)0);
   if (!pl.i8)
     hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
