@@ -246,8 +246,24 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     key[4 * i + 2] = f32_order_key(v[2]); key[4 * i + 3] = f32_order_key(v[3]);
   }
   unsigned lo = 0u;               // invariant: count(key >= lo) >= r
+  int first_bit = 31;
+  {  // The values of a row share their sign and most of their exponent: if r of them reach the row maximum's top 8 bits, those 8
+     // bits ARE the answer's (no larger prefix has any value at all) and the bisection starts below them -- 12 steps instead of 18.
+    unsigned mx = 0u;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) mx = key[i] > mx ? key[i] : mx;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+    const unsigned pre = mx & 0xFF000000u;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) c += (key[i] >= pre) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (c >= r) { lo = pre; first_bit = 23; }
+  }
 #pragma unroll 1
-  for (int bit = 31; bit >= KTH_LOW_BIT; --bit) {
+  for (int bit = first_bit; bit >= KTH_LOW_BIT; --bit) {
     const unsigned mid = lo | (1u << bit);
     int c = 0;
 #pragma unroll
