@@ -467,14 +467,29 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     }
   };
   float m_in = 0.f, m_out = 0.f, ss = 0.f;
-  for (int c = threadIdx.x * 4; c < d; c += 1024) {
-    const f32x4 v = load4(c);
-    const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c);
+  // a thread owns 16 consecutive dims of every 4096 (the 16 int8 it packs below); up to d = 8192 the row stays in registers
+  // between the two passes
+  constexpr int KEEP = 2;
+  f32x4 keep[KEEP][4];
+  unsigned keep_f[KEEP][4];
+  const bool resident = d <= KEEP * 4096;
+  {
+    int it = 0;
+    for (int c = threadIdx.x * 16; c < d; c += 4096, ++it) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float av = fabsf(v[e]);
-      ss = __builtin_fmaf(av, av, ss);
-      if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else m_in = fmaxf(m_in, av);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = load4(c + 4 * q);
+        const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q);
+        if (resident && it < KEEP) {
+          if (it == 0) { keep[0][q] = v; keep_f[0][q] = flags; } else { keep[1][q] = v; keep_f[1][q] = flags; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = fabsf(v[e]);
+          ss = __builtin_fmaf(av, av, ss);
+          if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else m_in = fmaxf(m_in, av);
+        }
+      }
     }
   }
 #pragma unroll
@@ -493,12 +508,15 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
   const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
   float e0 = 0.f;                              // energy of the non-outlier dims that round to zero (GUARD_E0_BANDS)
-  for (int c = threadIdx.x * 16; c < d; c += 4096) {
+  int it2 = 0;
+  for (int c = threadIdx.x * 16; c < d; c += 4096, ++it2) {
     i32x4 packed;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 v = load4(c + 4 * q);
-      const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q);
+      f32x4 v;
+      unsigned flags;
+      if (resident) { v = it2 == 0 ? keep[0][q] : keep[1][q]; flags = it2 == 0 ? keep_f[0][q] : keep_f[1][q]; }
+      else { v = load4(c + 4 * q); flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q); }
       unsigned w = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
