@@ -117,6 +117,11 @@ int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void 
  * encoding in the other mode. */
 int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const msae_options *opts,
                          void *stream);
+/* The same for ONE following encode of T_next tokens (the training loop, train/sae/sae/trainer.py:347-401: the weights change
+ * before the buffer is read again): a batch of more than 128 tokens does not read the copies the small-batch kernels use,
+ * and they are left stale.  Refresh again (or msae_encoder_prepare) before encoding a different number of tokens. */
+int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, int T_next, const msae_options *opts,
+                             void *stream);
 
 /* Fused Sae.encode: vals/idx[T][k] = canonical top-k of relu((x - b_dec) W_enc^T + b_enc), with
  * the reference hooks' edits of the dense latents applied before TopK:

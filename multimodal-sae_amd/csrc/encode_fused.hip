@@ -347,12 +347,14 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
       } else {
         *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
       }
-      if (MAIN_SKIPS_SAMPLE) { if (!samp) *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)main_row(n), c, d)) = packed; }
-      else *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)n, c, d)) = packed;
+      if (wqf) {                                   // (null: msae_encoder_refresh_for a large batch)
+        if (MAIN_SKIPS_SAMPLE) { if (!samp) *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)main_row(n), c, d)) = packed; }
+        else *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)n, c, d)) = packed;
+      }
       if (samp) {
         *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
         *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
-        *reinterpret_cast<i32x4 *>(wqsf + frag_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
+        if (wqsf) *reinterpret_cast<i32x4 *>(wqsf + frag_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
       }
     }
   }
@@ -2259,7 +2261,8 @@ extern "C" size_t msae_encoder_prepared_bytes(int N, int d) {
 }
 
 namespace {
-// modes: bit 0 = bf16 operands, bit 1 = int8 operands
+// modes: bit 0 = bf16 operands, bit 1 = int8 operands, bit 2 = without the fragment-major copies (the weight-stream kernels of
+// batches of <= 128 tokens read them; the caller refreshes for a large batch)
 int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hipStream_t s) {
   if (N <= 0 || d <= 0 || !prepared) return MSAE_EINVAL;
   if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
@@ -2278,8 +2281,9 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
                          colbf_s, reinterpret_cast<signed char *>(base + p.off_wq),
                          reinterpret_cast<signed char *>(base + p.off_wqs), reinterpret_cast<signed char *>(base + p.off_wqp),
-                         reinterpret_cast<signed char *>(base + p.off_wqsp), reinterpret_cast<signed char *>(base + p.off_wqf),
-                         reinterpret_cast<signed char *>(base + p.off_wqsf), gemm_layout() == 2 ? 2 : 1);
+                         reinterpret_cast<signed char *>(base + p.off_wqsp),
+                         (modes & 4) ? (signed char *)nullptr : reinterpret_cast<signed char *>(base + p.off_wqf),
+                         (modes & 4) ? (signed char *)nullptr : reinterpret_cast<signed char *>(base + p.off_wqsf), gemm_layout() == 2 ? 2 : 1);
     else
       hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
                          colbf_s, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr,
@@ -2300,6 +2304,16 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
+}
+
+// ... for an encode of T_next tokens that follows: a batch of more than 128 tokens does not read the fragment-major copies (0.5 GB
+// of scattered 16-byte stores per refresh at C2).  The buffer must be refreshed again before an encode of fewer tokens.
+extern "C" int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, int T_next, const msae_options *opts,
+                                        void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co) || T_next <= 0) return MSAE_EINVAL;
+  const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
+  return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 128 ? 4 : 0), (hipStream_t)stream);
 }
 
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts) {

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "msae_encoder_prepared_bytes": (c_size_t, [c_int, c_int]),
     "msae_encoder_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "msae_encoder_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
+    "msae_encoder_refresh_for": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_opts_p, c_void_p]),
     "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_opts_p]),
     "msae_encode_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,

@@ -327,10 +327,12 @@ def set_status_detail(on: bool) -> None:
     _defaults.status_detail = bool(on)
 
 
-def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_only: bool = False) -> Tensor:
+def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_only: bool = False,
+                    tokens_next: int = 0) -> Tensor:
     """Coarse-pass operands of the encoder weights for the fused path (bf16 copy, int8 quantisation,
     sampled rows).  Once per weight load; `out` + `active_mode_only` is the per-step refresh of a
-    training loop (rebuilds only what the coarse mode in force reads, into the same buffer)."""
+    training loop (rebuilds only what the coarse mode in force reads, into the same buffer; `tokens_next` > 0: only what
+    ONE following encode of that many tokens reads -- msae_encoder_refresh_for)."""
     dev = _hip.require_device(W_enc)
     lib = _hip.load()
     W = _f32c(W_enc)
@@ -339,7 +341,10 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
     if out is None or out.numel() != nbytes or out.device != dev:
         out, active_mode_only = torch.empty(nbytes, dtype=torch.uint8, device=dev), False
     with torch.cuda.device(dev):
-        if active_mode_only:
+        if active_mode_only and tokens_next > 0:
+            _hip.check(lib.msae_encoder_refresh_for(_hip.ptr(W), N, d, _hip.ptr(out), int(tokens_next), _opts().ref(),
+                                                    _hip.stream_of(W)), "msae_encoder_refresh_for")
+        elif active_mode_only:
             _hip.check(lib.msae_encoder_refresh(_hip.ptr(W), N, d, _hip.ptr(out), _opts().ref(), _hip.stream_of(W)),
                        "msae_encoder_refresh")
         else:
@@ -351,11 +356,12 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
 _TRAIN_PREPARED: dict = {}
 
 
-def _refresh_train_operands(W_enc: Tensor) -> Tensor:
+def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
     """Per-step operands of a weight that changes every step: one buffer per parameter, rebuilt in
-    place for the coarse mode in force (the encode that follows runs in that same mode)."""
+    place for the coarse mode in force and for the batch size of the ONE encode that follows (it runs in that mode on
+    `tokens` tokens; the buffer is rebuilt before it is read again)."""
     key = (W_enc.device, W_enc.data_ptr(), tuple(W_enc.shape))
-    buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True)
+    buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True, tokens_next=tokens)
     if len(_TRAIN_PREPARED) > 8 and key not in _TRAIN_PREPARED:
         _TRAIN_PREPARED.clear()
     _TRAIN_PREPARED[key] = buf
@@ -610,7 +616,7 @@ class _SparseEncode(torch.autograd.Function):
             # of a weight that does not change between calls (inference hooks); None = training step
             kk = max(k, k_multi)
             v, i, _ = encode_topk(x, W_enc, b_enc, b_dec,
-                                  prepared if prepared is not None else _refresh_train_operands(W_enc), kk,
+                                  prepared if prepared is not None else _refresh_train_operands(W_enc, x.shape[0]), kk,
                                   set_feature, set_value, zero_feature)
             vals.append(v[..., :k].contiguous()); idxs.append(i[..., :k].contiguous())
             if k_multi > 0:
