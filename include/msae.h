@@ -147,6 +147,20 @@ int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_enc, const f
                          int set_feature, float set_value, int zero_feature, float *vals, int64_t *idx,
                          int32_t *status, void *ws, size_t ws_bytes, const msae_options *opts, void *stream);
 
+/* Exact Sae.encode of a DEVICE-SIDE LIST of tokens: for i < min(*n_rows, max_rows), t = rows[i]:
+ * vals[t][k] / idx[t][k] (/ status[t] = 1, optional) = the canonical top-k of token t by msae_pre_acts_f32 +
+ * msae_topk_f32 -- what msae_encode_topk returns for t, bit for bit; rows of unlisted tokens are left untouched.
+ * rows / n_rows are device pointers: the work is sized on the device (ceil(max_rows / capacity) passes over a
+ * <= 1 GiB dense scratch are enqueued, passes without rows exit at once), so a caller can enqueue "redo whatever the
+ * previous kernel flagged" without reading the count back -- the second round of the feature-sharded engine
+ * (msae/parallel.py: shards whose truncated top-k_loc list may have lost a member), inside the same forward hook
+ * (features/cache.py:187-204: no host synchronisation).  No reference counterpart. */
+size_t msae_encode_topk_rows_ws_bytes(int max_rows, int N);
+int msae_encode_topk_rows(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                          const float *b_dec, const int32_t *rows, const int32_t *n_rows, int max_rows,
+                          int d, int N, int k, int set_feature, float set_value, int zero_feature,
+                          float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- feature-sharded group (BASELINE configs[2]: "per-shard TopK + RCCL merge over xGMI") ------
  * The encoder's feature axis is split over G ranks; every rank sees the same T tokens.  Re-scoring a local top-k
  * exactly on every rank would multiply the HBM-bound re-score work by G, so the shards exchange CANDIDATES:
@@ -224,6 +238,13 @@ int msae_sparsify_write(const float *vals, const int32_t *idx, int B, int S, int
  * candidate ranks inside the merged top-k (that shard may hold more members than it sent). */
 int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, int k, float *vals, int32_t *idx,
                     int32_t *flagged, void *stream);
+/* rows[0 .. n) = the t with flags[t] != 0 in ascending order, *n_rows = n (device pointers; one small kernel): the
+ * redo list msae_encode_topk_rows takes, derived identically on every rank from the same gathered data. */
+int msae_compact_flags(const int32_t *flags, int T, int32_t *rows, int32_t *n_rows, void *stream);
+/* msae_merge_topk for the tokens with mask[t] != 0 only, in place: the others' vals / idx rows are left as they are
+ * (second round: the redone tokens' full local lists, kl = k, replace round 1's merge).  idx or idx64 may be NULL. */
+int msae_merge_topk_masked(const int32_t *gathered, int T, int G, int kl, int k, const int32_t *mask,
+                           float *vals, int32_t *idx, int64_t *idx64, void *stream);
 
 /* ---- parameter-sized passes of one optimisation step (training) ----
  * msae_unit_norm_rows_f32: W[r][:] /= ||W[r][:]||_2 + eps, in place

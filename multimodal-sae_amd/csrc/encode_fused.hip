@@ -1406,33 +1406,41 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
 }
 
 
-// exact recompute of the flagged tokens, fb_cap at a time (device-side counts; passes without work exit
-// immediately)
+// exact recompute of a device-side list of tokens, fb_cap at a time (device-side counts; passes without work exit
+// immediately): list[0 .. *n_list) of token rows, pass_counts[fb_chunks] scratch, dense f32[fb_cap][N] scratch
+template <int DT>
+int run_exact_rows(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const int *list,
+                   const int *n_list, int *pass_counts, float *dense, int fb_cap, int fb_chunks, int d, int N, int k,
+                   int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx, int32_t *status,
+                   int detail, hipStream_t s) {
+  if (fb_chunks > 1)
+    hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_list, fb_cap, fb_chunks, pass_counts);
+  for (int c = 0; c < fb_chunks; ++c) {
+    // one pass covers every token (T <= fb_cap): the list's count itself is the pass's row count
+    const int *rows = list + (size_t)c * fb_cap, *n_rows = fb_chunks > 1 ? pass_counts + c : n_list;
+    int rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, rows, n_rows, fb_cap, d, N, 1, dense, N, s);
+    if (rc) return rc;
+    if (set_feature >= 0 || zero_feature >= 0)
+      hipLaunchKernelGGL(edit_dense_kernel, dim3((fb_cap + 255) / 256), dim3(256), 0, s, dense, N, fb_cap, n_rows,
+                         set_feature, set_value, zero_feature);
+    // the exact results go straight to the listed tokens' rows of the outputs (row map = the list)
+    TopkExtra ex;
+    ex.idx64 = idx.i64; ex.row_map = rows; ex.status = status; ex.detail = detail;
+    rc = msae_topk_launch(dense, fb_cap, N, k, N, n_rows, vals, idx.i32, s, ex);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ... of the tokens the fused path flagged
 template <int DT>
 int run_exact_fallback(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, int T, int d, int N,
                        int k, int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx,
                        int32_t *status, unsigned char *ws, const FusedPlan &pl, int detail, hipStream_t s) {
   int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
-  int *n_flagged = flagged + T;
-  int *fb_counts = flagged + T + 64;
-  float *fbdense = reinterpret_cast<float *>(ws + pl.off_fbdense);
-  if (pl.fb_chunks > 1)
-    hipLaunchKernelGGL(fallback_counts_kernel, dim3(1), dim3(64), 0, s, n_flagged, pl.fb_cap, pl.fb_chunks, fb_counts);
-  for (int c = 0; c < pl.fb_chunks; ++c) {
-    // one pass covers every token (T <= fb_cap): the flagged count itself is the pass's row count
-    const int *rows = flagged + (size_t)c * pl.fb_cap, *n_rows = pl.fb_chunks > 1 ? fb_counts + c : n_flagged;
-    int rc = msae_pre_acts_launch(x, DT, W_enc, b_enc, b_dec, rows, n_rows, pl.fb_cap, d, N, 1, fbdense, N, s);
-    if (rc) return rc;
-    if (set_feature >= 0 || zero_feature >= 0)
-      hipLaunchKernelGGL(edit_dense_kernel, dim3((pl.fb_cap + 255) / 256), dim3(256), 0, s, fbdense, N, pl.fb_cap, n_rows,
-                         set_feature, set_value, zero_feature);
-    // the exact results go straight to the flagged tokens' rows of the outputs (row map = the flag list)
-    TopkExtra ex;
-    ex.idx64 = idx.i64; ex.row_map = rows; ex.status = status; ex.detail = detail;
-    rc = msae_topk_launch(fbdense, pl.fb_cap, N, k, N, n_rows, vals, idx.i32, s, ex);
-    if (rc) return rc;
-  }
-  return 0;
+  return run_exact_rows<DT>(x, W_enc, b_enc, b_dec, flagged, flagged + T, flagged + T + 64,
+                            reinterpret_cast<float *>(ws + pl.off_fbdense), pl.fb_cap, pl.fb_chunks, d, N, k, set_feature,
+                            set_value, zero_feature, vals, idx, status, detail, s);
 }
 
 // ---- small-T path kernels ---------------------------------------------------------------------------------
@@ -2393,6 +2401,55 @@ extern "C" int msae_encode_topk_i64(const void *x, int x_dtype, const float *W_e
   if (!idx) return MSAE_EINVAL;
   return encode_topk_impl(x, x_dtype, W_enc, b_enc, b_dec, prepared, T, d, N, k, set_feature, set_value,
                           zero_feature, vals, IdxOut{nullptr, idx}, status, ws, ws_bytes, opts, stream);
+}
+
+// ---- exact encode of a device-side token list (second round of the feature-sharded engine's per-shard top-k scheme) ----
+namespace {
+struct RowsPlan { size_t off_counts, off_dense, bytes; int fb_cap, fb_chunks; };
+inline RowsPlan make_plan_rows(int max_rows, int N) {
+  RowsPlan p{};
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += msae_align_up(b, 256); return at; };
+  p.fb_cap = fallback_capacity(max_rows, N);
+  p.fb_chunks = (max_rows + p.fb_cap - 1) / p.fb_cap;
+  p.off_counts = take(((size_t)64 + p.fb_chunks) * 4);
+  p.off_dense = take((size_t)p.fb_cap * N * 4);
+  p.bytes = o;
+  return p;
+}
+}  // namespace
+
+extern "C" size_t msae_encode_topk_rows_ws_bytes(int max_rows, int N) {
+  if (max_rows <= 0 || N <= 0) return 0;
+  return make_plan_rows(max_rows, N).bytes;
+}
+
+extern "C" int msae_encode_topk_rows(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
+                                     const float *b_dec, const int32_t *rows, const int32_t *n_rows, int max_rows,
+                                     int d, int N, int k, int set_feature, float set_value, int zero_feature,
+                                     float *vals, int64_t *idx, int32_t *status, void *ws, size_t ws_bytes,
+                                     void *stream) {
+  if (max_rows < 0 || d <= 0 || N <= 0 || k <= 0 || k > N || k > 16384 || !rows || !n_rows || !vals || !idx) return MSAE_EINVAL;
+  if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
+  if (set_feature >= N || zero_feature >= N) return MSAE_EINVAL;
+  if (max_rows == 0) return 0;
+  const RowsPlan rp = make_plan_rows(max_rows, N);
+  if (ws_bytes < rp.bytes || !ws) return MSAE_EWS;
+  if (!msae_aligned(ws, 256) || !msae_aligned(W_enc, 16) || !msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) ||
+      (b_dec && !msae_aligned(b_dec, 16)))
+    return MSAE_EALIGN;
+  unsigned char *wsb = static_cast<unsigned char *>(ws);
+  int *counts = reinterpret_cast<int *>(wsb + rp.off_counts) + 64;
+  float *dense = reinterpret_cast<float *>(wsb + rp.off_dense);
+  hipStream_t s = (hipStream_t)stream;
+  const IdxOut io{nullptr, idx};
+  int rc;
+  switch (x_dtype) {
+    case MSAE_F32: rc = run_exact_rows<MSAE_F32>(x, W_enc, b_enc, b_dec, rows, n_rows, counts, dense, rp.fb_cap, rp.fb_chunks, d, N, k, set_feature, set_value, zero_feature, vals, io, status, 0, s); break;
+    case MSAE_BF16: rc = run_exact_rows<MSAE_BF16>(x, W_enc, b_enc, b_dec, rows, n_rows, counts, dense, rp.fb_cap, rp.fb_chunks, d, N, k, set_feature, set_value, zero_feature, vals, io, status, 0, s); break;
+    default: rc = run_exact_rows<MSAE_F16>(x, W_enc, b_enc, b_dec, rows, n_rows, counts, dense, rp.fb_cap, rp.fb_chunks, d, N, k, set_feature, set_value, zero_feature, vals, io, status, 0, s); break;
+  }
+  return rc ? rc : msae_launch_status();
 }
 
 // ---- feature-sharded group: per-shard candidates, owner-side exact re-score ----------------------------

@@ -359,6 +359,74 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t *__restric
   if (lane == 0 && flagged) flagged[t] = (kl < k && worst_last >= mkeys[k - 1]) ? 1 : 0;
 }
 
+// rows[0 .. n) = the t with flags[t] != 0, ascending; *n_rows = n.  ONE workgroup walks the flags 1024 at a time (ballot
+// prefix counts): the device-side redo list of the feature-sharded engine's second round -- every rank derives the same
+// list from the same gathered data, nothing is read back to the host.
+__global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t *__restrict__ flags, int T,
+                                                             int32_t *__restrict__ rows, int32_t *__restrict__ n_rows) {
+  __shared__ int wsum[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += 1024) {
+    const int t = base + tid;
+    const bool f = t < T && flags[t] != 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+    if (lane == 0) wsum[wv] = __builtin_popcountll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wv; ++w) off += wsum[w];
+    if (f) rows[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_rows = s_base;
+}
+
+// merge_topk_kernel for the tokens of a mask only (second round: the redone tokens' full local top-k lists replace the
+// truncated merge; everybody else keeps round 1's result).  One wave per token, same key order.
+__global__ __launch_bounds__(64) void merge_topk_masked_kernel(const int32_t *__restrict__ gathered, int T, int G, int kl,
+                                                               int k, const int32_t *__restrict__ mask,
+                                                               float *__restrict__ vals, int32_t *__restrict__ idx,
+                                                               int64_t *__restrict__ idx64) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];
+  const int lane = threadIdx.x, t = blockIdx.x;
+  if (mask[t] == 0) return;                         // wave-uniform
+  const int M = G * kl, np = next_pow2(M);
+  for (int i = lane; i < np; i += 64) {
+    unsigned long long key = 0ull;
+    if (i < M) {
+      const int g = i / kl, j = i % kl;
+      const float v = __int_as_float(gathered[(((size_t)g * 2 + 0) * T + t) * kl + j]);
+      key = rank_key(v, gathered[(((size_t)g * 2 + 1) * T + t) * kl + j]);
+    }
+    mkeys[i] = key;
+  }
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = lane; i < (np >> 1); i += 64) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = mkeys[lo], y = mkeys[hi];
+        if ((x < y) == desc) { mkeys[lo] = y; mkeys[hi] = x; }
+      }
+    }
+  __syncthreads();
+  for (int j = lane; j < k; j += 64) {
+    const unsigned long long key = mkeys[j];
+    if (idx) idx[(size_t)t * k + j] = rank_key_index(key);
+    if (idx64) idx64[(size_t)t * k + j] = rank_key_index(key);
+    vals[(size_t)t * k + j] = f32_from_order_key((unsigned)(key >> 32));
+  }
+}
+
 }  // namespace
 
 extern "C" size_t msae_topk_ws_bytes(int T, int N, int k) {
@@ -419,5 +487,24 @@ extern "C" int msae_merge_topk(const int32_t *gathered, int T, int G, int kl, in
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(merge_topk_kernel, dim3(T), dim3(64), smem, (hipStream_t)stream, gathered, T, G,
                      kl, k, vals, idx, flagged);
+  return msae_launch_status();
+}
+
+extern "C" int msae_compact_flags(const int32_t *flags, int T, int32_t *rows, int32_t *n_rows, void *stream) {
+  if (T < 0 || !rows || !n_rows || (T > 0 && !flags)) return MSAE_EINVAL;
+  hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flags, T, rows, n_rows);
+  return msae_launch_status();
+}
+
+extern "C" int msae_merge_topk_masked(const int32_t *gathered, int T, int G, int kl, int k, const int32_t *mask,
+                                      float *vals, int32_t *idx, int64_t *idx64, void *stream) {
+  if (T < 0 || G <= 0 || kl <= 0 || k <= 0 || (long)G * kl < k || (long)G * kl > 8192 || !mask || !vals || (!idx && !idx64))
+    return MSAE_EINVAL;
+  if (T == 0) return 0;
+  const size_t smem = (size_t)next_pow2(G * kl) * sizeof(unsigned long long);
+  MSAE_HIP_TRY(hipFuncSetAttribute((const void *)merge_topk_masked_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(merge_topk_masked_kernel, dim3(T), dim3(64), smem, (hipStream_t)stream, gathered, T, G, kl, k, mask,
+                     vals, idx, idx64);
   return msae_launch_status();
 }

@@ -51,6 +51,10 @@ PROTOTYPES = {
     "msae_encode_topk_i64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_opts_p, c_void_p]),
+    "msae_encode_topk_rows_ws_bytes": (c_size_t, [c_int, c_int]),
+    "msae_encode_topk_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
     "msae_shard_record_bytes": (c_size_t, [c_int]),
     "msae_shard_candidates": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_opts_p, c_void_p]),
@@ -72,6 +76,9 @@ PROTOTYPES = {
     "msae_sparsify_write": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                     c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "msae_merge_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "msae_compact_flags": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "msae_merge_topk_masked": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "msae_unit_norm_rows_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "msae_grad_sumsq_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "msae_adam_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float,

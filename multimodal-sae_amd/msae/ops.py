@@ -580,7 +580,7 @@ def sparsify(top_acts: Tensor, top_indices: Tensor, num_latents: int, row_base: 
 
 def merge_topk_gathered(gathered: Tensor, T: int, G: int, kl: int, k: int):
     """Canonical top-k of the all-gathered per-shard pairs (int32 [G*2, T, kl]) on the device.
-    -> (vals f32 [T,k], idx int64 [T,k], flagged bool [T])."""
+    -> (vals f32 [T,k], idx int64 [T,k], flagged int32 [T])."""
     dev = _hip.require_device(gathered)
     lib = _hip.load()
     assert gathered.dtype == torch.int32 and gathered.is_contiguous() and gathered.numel() == G * 2 * T * kl
@@ -590,7 +590,61 @@ def merge_topk_gathered(gathered: Tensor, T: int, G: int, kl: int, k: int):
     with torch.cuda.device(dev):
         _hip.check(lib.msae_merge_topk(_hip.ptr(gathered), T, G, kl, k, _hip.ptr(vals), _hip.ptr(idx),
                                        _hip.ptr(flagged), _hip.stream_of(gathered)), "msae_merge_topk")
-    return vals, idx.to(torch.int64), flagged.bool()
+    return vals, idx.to(torch.int64), flagged
+
+
+def merge_topk_gathered_masked_(gathered: Tensor, T: int, G: int, kl: int, k: int, mask: Tensor, vals: Tensor,
+                                idx: Tensor) -> None:
+    """msae_merge_topk_masked: rows t of (vals f32 [T,k], idx int64 [T,k]) with mask[t] != 0 (int32 [T]) become the
+    canonical top-k of the gathered pairs, in place; the other rows keep what they hold."""
+    dev = _hip.require_device(gathered, mask, vals, idx)
+    assert gathered.dtype == torch.int32 and gathered.is_contiguous() and gathered.numel() == G * 2 * T * kl
+    assert mask.dtype == torch.int32 and mask.numel() == T and mask.is_contiguous()
+    assert vals.dtype == torch.float32 and idx.dtype == torch.int64 and vals.is_contiguous() and idx.is_contiguous()
+    assert vals.shape == (T, k) and idx.shape == (T, k)
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_merge_topk_masked(_hip.ptr(gathered), T, G, kl, k, _hip.ptr(mask), _hip.ptr(vals),
+                                                      None, _hip.ptr(idx), _hip.stream_of(gathered)),
+                   "msae_merge_topk_masked")
+
+
+def compact_flags(flags: Tensor) -> Tuple[Tensor, Tensor]:
+    """flags int32 [T] -> (rows int32 [T]: the flagged t in ascending order in rows[:n], n int32 [1]), all on the
+    device: the redo list `encode_topk_rows_` takes.  Nothing is read back."""
+    dev = _hip.require_device(flags)
+    assert flags.dtype == torch.int32 and flags.is_contiguous()
+    T = flags.numel()
+    rows = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
+    n = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_compact_flags(_hip.ptr(flags), T, _hip.ptr(rows), _hip.ptr(n),
+                                                  _hip.stream_of(flags)), "msae_compact_flags")
+    return rows, n
+
+
+def encode_topk_rows_(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor], rows: Tensor,
+                      n_rows: Tensor, k: int, vals: Tensor, idx: Tensor, status: Optional[Tensor] = None,
+                      set_feature: int = -1, set_value: float = 0.0, zero_feature: int = -1) -> None:
+    """msae_encode_topk_rows: the exact Sae.encode of the tokens rows[:n_rows] (device-side list and count) of
+    x [T, d], written to rows of vals f32 [T, k] / idx int64 [T, k] (/ status int32 [T] = 1) in place.  The work is
+    sized on the device; nothing is read back."""
+    dev = _hip.require_device(x, W_enc, b_enc, b_dec, rows, n_rows, vals, idx, status)
+    lib = _hip.load()
+    xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
+    N, d = W.shape
+    T = xa.numel() // d
+    assert rows.dtype == torch.int32 and n_rows.dtype == torch.int32 and rows.numel() >= T
+    assert vals.dtype == torch.float32 and idx.dtype == torch.int64 and vals.is_contiguous() and idx.is_contiguous()
+    assert vals.shape == (T, k) and idx.shape == (T, k)
+    if T == 0:
+        return
+    ws = _workspace(dev, lib.msae_encode_topk_rows_ws_bytes(T, N))
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_encode_topk_rows(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W), _hip.ptr(be),
+                                             _hip.ptr(bd), _hip.ptr(rows), _hip.ptr(n_rows), T, d, N, k, set_feature,
+                                             float(set_value), zero_feature, _hip.ptr(vals), _hip.ptr(idx),
+                                             _hip.ptr(status), _hip.ptr(ws), ws.numel(), _hip.stream_of(xa)),
+                   "msae_encode_topk_rows")
 
 
 # ---- trainable encoder (training forward, sae.py:193-247) -------------------------------------------

@@ -16,7 +16,12 @@ Rank g of G owns rows [g*N/G, (g+1)*N/G) of W_enc / b_enc.  Every rank sees the 
      index asc) and VERIFIES the truncation: if a shard's last gathered latent made it into the
      merged top-k that shard may hold more members, and the token is redone with k_loc = k (every
      rank derives the same flagged set from the same gathered data; normally it is empty).  The
-     result is bit-identical to the single-GPU result
+     second round is ENQUEUED UNCONDITIONALLY and sized on the device -- the flags are compacted into
+     a device-side redo list (msae_compact_flags), msae_encode_topk_rows recomputes exactly the listed
+     tokens' full local top-k (no work when the list is empty), one more all-gather of the [T, k]
+     round-2 pairs, and a masked merge overwrites the flagged tokens' rows -- so the encode never
+     reads a count back: it runs inside an HF forward hook like every other op (reference
+     features/cache.py:187-204).  The result is bit-identical to the single-GPU result
   4. decode is token-sharded against a replicated W_dec (2 GiB of 288 GB): rank g reconstructs
      tokens [g*T/G, (g+1)*T/G) and an all-gather returns the full [T, d] to every rank (the hook
      that replaces the layer output needs it everywhere; the caching path skips it).
@@ -123,7 +128,7 @@ class ShardedSae:
                  row_offset: Optional[int] = None, mode: str = "topk", W_enc_full: Optional[Tensor] = None,
                  b_enc_full: Optional[Tensor] = None, n_cand: Optional[int] = None,
                  cand_fn: Optional[Callable] = None, rescore_fn: Optional[Callable] = None,
-                 local_decode_max_t: int = LOCAL_DECODE_MAX_T):
+                 local_decode_max_t: int = LOCAL_DECODE_MAX_T, rows_fn: Optional[Callable] = None):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.local_decode_max_t = local_decode_max_t
         self.k, self.rank, self.world, self.group = k, rank, world, group
@@ -136,7 +141,7 @@ class ShardedSae:
         self.decode_events = None
         self.decode_event_i = 0
         self._pending = None
-        self.second_round_tokens = 0
+        self._second_round = None     # device-side count of second-round tokens (read by the property only)
         if k_loc is None:
             k_loc = default_k_loc(k, world) if self.collective else k
         k_loc = max(k_loc, -(-k // world))      # the union must hold at least k candidates
@@ -150,7 +155,11 @@ class ShardedSae:
             encode_fn = lambda x, kk, **ed: ops.encode_topk(x, self.W_enc, self.b_enc, self.b_dec, prepared, kk,
                                                            **self._local_edits(ed))
             decode_fn = lambda idx, vals: ops.decode(idx, vals, self.W_dec, self.b_dec)
+            if rows_fn is None:
+                rows_fn = self._rows_device
         self._encode, self._decode = encode_fn, decode_fn
+        # second round: exact local top-k of the flagged tokens -> ([T, k] f32, [T, k] int64 LOCAL ids; other rows 0)
+        self._rows = rows_fn if rows_fn is not None else self._rows_host
         # mode "candidates": per-shard candidate lists travel, the owner of a token re-scores (module docstring)
         assert mode in ("topk", "candidates")
         self.mode = mode if self.collective else "topk"
@@ -184,9 +193,40 @@ class ShardedSae:
         return torch.stack((vals.contiguous().view(torch.int32),
                             (idx + self.row_offset).to(torch.int32)), 0).contiguous()
 
+    @property
+    def second_round_tokens(self) -> int:
+        """Tokens redone with the full local top-k so far (diagnostics: reading it synchronises with the device)."""
+        return 0 if self._second_round is None else int(self._second_round)
+
+    def _count_second_round(self, flagged: Tensor) -> None:
+        n = flagged.sum()
+        self._second_round = n if self._second_round is None else self._second_round + n
+
+    def _rows_device(self, x: Tensor, flagged: Tensor, **ed):
+        """The HIP path's second round: device-side redo list, work sized on the device (msae_encode_topk_rows)."""
+        from . import ops
+
+        T = x.shape[0]
+        rows, n = ops.compact_flags(flagged)
+        v2 = torch.zeros(T, self.k, dtype=torch.float32, device=x.device)
+        i2 = torch.zeros(T, self.k, dtype=torch.int64, device=x.device)
+        ops.encode_topk_rows_(x, self.W_enc, self.b_enc, self.b_dec, rows, n, self.k, v2, i2, None, **self._local_edits(ed))
+        return v2, i2
+
+    def _rows_host(self, x: Tensor, flagged: Tensor, **ed):
+        """Second round through an injected `encode_fn` (CPU / gloo tests with the oracle's kernels): same outputs."""
+        T = x.shape[0]
+        v2 = torch.zeros(T, self.k, dtype=torch.float32, device=x.device)
+        i2 = torch.zeros(T, self.k, dtype=torch.int64, device=x.device)
+        redo = torch.nonzero(flagged).flatten()
+        if redo.numel():
+            v, i, _ = self._encode(x[redo].contiguous(), self.k, **ed)
+            v2[redo], i2[redo] = v, i.to(torch.int64)
+        return v2, i2
+
     def _merge_gathered(self, flat: Tensor, T: int, kk: int):
         """flat int32 [G*2, T, kk] exactly as all_gather_into_tensor lays the ranks' packs out ->
-        (vals [T,k], idx [T,k] int64, flagged [T] bool: a shard's LAST gathered latent ranks inside the
+        (vals [T,k], idx [T,k] int64, flagged [T] int32: a shard's LAST gathered latent ranks inside the
         merged top-k, so that shard may own further members)."""
         G = flat.shape[0] // 2
         if flat.is_cuda:
@@ -201,15 +241,33 @@ class ShardedSae:
             flagged = (canonical_key(av[:, :, -1], ai[:, :, -1]) >= kth[:, None]).any(dim=1)
         else:
             flagged = torch.zeros(T, dtype=torch.bool, device=mv.device)
-        return mv, mi, flagged
+        return mv, mi, flagged.to(torch.int32)
 
-    def _gather_merge(self, vals: Tensor, idx: Tensor):
-        """ONE all-gather of the [T, kk] pairs of every rank, then the canonical merge."""
+    def _merge_second_round(self, flat2: Tensor, flagged: Tensor, mv: Tensor, mi: Tensor) -> None:
+        """Rows of the flagged tokens <- the canonical top-k of the ranks' FULL local lists (flat2 int32 [G*2, T, k]),
+        in place; every other row keeps round 1's merge."""
+        T, G = mv.shape[0], flat2.shape[0] // 2
+        if flat2.is_cuda:
+            from . import ops
+
+            ops.merge_topk_gathered_masked_(flat2, T, G, self.k, self.k, flagged, mv, mi)
+            return
+        mv2, mi2, _ = self._merge_gathered(flat2, T, self.k)
+        f = flagged.bool()[:, None]
+        mv.copy_(torch.where(f, mv2, mv))
+        mi.copy_(torch.where(f, mi2, mi))
+
+    def _gather(self, vals: Tensor, idx: Tensor) -> Tensor:
+        """ONE all-gather of the [T, kk] pairs of every rank -> int32 [G*2, T, kk]."""
         T, kk = vals.shape
         packed = self._pack(vals, idx)
         flat = torch.empty((self.world * 2, T, kk), dtype=torch.int32, device=packed.device)
         dist.all_gather_into_tensor(flat, packed, group=self.group)  # concat along dim 0
-        return self._merge_gathered(flat, T, kk)
+        return flat
+
+    def _gather_merge(self, vals: Tensor, idx: Tensor):
+        """ONE all-gather of the [T, kk] pairs of every rank, then the canonical merge."""
+        return self._merge_gathered(self._gather(vals, idx), vals.shape[0], vals.shape[1])
 
     def _encode_candidates(self, x: Tensor, **ed):
         """-> (join, (own vals, own idx), keep-alive), or None when the shape has no candidate pass (the engine then
@@ -264,33 +322,29 @@ class ShardedSae:
         vals, idx, status = self._encode(x, self.k_loc, **ed)
         mv, mi, flagged = self._gather_merge(vals, idx)
         if self.k_loc < self.k:
-            redo = torch.nonzero(flagged).flatten()             # identical on every rank
-            if redo.numel():
-                self.second_round_tokens += int(redo.numel())
-                v2, i2, s2 = self._encode(x[redo].contiguous(), self.k, **ed)
-                mv2, mi2, _ = self._gather_merge(v2, i2)
-                mv[redo], mi[redo] = mv2, mi2
-                status = status.clone()
-                status[redo] = torch.maximum(status[redo], s2)
+            # second round, enqueued whatever `flagged` holds (identical on every rank; usually all zero): nothing is
+            # read back, the exact recompute is sized on the device and the masked merge touches the flagged rows only
+            self._count_second_round(flagged)
+            v2, i2 = self._rows(x, flagged, **ed)
+            self._merge_second_round(self._gather(v2, i2), flagged, mv, mi)
+            status = torch.where(flagged != 0, torch.ones_like(status), status)   # 1 = recomputed exactly in the call
         return mv, mi, status
 
     @staticmethod
     def encode_emulated(engines, x: Tensor, **ed):
         """The G ranks of a feature-sharded group executed one after the other in ONE process (one GPU):
         same local encodes, same packs laid out as all_gather_into_tensor would, same merge kernel, same
-        truncation check and second round -- only the transport is a torch.cat.  For tests and per-rank
-        cost studies on a single-GPU box.  -> (vals, idx, number of second-round tokens)."""
+        truncation check and (device-sized, unconditionally enqueued) second round -- only the transport is a
+        torch.cat.  For tests and per-rank cost studies on a single-GPU box.
+        -> (vals, idx, number of second-round tokens as a device scalar)."""
         e0 = engines[0]
         T = x.shape[0]
         packs = [e._pack(*e._encode(x, e.k_loc, **ed)[:2]) for e in engines]
         mv, mi, flagged = e0._merge_gathered(torch.cat(packs, 0), T, e0.k_loc)
-        redo = torch.nonzero(flagged).flatten() if e0.k_loc < e0.k else flagged.new_zeros(0, dtype=torch.long)
-        if redo.numel():
-            xr = x[redo].contiguous()
-            packs = [e._pack(*e._encode(xr, e.k, **ed)[:2]) for e in engines]
-            mv2, mi2, _ = e0._merge_gathered(torch.cat(packs, 0), int(redo.numel()), e0.k)
-            mv[redo], mi[redo] = mv2, mi2
-        return mv, mi, int(redo.numel())
+        if e0.k_loc < e0.k:
+            packs = [e._pack(*e._rows(x, flagged, **ed)) for e in engines]
+            e0._merge_second_round(torch.cat(packs, 0), flagged, mv, mi)
+        return mv, mi, flagged.sum()
 
     @staticmethod
     def encode_emulated_candidates(engines, x: Tensor, **ed):
@@ -386,7 +440,7 @@ class EmulatedShardGroup:
     def __init__(self, sae, world: int, mode: str = "topk", **kw):
         self.engines = [ShardedSae.from_sae(sae, rank=r, world=world, mode=mode, **kw) for r in range(world)]
         self.mode, self.world = mode, world
-        self.second_round_tokens = 0
+        self._second_round = None
 
     def encode(self, x: Tensor, set_feature: int = -1, set_value: float = 0.0, zero_feature: int = -1):
         ed = {}
@@ -402,8 +456,12 @@ class EmulatedShardGroup:
             except MsaeNotImplemented:
                 self.mode = "topk"
         vals, idx, redo = ShardedSae.encode_emulated(self.engines, x, **ed)
-        self.second_round_tokens += redo
+        self._second_round = redo if self._second_round is None else self._second_round + redo
         return vals, idx, torch.zeros(x.shape[0], dtype=torch.int32, device=x.device)
+
+    @property
+    def second_round_tokens(self) -> int:
+        return 0 if self._second_round is None else int(self._second_round)
 
     def decode(self, vals: Tensor, idx: Tensor, **_):
         return self.engines[0]._decode(idx, vals)

@@ -99,12 +99,12 @@ def _make_sae(dev, d, N, k, cluster=False):
     return sae
 
 
-def _sharded_worker(rank, world, port, mode, out_dir):
+def _sharded_worker(rank, world, port, mode, out_dir, shape=(256, 16384, 32, 301)):
     dev = _setup(rank, world, port)
     from msae import ops
     from msae.parallel import ShardedSae
 
-    d, N, k, T = 256, 16384, 32, 301                # 8192 features per rank: the fused candidate pass runs; 301 % 2 != 0
+    d, N, k, T = shape                              # default: 8192 features per rank (the fused candidate pass runs); 301 % 2 != 0
     sae = _make_sae(dev, d, N, k)
     x = torch.randn(T, d, generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.bfloat16)
     W, b = sae.encoder.weight.detach(), sae.encoder.bias.detach()
@@ -113,8 +113,8 @@ def _sharded_worker(rank, world, port, mode, out_dir):
     assert eng.collective and eng.mode == mode
     report = {}
     with torch.no_grad():
-        for name, ed in (("plain", {}), ("steer", {"set_feature": 9000, "set_value": 10.0}),
-                         ("steer_low", {"set_feature": 5, "set_value": 0.25}), ("mask", {"zero_feature": 8191})):
+        for name, ed in (("plain", {}), ("steer", {"set_feature": N // 2 + 808, "set_value": 10.0}),
+                         ("steer_low", {"set_feature": 5, "set_value": 0.25}), ("mask", {"zero_feature": N // 2 - 1})):
             rv, ri, _ = ops.encode_topk(x, W, b, sae.b_dec, prepared, k, ed.get("set_feature", -1),
                                         ed.get("set_value", 0.0), ed.get("zero_feature", -1))
             v, i, st = eng.encode(x, **ed)
@@ -149,6 +149,21 @@ def test_feature_sharded_engine_two_processes_one_gpu(tmp_path, mode):
     """ShardedSae over two ranks == the single-GPU encode / decode, bit for bit, in both exchange schemes."""
     world = 2
     mp.spawn(_sharded_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        rep = torch.load(tmp_path / f"rank{rank}.pt")
+        for key in ("plain", "steer", "steer_low", "mask", "forward", "S1"):
+            assert rep[key] is True, (rank, key, rep)
+        if mode == "topk":
+            assert rep["second_round"] is True and rep["second_round_tokens"] > 0, rep
+
+
+@pytest.mark.parametrize("mode", ["topk", "candidates"])
+def test_feature_sharded_engine_two_processes_at_c2_width(tmp_path, mode):
+    """The same at BASELINE configs[2]'s own width: d = 4096, N = 131072 as 2 x 65536 rows, 1025 tokens (odd), k = 32 --
+    two address spaces, the real HIP kernels on both ranks, packs / records crossing a transport; bit-identical to the
+    single-GPU encode / decode, including the hooks' edits and (per-shard top-k scheme) a forced second round."""
+    world = 2
+    mp.spawn(_sharded_worker, args=(world, _free_port(), mode, str(tmp_path), (4096, 131072, 32, 1025)), nprocs=world, join=True)
     for rank in range(world):
         rep = torch.load(tmp_path / f"rank{rank}.pt")
         for key in ("plain", "steer", "steer_low", "mask", "forward", "S1"):
