@@ -40,8 +40,16 @@ class SteeringController:
         return clamp_features_max(sae, feature, hooked_module, k=k)
 
     def _generate(self) -> str:
+        kw = {}
+        world = getattr(self.sae, "world", 1)
+        if not isinstance(self.sae, Sae) and world > 1:
+            # feature-sharded engine: all ranks meet in its collectives at every hooked forward, so their generation
+            # loops must take the same number of steps.  Same RNG state on every rank (the model's generation_config
+            # may sample), and HF's `synced_gpus`: a rank whose sequence hit EOS keeps stepping until all have.
+            torch.manual_seed(0x5AE)
+            kw["synced_gpus"] = True
         with torch.no_grad():
-            output = self.model.generate(**self.inputs, max_new_tokens=512)
+            output = self.model.generate(**self.inputs, max_new_tokens=512, **kw)
         cont = output[:, self.inputs["input_ids"].shape[-1]:]
         return self.processor.batch_decode(cont, skip_special_tokens=True)[0]
 

@@ -45,7 +45,11 @@ def main(argv=None):
         if shard:       # one SAE over all ranks: every rank walks the whole feature list in step
             from ...parallel import ShardedSae
 
-            engine = ShardedSae.from_sae(sae, rank=rank, world=world, group=dist.group.WORLD, mode=args.shard_mode)
+            # broadcast_input: every rank runs its own LLM forward; rank 0's hidden state is the one all shards encode
+            # (nondeterministic kernels / sampling cannot make the ranks merge results of different inputs), and the
+            # controller keeps the ranks' generation loops in lockstep (SteeringController._generate)
+            engine = ShardedSae.from_sae(sae, rank=rank, world=world, group=dist.group.WORLD, mode=args.shard_mode,
+                                         broadcast_input=True)
             feature_idx = feats.cpu().tolist()
         else:           # the reference's split: every rank its own slice of the feature list (steering.py:70-75)
             engine = sae

@@ -128,9 +128,15 @@ class ShardedSae:
                  row_offset: Optional[int] = None, mode: str = "topk", W_enc_full: Optional[Tensor] = None,
                  b_enc_full: Optional[Tensor] = None, n_cand: Optional[int] = None,
                  cand_fn: Optional[Callable] = None, rescore_fn: Optional[Callable] = None,
-                 local_decode_max_t: int = LOCAL_DECODE_MAX_T, rows_fn: Optional[Callable] = None):
+                 local_decode_max_t: int = LOCAL_DECODE_MAX_T, rows_fn: Optional[Callable] = None,
+                 broadcast_input: bool = False):
         self.W_enc, self.b_enc, self.W_dec, self.b_dec = W_enc_shard, b_enc_shard, W_dec, b_dec
         self.local_decode_max_t = local_decode_max_t
+        # Every rank must encode the SAME activations (the merge combines per-rank results of one x).  Callers that
+        # cannot guarantee bit-identical inputs on all ranks -- an LLM forward per rank with nondeterministic kernels,
+        # sampling -- set broadcast_input: rank 0's x is broadcast at the top of every encode (S = 1 decode steps:
+        # 8 KB; once per prefill), so the ranks can never merge results of different inputs.
+        self.broadcast_input = broadcast_input
         self.k, self.rank, self.world, self.group = k, rank, world, group
         self.n_loc = W_enc_shard.shape[0]
         # global id of this shard's first feature: equal shards unless the caller says otherwise
@@ -315,6 +321,7 @@ class ShardedSae:
             ed.update(zero_feature=zero_feature)
         if not self.collective:
             return self._encode(x, self.k, **ed)
+        x = self._same_input(x)
         if self.mode == "candidates":
             got = self._encode_candidates(x, **ed)
             if got is not None:
@@ -329,6 +336,28 @@ class ShardedSae:
             self._merge_second_round(self._gather(v2, i2), flagged, mv, mi)
             status = torch.where(flagged != 0, torch.ones_like(status), status)   # 1 = recomputed exactly in the call
         return mv, mi, status
+
+    def _same_input(self, x: Tensor) -> Tensor:
+        """broadcast_input: rank 0's activations replace everybody's (see __init__).  MSAE_DEBUG_SHARD_CHECK=1 instead
+        ASSERTS that the ranks already agree (an all-reduce of a checksum; one host synchronisation per encode)."""
+        import os
+
+        if not (dist.is_initialized() and self.world > 1):
+            return x
+        if self.broadcast_input:
+            x = x.contiguous().clone() if x.requires_grad else x.contiguous()
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(x, src=src, group=self.group)
+        elif os.environ.get("MSAE_DEBUG_SHARD_CHECK", "0") not in ("", "0"):
+            h = x.detach().float()
+            chk = torch.stack((h.sum(), h.abs().sum(), torch.tensor(float(x.shape[0]), device=x.device)))
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("ShardedSae.encode: the ranks hold different activations (checksum mismatch); every "
+                                   "rank must encode the same x -- pass broadcast_input=True")
+        return x
 
     @staticmethod
     def encode_emulated(engines, x: Tensor, **ed):
@@ -420,6 +449,7 @@ class ShardedSae:
     def forward(self, x: Tensor, async_gather: bool = False) -> dict:
         if self.collective and self.mode == "candidates" and x.shape[0] > self.local_decode_max_t:
             # the owner already holds its tokens' results: decode them while the result gather is in flight
+            x = self._same_input(x)
             got = self._encode_candidates(x)
             if got is not None:
                 join, (lv, li), _keep = got

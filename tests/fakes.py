@@ -91,6 +91,7 @@ class TinyLlava(nn.Module):
         """Greedy decoding; like HF generate with a KV cache, each new token is ONE single-token forward
         (S = 1), which is what the steering hook distinguishes (features/steering.py:111)."""
         max_new_tokens = min(max_new_tokens, self.max_gen)   # the callers hard-code 512 (steering.py:86)
+        kw.pop("synced_gpus", None)                          # (HF generate's lockstep flag: greedy fakes are in lockstep)
         out = input_ids
         nxt = self.forward(input_ids=out, **kw)["logits"][:, -1].argmax(-1, keepdim=True)
         for _ in range(max_new_tokens):

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False):
+def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, diverge=False):
     for p in (REPO, REPO / "tests", REPO / "multimodal-sae_amd"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -49,8 +49,23 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False):
     eng = ShardedSae(torch.from_numpy(W_enc[lo:hi]), torch.from_numpy(b_enc[lo:hi]),
                      torch.from_numpy(W_dec), torch.from_numpy(b_dec), k, rank=rank, world=world,
                      group=dist.group.WORLD, encode_fn=encode_fn, decode_fn=decode_fn, k_loc=k_loc,
-                     local_decode_max_t=0)      # (a handful of tokens would be decoded locally: exercise the sharded decode)
-    out = eng.forward(torch.from_numpy(x))
+                     local_decode_max_t=0,      # (a handful of tokens would be decoded locally: exercise the sharded decode)
+                     broadcast_input=diverge)
+    xt = torch.from_numpy(x)
+    if diverge and rank > 0:                    # this rank's "LLM forward" came out different: rank 0's input must win
+        xt = xt + 0.25 * torch.randn(xt.shape, generator=torch.Generator().manual_seed(rank))
+    if diverge and os.environ.get("MSAE_DEBUG_SHARD_CHECK"):
+        eng.broadcast_input = False             # debug mode instead: the mismatch must be DETECTED
+        try:
+            eng.forward(xt)
+            caught = False
+        except RuntimeError as e:
+            caught = "different activations" in str(e)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), caught=caught)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    out = eng.forward(xt)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(),
              i=out["top_indices"].numpy(), r=out["sae_out"].numpy(), redo=eng.second_round_tokens,
              k_loc=eng.k_loc)
@@ -83,6 +98,27 @@ def test_feature_sharded_equals_single_shard(tmp_path, T, k, k_loc, cluster):
         assert np.array_equal(g["r"], ref_r)
         if cluster:
             assert int(g["redo"]) > 0 and int(g["k_loc"]) == k_loc   # the second round really ran
+
+
+def test_broadcast_input_makes_diverged_ranks_agree(tmp_path, monkeypatch):
+    """`--shard-sae` runs one LLM forward per rank; if a rank's hidden state differs (nondeterministic
+    kernel, sampling) the merge would combine results of different inputs.  broadcast_input=True: rank 0's
+    activations are what every shard encodes -- both ranks return the single-shard result of RANK 0's x."""
+    import synth
+    from oracle import oracle
+
+    T, d, N, k, world = 13, 64, 1024, 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), T, d, N, k, str(tmp_path), None, False, True), nprocs=world, join=True)
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    ref_v, ref_i = oracle.encode_topk(synth.activations(T, d, seed=32), W_enc, b_enc, b_dec, k)
+    for rank in range(world):
+        g = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(g["i"], ref_i) and np.array_equal(g["v"], ref_v), rank
+    # without the broadcast, MSAE_DEBUG_SHARD_CHECK=1 detects the mismatch on every rank instead of merging silently
+    monkeypatch.setenv("MSAE_DEBUG_SHARD_CHECK", "1")
+    mp.spawn(_worker, args=(world, _free_port(), T, d, N, k, str(tmp_path), None, False, True), nprocs=world, join=True)
+    for rank in range(world):
+        assert bool(np.load(tmp_path / f"rank{rank}.npz")["caught"]), rank
 
 
 def test_merge_topk_is_canonical_with_ties():
