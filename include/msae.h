@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MSAE_ABI_VERSION 2
+#define MSAE_ABI_VERSION 3
 
 /* element type of the activation tensor x handed over by the LLM hook (sae.py:174 up-casts) */
 enum { MSAE_F32 = 0, MSAE_BF16 = 1, MSAE_F16 = 2 };
@@ -74,14 +74,28 @@ enum {
  *                 re-scores more rows per token; results of verified tokens do not depend on it.
  *   status_detail diagnostics (tools/soak_fused.py): a token recomputed inside the call reports
  *                 status = 1 | reason << 8 (reason bits below) instead of 1, so `status & 0xFF` is the code.
- *   profile       a handle from msae_profile_create (stage timing, below) or NULL. */
+ *   profile       a handle from msae_profile_create (stage timing, below) or NULL.
+ *   exact         (ABI 3) != 0: msae_encode_topk[_i64] computes EVERY token by the exact path (msae_pre_acts_f32 +
+ *                 msae_topk_f32 semantics through the in-call fallback: <= 1 GiB of dense scratch whatever T; status 1
+ *                 for every token).  The switch for callers that cannot accept the fused path's statistical contract:
+ *                 "bit-identical for every verified token, a member of the true top-k missed with probability < 3e-13
+ *                 per token UNDER THE NOISE MODEL" -- the model assumes the rounding residuals of one operand are not
+ *                 aligned with the other operand.  Encoder rows constructed from a token's own int8 rounding residual
+ *                 (W_n ~ sign(x/sx - rint(x/sx))) violate it by construction: such a row's coarse value is low by
+ *                 ~0.25 sqrt(12 d) = 55 sigma at d = 4096, it is never re-scored, no check sees it, and the int8 pass
+ *                 returns status 0 with that feature missing (tests/test_gpu_hostile.py::test_row_aligned_with_a_
+ *                 token_s_rounding_residual pins exactly this; the bf16 pass, whose residuals are relative roundings of
+ *                 other bits, and exact = 1 return the right answer).  Trained weights cannot know a future token's
+ *                 residual; weights under an adversary's control can.  Slower by ~20x on large batches. */
 enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1 };
 typedef struct msae_options {
-  uint32_t size;          /* sizeof(msae_options) of the caller's header */
+  uint32_t size;          /* sizeof(msae_options) of the caller's header (ABI 2's 24-byte struct is accepted: exact = 0) */
   int32_t coarse_mode;    /* MSAE_COARSE_* */
   float guard_z;          /* 0 = default */
   int32_t status_detail;  /* 0 / 1 */
   void *profile;          /* msae_profile_create handle or NULL */
+  int32_t exact;          /* 0 / 1 */
+  int32_t reserved;       /* 0 */
 } msae_options;
 /* Fills *opts with the defaults (coarse_mode MSAE_COARSE_DEFAULT, guard_z 0, no detail, no profile). */
 void msae_options_init(msae_options *opts);
@@ -117,9 +131,13 @@ int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void 
  * encoding in the other mode. */
 int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const msae_options *opts,
                          void *stream);
-/* The same for ONE following encode of T_next tokens (the training loop, train/sae/sae/trainer.py:347-401: the weights change
+/* The buffer records which operand groups hold the current weights (bf16 | int8 | fragment-major int8); a refresh clears
+ * the record of everything it does not rebuild, and an encode whose candidate pass would read a stale group computes all
+ * its tokens by the exact path instead (status 1; reason 128 with status_detail) -- stale operands cost time, never a
+ * wrong top-k.
+ * The same for ONE following encode of T_next tokens (the training loop, train/sae/sae/trainer.py:347-401: the weights change
  * before the buffer is read again): a batch of more than 128 tokens does not read the copies the small-batch kernels use,
- * and they are left stale.  Refresh again (or msae_encoder_prepare) before encoding a different number of tokens. */
+ * and they are left stale (a later encode of <= 128 tokens falls back to the exact path until the next refresh / prepare). */
 int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, int T_next, const msae_options *opts,
                              void *stream);
 

@@ -43,6 +43,7 @@
 //
 // Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the token
 // verifies, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
+#include <cstddef>
 #include <cstdlib>
 #include <type_traits>
 
@@ -84,8 +85,16 @@ struct Prepared {
   unsigned magic;
   int N, d, S;
   size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, off_wqp, off_wqsp, off_wqf, off_wqsf, bytes;
+  // Which operand groups hold the CURRENT weights (PREP_* bits).  msae_encoder_refresh[_for] rebuilds only what the following
+  // encode reads and clears the bits of everything else; every fused path's prep kernel tests the bits of the operands ITS
+  // candidate pass is about to read and, when one is missing, hands all its tokens to the exact path (reason 128) -- stale
+  // operands cost time, never a wrong top-k, and nothing about them lives on the host.
+  unsigned valid;
 };
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
+constexpr unsigned PREP_BF16 = 1u;   // W_bf16 + bf16 sample rows
+constexpr unsigned PREP_I8 = 2u;     // Wq row-major, tile-major (+ sample copies)
+constexpr unsigned PREP_FRAG = 4u;   // Wq fragment-major (+ sample copy): the weight-stream kernels of <= 128 tokens
 
 __host__ __device__ inline bool fast_shape_ok(int N, int d) {
   return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/32 must tile by BN = 256
@@ -141,13 +150,16 @@ struct CallOpts {
   float z;           // width of the error band: u = coarse + z*sigma
   int detail;        // status = 1 | reason << 8 for tokens recomputed in the call
   ProfState *prof;   // stage timing handle or null
+  int exact;         // every token by the exact path (msae_options::exact)
 };
 inline bool resolve_opts(const msae_options *o, CallOpts &c) {
-  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr;
+  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr; c.exact = 0;
   if (o) {
-    if (o->size < sizeof(msae_options)) return false;
+    // `size` is the caller's sizeof: a caller compiled against ABI 2's header (no `exact`) is served with exact = 0
+    if (o->size < offsetof(msae_options, exact)) return false;
     c.mode = o->coarse_mode; c.z = o->guard_z; c.detail = o->status_detail ? 1 : 0;
     c.prof = static_cast<ProfState *>(o->profile);
+    if (o->size >= offsetof(msae_options, exact) + sizeof(int32_t)) c.exact = o->exact ? 1 : 0;
   }
   if (c.mode < 0) {
     const char *e = getenv("MSAE_COARSE");
@@ -448,7 +460,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
                                                       const unsigned char *__restrict__ is_out,
                                                       signed char *__restrict__ xq,
                                                       signed char *__restrict__ xqo,
-                                                      f32x4 *__restrict__ rowc, float zz12, int tile_major) {
+                                                      f32x4 *__restrict__ rowc, float zz12, int tile_major,
+                                                      const unsigned *__restrict__ valid, unsigned need) {
   __shared__ float red[3][4];
   const int t = blockIdx.x;
   auto xq_at = [&](int c) { return xq + (tile_major ? packed_off((size_t)t, c, d, tile_major) : (size_t)t * d + c); };
@@ -539,7 +552,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   __syncthreads();
   if (threadIdx.x == 0) {
     e0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const float guard = e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale ? 1.f : 0.f;
+    // (stale operands, Prepared::valid: the candidate pass would read old weights -- every token to the exact path)
+    const float guard = (e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale || (*valid & need) != need) ? 1.f : 0.f;
     rowc[t] = f32x4{scale, (float)m, zz12 * ss, guard};
   }
   if (threadIdx.x < MAX_OUT) {
@@ -557,7 +571,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
 
 // bf16 pass: rowc[t] = (1, 1, P = z^2 * 5.5e-6 * |a_t|_4^2, 0); one 256-thread workgroup per token
 __global__ __launch_bounds__(256) void row_p4_kernel(const float *__restrict__ a32, int T, int d,
-                                                     f32x4 *__restrict__ rowc, float z2) {
+                                                     f32x4 *__restrict__ rowc, float z2,
+                                                     const unsigned *__restrict__ valid) {
   __shared__ float red[4];
   const int t = blockIdx.x;
   const float *row = a32 + (size_t)t * d;
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256) void row_p4_kernel(const float *__restrict__ a
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s4;
   __syncthreads();
   s4 = (red[0] + red[1]) + (red[2] + red[3]);
-  if (threadIdx.x == 0) rowc[t] = f32x4{1.f, 1.f, z2 * BF16_REL_VAR2 * __builtin_sqrtf(s4), 0.f};
+  if (threadIdx.x == 0) rowc[t] = f32x4{1.f, 1.f, z2 * BF16_REL_VAR2 * __builtin_sqrtf(s4), (*valid & PREP_BF16) ? 0.f : 1.f};
 }
 
 // Wq_o[n][j] = Wq[n][odims[j]] (0 where odims[j] < 0) for every feature row, and for the sample rows;
@@ -1263,6 +1278,12 @@ __global__ void edit_dense_kernel(float *dense, int ld, int rows, const int *n_r
   if (zero_feature >= 0) dense[(size_t)r * ld + zero_feature] = 0.f;
 }
 
+// list[0 .. T) = 0 .. T - 1, list[T] = T (the count), the words behind it 0: "every token is flagged" (msae_options::exact)
+__global__ void iota_list_kernel(int *list, int T, int n_total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_total) list[i] = i < T ? i : (i == T ? T : 0);
+}
+
 // counts[c] = number of flagged tokens in pass c of the exact fallback
 __global__ void fallback_counts_kernel(const int *n_flagged, int fb_cap, int chunks, int *counts) {
   const int nf = *n_flagged;
@@ -1451,11 +1472,14 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict_
                                                          int d, float *__restrict__ a32, signed char *__restrict__ xhi,
                                                          signed char *__restrict__ xlo, f32x4 *__restrict__ rowc,
                                                          float zz12, int *__restrict__ zero_a, int n_a,
-                                                         int *__restrict__ zero_b, int n_b) {
+                                                         int *__restrict__ zero_b, int n_b,
+                                                         const unsigned *__restrict__ valid, unsigned need, int T) {
   __shared__ float red[2][4];
   const int t = blockIdx.x;
-  if (t == 0) {   // per-call counters (model-check flags, flag list + counts) start at zero
-    for (int i = threadIdx.x; i < n_a; i += 256) zero_a[i] = 0;
+  if (t == 0) {   // per-call counters (model-check flags [T], finished-wave counters [T], flag list + counts) start at zero
+    // stale operands (Prepared::valid): the model-check flag of every token starts RAISED -- all of them go to the exact path
+    const int stale = (*valid & need) != need ? 1 : 0;
+    for (int i = threadIdx.x; i < n_a; i += 256) zero_a[i] = i < T ? stale : 0;
     for (int i = threadIdx.x; i < n_b; i += 256) zero_b[i] = 0;
   }
   float m = 0.f, ss = 0.f;
@@ -1901,6 +1925,11 @@ __global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restri
   finalize_small(keys, exact, tau[t], t, k, set_feature, set_value, vi, vals, idx, status, flagged, n_flagged, lane);
 }
 
+inline int dot4_max_small() {   // largest T of the dot4 weight stream (tuning knob; the MFMA stream takes the rest of the small path)
+  static const int v = [] { const char *e = getenv("MSAE_SMALL_DOT4_MAX"); return e ? atoi(e) : SMALL_DOT4_PREF; }();
+  return v;
+}
+
 template <int DT>
 int run_small(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const Prepared &pp,
               const unsigned char *prepared, int T, int d, int N, int k, int set_feature, float set_value,
@@ -1925,8 +1954,10 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   const signed char *wqsf = reinterpret_cast<const signed char *>(prepared + pp.off_wqsf);
   const f32x4 *wstat = reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat);
   prof_mark(co.prof, 0, s);
+  const unsigned *valid = reinterpret_cast<const unsigned *>(prepared + offsetof(Prepared, valid));
+  const unsigned need = (T > dot4_max_small() && d <= 4096) ? (PREP_I8 | PREP_FRAG) : PREP_I8;
   hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, 2 * T,
-                     flagged, T + 64 + pl.fb_chunks);
+                     flagged, T + 64 + pl.fb_chunks, valid, need, T);
   prof_mark(co.prof, 1, s);
   prof_mark(co.prof, 2, s);
   prof_mark(co.prof, 3, s);
@@ -1936,7 +1967,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
                      rowc, zz12, skip_a, skip_b, surv, bound)
   const int dseg = d / 1024;
   int n_surv = SMALL_SURV, n_bound = SMALL_GRID;
-  static const int dot4_max = [] { const char *e = getenv("MSAE_SMALL_DOT4_MAX"); return e ? atoi(e) : SMALL_DOT4_PREF; }();
+  const int dot4_max = dot4_max_small();
   if (T > dot4_max && d <= 4096) {
     static int n_cu = [] {
       int dev = 0, cus = 256;
@@ -2001,6 +2032,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   int *n_flagged = flagged + T;
   const unsigned short *wb = reinterpret_cast<const unsigned short *>(prepared + pp.off_wb);
   const unsigned short *wsamp = reinterpret_cast<const unsigned short *>(prepared + pp.off_ws);
+  const unsigned *valid = reinterpret_cast<const unsigned *>(prepared + offsetof(Prepared, valid));
   prof_mark(co.prof, 0, s);
   // producers of the candidate lists write the segmented lists when the plan has them (compact_candidates_kernel joins them)
   int *pcnt = pl.segs > 1 ? reinterpret_cast<int *>(ws + pl.off_segcnt) : cnt;
@@ -2048,11 +2080,13 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
+    const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
     if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
-      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
+      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
+                         valid, need);
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
-                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major);
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need);
     skip_sample = MAIN_SKIPS_SAMPLE && w_packed;   // the tile-major main operand holds the non-sample rows only
     cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
@@ -2071,7 +2105,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     op_samp.B = skinny ? prepared + pp.off_wqsf : tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
   } else {
-    hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z);
+    hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z, valid);
     colc = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
     colc_s = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf_s);
     op_main.A = reinterpret_cast<const unsigned char *>(xb); op_main.ldA = (size_t)d * 2;
@@ -2218,6 +2252,8 @@ extern "C" void msae_options_init(msae_options *opts) {
   opts->guard_z = 0.f;
   opts->status_detail = 0;
   opts->profile = nullptr;
+  opts->exact = 0;
+  opts->reserved = 0;
 }
 
 extern "C" int msae_profile_create(int max_steps, void **handle) {
@@ -2275,6 +2311,8 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
   if (N <= 0 || d <= 0 || !prepared) return MSAE_EINVAL;
   if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
   Prepared p = make_prepared(N, d);
+  // what this call rebuilds is valid, everything else is stale from now on (the weights have changed)
+  p.valid = ((modes & 1) ? PREP_BF16 : 0u) | (((modes & 2) && i8_shape_ok(N, d)) ? (PREP_I8 | ((modes & 4) ? 0u : PREP_FRAG)) : 0u);
   MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
   if (p.S) {
     if (!msae_aligned(W_enc, 16)) return MSAE_EALIGN;
@@ -2369,6 +2407,17 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
   if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || !msae_aligned(W_enc, 16) ||
       (b_dec && !msae_aligned(b_dec, 16)))
     return MSAE_EALIGN;
+  if (co.exact) {   // msae_options::exact: every token through the in-call exact path (bounded scratch, status 1)
+    int *flagged = reinterpret_cast<int *>(wsb + pl.off_flag);
+    hipLaunchKernelGGL(iota_list_kernel, dim3((T + 255) / 256), dim3(256), 0, s, flagged, T, T + 64 + pl.fb_chunks);
+    int rc;
+    switch (x_dtype) {
+      case MSAE_F32: rc = run_exact_fallback<MSAE_F32>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, 0, s); break;
+      case MSAE_BF16: rc = run_exact_fallback<MSAE_BF16>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, 0, s); break;
+      default: rc = run_exact_fallback<MSAE_F16>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, 0, s); break;
+    }
+    return rc ? rc : msae_launch_status();
+  }
   if (pl.small) {
     switch (x_dtype) {
       case MSAE_F32: return run_small<MSAE_F32>(x, W_enc, b_enc, b_dec, pp, pb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);

@@ -18,13 +18,14 @@ LIB_PATH = _LIB_DIR / "libmsae_hip.so"
 c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_size_t, ctypes.c_int64)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MsaeOptions(ctypes.Structure):
     """struct msae_options of include/msae.h: the per-call options of the fused encoder."""
     _fields_ = [("size", ctypes.c_uint32), ("coarse_mode", ctypes.c_int32), ("guard_z", ctypes.c_float),
-                ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p)]
+                ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p), ("exact", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 c_opts_p = ctypes.POINTER(MsaeOptions)

@@ -93,8 +93,9 @@ class Options:
     COARSE = {"default": -1, "bf16": 0, "int8": 1}
 
     def __init__(self, coarse: str = "default", guard_z: float = 0.0, status_detail: bool = False,
-                 profile: Optional[StageProfile] = None):
+                 profile: Optional[StageProfile] = None, exact: bool = False):
         self.coarse, self.guard_z, self.status_detail, self.profile = coarse, guard_z, status_detail, profile
+        self.exact = exact
 
     def struct(self) -> "_hip.MsaeOptions":
         o = _hip.MsaeOptions()
@@ -103,6 +104,7 @@ class Options:
         o.guard_z = float(self.guard_z)
         o.status_detail = int(bool(self.status_detail))
         o.profile = self.profile.handle if self.profile is not None else None
+        o.exact = int(bool(self.exact))
         return o
 
     def ref(self):
@@ -130,18 +132,19 @@ _OPTS_CACHE: dict = {}
 _WS_BYTES_CACHE: dict = {}
 
 
-def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False) -> _OptsRef:
+def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False, exact: bool = False) -> _OptsRef:
     """Options of one call: explicit arguments win, the process defaults fill the rest."""
     coarse = _defaults.coarse if coarse_mode < 0 else ("int8" if coarse_mode == 1 else "bf16")
     z = guard_z if guard_z > 0.0 else _defaults.guard_z
     detail = bool(status_detail or _defaults.status_detail)
+    exact = bool(exact or _defaults.exact)
     prof = _defaults.profile
-    key = (coarse, z, detail, id(prof) if prof is not None else 0)
+    key = (coarse, z, detail, id(prof) if prof is not None else 0, exact)
     ref = _OPTS_CACHE.get(key)
     if ref is None or ref.profile is not prof:
         if len(_OPTS_CACHE) > 64:
             _OPTS_CACHE.clear()
-        ref = _OPTS_CACHE[key] = _OptsRef(Options(coarse, z, detail, prof))
+        ref = _OPTS_CACHE[key] = _OptsRef(Options(coarse, z, detail, prof, exact))
     return ref
 
 
@@ -322,6 +325,12 @@ def set_guard_z(z: float) -> None:
     _defaults.guard_z = float(z)
 
 
+def set_exact(on: bool) -> None:
+    """Default of msae_options::exact for this process's ops: every fused encode computes every token by the exact path
+    (no statistical contract; ~20x slower on large batches)."""
+    _defaults.exact = bool(on)
+
+
 def set_status_detail(on: bool) -> None:
     """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
     _defaults.status_detail = bool(on)
@@ -372,10 +381,11 @@ def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
 def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
                 prepared: Optional[Tensor], k: int, set_feature: int = -1, set_value: float = 0.0,
                 zero_feature: int = -1, coarse_mode: int = -1, guard_z: float = 0.0,
-                status_detail: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+                status_detail: bool = False, exact: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...]).
-    coarse_mode (-1 default / 0 bf16 / 1 int8), guard_z (0 = default) and status_detail are this call's
-    msae_options; what is left at its default comes from the process defaults (set_coarse_mode & co.)."""
+    coarse_mode (-1 default / 0 bf16 / 1 int8), guard_z (0 = default), status_detail and exact (every token by the
+    exact path: include/msae.h, msae_options::exact) are this call's msae_options; what is left at its default comes
+    from the process defaults (set_coarse_mode & co.)."""
     dev = _hip.require_device(x, W_enc, b_enc, b_dec, prepared)
     lib = _hip.load()
     xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
@@ -388,7 +398,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     status = torch.empty(xa.shape[:-1], dtype=torch.int32, device=dev)
     if T == 0:
         return vals, idx, status
-    opts = _opts(coarse_mode, guard_z, status_detail)
+    opts = _opts(coarse_mode, guard_z, status_detail, exact)
     ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
@@ -401,7 +411,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
 
 @encode_topk.register_fake
 def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1, coarse_mode=-1,
-      guard_z=0.0, status_detail=False):
+      guard_z=0.0, status_detail=False, exact=False):
     return (x.new_empty(*x.shape[:-1], k, dtype=torch.float32),
             x.new_empty(*x.shape[:-1], k, dtype=torch.int64),
             x.new_empty(x.shape[:-1], dtype=torch.int32))

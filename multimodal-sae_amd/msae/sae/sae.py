@@ -163,7 +163,7 @@ class Sae(nn.Module):
 
     def encode(self, x: Tensor, *, set_feature: int = -1, set_value: float = 0.0,
                zero_feature: int = -1, return_status: bool = False, resolve: bool = True,
-               differentiable: Optional[bool] = None):
+               differentiable: Optional[bool] = None, exact: bool = False):
         """Fused encode + TopK (sae.py:183-185).  `set_feature/set_value` and `zero_feature` apply
         the steering / attribution hooks' edits of the dense latents (steering.py:113-114,
         patching/utils.py:43-48) inside the kernel, before TopK.
@@ -173,12 +173,19 @@ class Sae(nn.Module):
         candidate pass does not describe ...) exactly inside the call, on the device; nothing is read
         back, so the method is stream-ordered like every other op.  `status` (return_status=True):
         0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored.
+        `exact=True` computes EVERY token by the exact path (msae_options::exact, include/msae.h): for callers that
+        cannot accept the fused path's statistical contract (a miss needs a feature whose int8 / bf16 rounding error
+        exceeds 7 of its own sigma: < 3e-13 per token for weights that do not know the token's rounding residual;
+        adversarially constructed rows can).  Inference only.
 
         Autograd: the call is one differentiable node (sparse backward through the selected latents) when
         gradients are enabled and `x` requires grad (the attribution hooks: the LLM's hidden states do) or
         `differentiable=True` is passed (a custom training loop that wants d/dW from a constant input);
         plain inference on a loaded module -- whose parameters require grad by default -- saves nothing."""
         want_grad = torch.is_grad_enabled() and (x.requires_grad if differentiable is None else differentiable)
+        if want_grad and exact:
+            raise RuntimeError("Sae.encode(exact=True) is an inference switch: differentiate pre_acts -> select_topk (the "
+                               "exact path with autograd) instead")
         if want_grad and return_status:
             raise RuntimeError("Sae.encode(return_status=True) returns non-differentiable outputs: call it under "
                                "torch.no_grad(), or without return_status where gradients must flow")
@@ -192,7 +199,7 @@ class Sae(nn.Module):
         with torch.no_grad():      # (a custom op without an autograd formula would hang a raising node on the outputs)
             acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
                                                 self._prepared_weights(), self.cfg.k, set_feature,
-                                                float(set_value), zero_feature)
+                                                float(set_value), zero_feature, exact=exact)
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 

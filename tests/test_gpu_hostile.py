@@ -296,3 +296,104 @@ def test_soak_small(dev):
     print(f"\nsoak 65536 tokens: wrong {wrong}, exact fallback {fallback}")
     assert wrong == 0
     assert fallback < 0.03 * 65536
+
+
+def test_row_aligned_with_a_token_s_rounding_residual(dev):
+    """THE EDGE OF THE CONTRACT, pinned (round-3 verdict).  The fused path is exact iff no never-re-scored feature's
+    rounding error exceeds 7 of its own sigma UNDER THE NOISE MODEL, which takes the residuals of one operand to be
+    uncorrelated with the other operand.  One encoder row built from a token's own int8 rounding residual,
+        W_n = alpha * sign(a_t / sx_t - rint(a_t / sx_t)),
+    violates that by construction: its weights quantise exactly (+-127), and the x-side error sx * sum_c delta_c w_c =
+    alpha sx sum |delta_c| = alpha sx d / 4 is 0.25 sqrt(12 d) = 55 sigma at d = 4096, all of one sign.  alpha puts the
+    row's exact pre-activation at 1.5 v_k -- a member of the token's true top-k -- while its coarse value sits near 0:
+    it is never re-scored, no re-scored pair looks abnormal, the token's shape is ordinary.
+
+    What the library does, asserted:  int8 pass -> THAT token verified (status 0) and WRONG (the feature is missing);
+    every other token of the batch right.  bf16 pass (relative roundings of other bits: the construction means nothing to
+    it) -> right.  msae_options::exact / Sae.encode(exact=True) -> right, status 1 everywhere.  Trained weights cannot know
+    a future token's residual; weights under an adversary's control can -- include/msae.h says so next to the 3e-13.
+    If a guard ever closes this, flip the int8 assertion."""
+    from msae import ops
+
+    d, N, T, k = 4096, 16384, 512, 32
+    W, b, bd = hostile.weights("gauss", N, d, dev, seed=21)
+    x = hostile.activations(T, d, dev, seed=22, kind="gauss")     # no massive dims: the batch's outlier list is empty
+    a = x.float() - bd
+    # the int8 pass's quantisation of a token, restated (quant_x_kernel: scale = max|a| / 127, q = rint(a / scale))
+    scale = a.abs().amax(dim=1, keepdim=True) / 127.0
+    u = a * (1.0 / scale)
+    q = torch.round(u)
+    delta = u - q
+    sgn = torch.where(delta >= 0, 1.0, -1.0)
+    R = (q * sgn).sum(dim=1)                                      # the part of the row's response the coarse pass DOES see
+    t_star = int(R[:64].abs().argmin())                           # a token whose coarse value of the row is ~0
+    s_vec = sgn[t_star]
+    ev, ei = _exact(ops, x[t_star:t_star + 1], W, b, bd, k)
+    v_k = float(ev[0, -1])
+    bracket = float((a[t_star] * s_vec).sum())
+    assert bracket > 0
+    n_star = 4242
+    assert n_star not in ei[0].tolist()
+    W[n_star] = (1.5 * v_k / bracket) * s_vec
+    b[n_star] = 0.0
+    W = W.contiguous()
+    ev, ei = _exact(ops, x, W, b, bd, k)
+    assert n_star in ei[t_star].tolist(), "construction: the row must be a member of the token's true top-k"
+    prepared = ops.prepare_encoder(W)
+
+    v8, i8, st8 = ops.encode_topk(x, W, b, bd, prepared, k, coarse_mode=1)
+    vb, ib, stb = ops.encode_topk(x, W, b, bd, prepared, k, coarse_mode=0)
+    vx, ix, stx = ops.encode_topk(x, W, b, bd, prepared, k, exact=True)
+    others = torch.ones(T, dtype=torch.bool, device=dev)
+    others[t_star] = False
+    print(f"\nresidual-aligned row: token {t_star}, int8 status {int(st8[t_star])}, row in int8 top-k: "
+          f"{n_star in i8[t_star].tolist()}, in bf16 top-k: {n_star in ib[t_star].tolist()}, exact: {n_star in ix[t_star].tolist()}")
+    # the exact switch and the bf16 pass: right everywhere
+    assert torch.equal(ix, ei) and torch.equal(vx, ev) and bool((stx == 1).all())
+    assert torch.equal(ib, ei) and torch.equal(vb, ev)
+    # the int8 pass: every other token right ...
+    assert torch.equal(i8[others], ei[others]) and torch.equal(v8[others], ev[others])
+    # ... and the token the row was built from: verified, and wrong -- the residual risk the contract names
+    assert int(st8[t_star]) == 0 and n_star not in i8[t_star].tolist()
+
+
+def test_stale_operand_groups_fall_back_to_the_exact_path(dev):
+    """msae_encoder_refresh_for(T_next > 128) leaves the fragment-major copies (the weight-stream kernels of
+    <= 128 tokens) stale, msae_encoder_refresh leaves the other coarse mode's operands stale.  The buffer records which
+    groups hold the current weights; an encode whose candidate pass would read a stale group computes ALL its tokens by
+    the exact path (deterministically -- not by the 6-sigma check's luck), one that reads fresh groups runs fused."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W, b, bd = hostile.weights("gauss", N, d, dev, seed=31)
+    prepared = ops.prepare_encoder(W)
+    g = torch.Generator(device=dev).manual_seed(32)
+    W2 = (W + 0.02 * torch.randn(N, d, generator=g, device=dev) / d ** 0.5).contiguous()   # "one optimiser step"
+    ops.prepare_encoder(W2, out=prepared, active_mode_only=True, tokens_next=2048)        # refresh for ONE large batch
+
+    def run(T, seed, **kw):
+        x = hostile.activations(T, d, dev, seed=seed)
+        v, i, st = ops.encode_topk(x, W2, b, bd, prepared, k, status_detail=True, **kw)
+        ev, ei = _exact(ops, x, W2, b, bd, k)
+        assert torch.equal(i, ei) and torch.equal(v, ev), T
+        return st
+
+    st = run(2048, 33)
+    assert int(((st & 0xFF) == 0).sum()) > 0.95 * 2048             # tile-major operands are fresh: fused
+    for T in (64, 128, 17, 8, 2):                                  # weight-stream / MFMA-stream kernels: stale copies
+        st = run(T, 34 + T)
+        assert bool(((st & 0xFF) == 1).all()), (T, st.tolist()[:8])
+    st = run(1, 35)                                                # the S = 1 stream reads the row-major copy: fresh
+    assert int(st[0]) == 0
+    # a refresh in the bf16 mode leaves every int8 group stale
+    ops.set_coarse_mode("bf16")
+    try:
+        ops.prepare_encoder(W2, out=prepared, active_mode_only=True)
+        st = run(2048, 36)
+        assert int(((st & 0xFF) == 0).sum()) > 0.95 * 2048
+    finally:
+        ops.set_coarse_mode("int8")
+    st = run(2048, 37)
+    assert bool(((st & 0xFF) == 1).all()) and bool((((st >> 8) & 128) != 0).all())
+    ops.prepare_encoder(W2, out=prepared)                          # a full prepare restores everything
+    assert int(((run(64, 38) & 0xFF) == 0).sum()) >= 60 and int(((run(2048, 39) & 0xFF) == 0).sum()) > 0.95 * 2048
