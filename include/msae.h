@@ -136,8 +136,8 @@ int msae_encoder_refresh(const float *W_enc, int N, int d, void *prepared, const
  * its tokens by the exact path instead (status 1; reason 128 with status_detail) -- stale operands cost time, never a
  * wrong top-k.
  * The same for ONE following encode of T_next tokens (the training loop, train/sae/sae/trainer.py:347-401: the weights change
- * before the buffer is read again): a batch of more than 128 tokens does not read the copies the small-batch kernels use,
- * and they are left stale (a later encode of <= 128 tokens falls back to the exact path until the next refresh / prepare). */
+ * before the buffer is read again): a batch of more than 256 tokens does not read the copies the small-batch kernels use,
+ * and they are left stale (a later encode of <= 256 tokens falls back to the exact path until the next refresh / prepare). */
 int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, int T_next, const msae_options *opts,
                              void *stream);
 

@@ -2068,9 +2068,9 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     // issue: tile-major + stagger measured 2-3 % slower there (profiles/r03_ab_small_T.txt)
     const int tile_major = pl.Tp > G_BM ? gemm_layout() : 0;
     // up to 128 tokens: the weight-stream kernel (gemm_skinny.h) runs both candidate passes: xq row-major, Wq fragment-major
-    if (T <= 128 && tile_major == 0 && gemm_layout() == 1 && d % 1024 == 0 && N % (SAMPLE_STRIDE * 256) == 0 &&
+    if (T <= 256 && tile_major == 0 && gemm_layout() == 1 && d % 1024 == 0 && N % (SAMPLE_STRIDE * 256) == 0 &&
         getenv("MSAE_NO_SKINNY") == nullptr)
-      skinny = T <= 64 ? 64 : 128;
+      skinny = T <= 64 ? 64 : (T <= 128 ? 128 : 256);
     const bool w_packed = tile_major == 1 || skinny != 0;   // the W side of the candidate passes reads the tile-major copies
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
@@ -2133,6 +2133,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #else
     const int grc = skinny == 64    ? gemm_skinny_launch<64, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 128 ? gemm_skinny_launch<128, true>(op_samp, T, d, pl.S, ep, s)
+                    : skinny == 256 ? gemm_skinny_launch<256, true>(op_samp, T, d, pl.S, ep, s)
                     : pl.i8         ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
                                     : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
 #endif
@@ -2181,6 +2182,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 #else
     const int grc = skinny == 64    ? gemm_skinny_launch<64, false>(op_main, T, d, N_main, ep, s)
                     : skinny == 128 ? gemm_skinny_launch<128, false>(op_main, T, d, N_main, ep, s)
+                    : skinny == 256 ? gemm_skinny_launch<256, false>(op_main, T, d, N_main, ep, s)
                     : pl.i8         ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s)
                                     : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
 #endif
@@ -2352,14 +2354,14 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
 }
 
-// ... for an encode of T_next tokens that follows: a batch of more than 128 tokens does not read the fragment-major copies (0.5 GB
+// ... for an encode of T_next tokens that follows: a batch of more than 256 tokens does not read the fragment-major copies (0.5 GB
 // of scattered 16-byte stores per refresh at C2).  The buffer must be refreshed again before an encode of fewer tokens.
 extern "C" int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, int T_next, const msae_options *opts,
                                         void *stream) {
   CallOpts co;
   if (!resolve_opts(opts, co) || T_next <= 0) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
-  return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 128 ? 4 : 0), (hipStream_t)stream);
+  return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0), (hipStream_t)stream);
 }
 
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts) {
@@ -2409,7 +2411,8 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
     return MSAE_EALIGN;
   if (co.exact) {   // msae_options::exact: every token through the in-call exact path (bounded scratch, status 1)
     int *flagged = reinterpret_cast<int *>(wsb + pl.off_flag);
-    hipLaunchKernelGGL(iota_list_kernel, dim3((T + 255) / 256), dim3(256), 0, s, flagged, T, T + 64 + pl.fb_chunks);
+    const int n_list = T + 64 + pl.fb_chunks;
+    hipLaunchKernelGGL(iota_list_kernel, dim3((n_list + 255) / 256), dim3(256), 0, s, flagged, T, n_list);
     int rc;
     switch (x_dtype) {
       case MSAE_F32: rc = run_exact_fallback<MSAE_F32>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, 0, s); break;

@@ -1,4 +1,4 @@
-// gemm_skinny.h -- the candidate pass for ONE row of output tiles with few tokens (T <= 128): a weight STREAM.
+// gemm_skinny.h -- the candidate pass for ONE row of output tiles with few tokens (T <= 256): a weight STREAM.
 //
 // gemm_mfma.h keeps one 64-KB k-tile in flight per CU (2-slot LDS ring).  That is what a compute-bound 256 x 256 tile
 // wants; a batch of 17 ... 128 tokens is bound by the HBM latency of Wq instead: its single row of output tiles
@@ -50,8 +50,9 @@ struct SkinnyCfg {
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 128 * NW_;                // ~0.5 % of BM x BN outputs pass the hot loop's bound
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
-  static constexpr int UN = BM_ > 64 ? MSAE_SK_UN / 2 : MSAE_SK_UN;   // k-steps (64 B of k each) per B batch (registers: 8 UN per batch)
-  static_assert(BM % 32 == 0 && BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
+  // k-steps (64 B of k each) per B batch (registers: 8 UN per batch; the accumulators take BM / 2 of the wave's budget)
+  static constexpr int UN = BM_ > 128 ? MSAE_SK_UN / 4 : (BM_ > 64 ? MSAE_SK_UN / 2 : MSAE_SK_UN);
+  static_assert(UN >= 1 && BM % 32 == 0 && BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static_assert(KC % (2 * UN * 64) == 0, "a chunk is a whole number of B double-batches");
   static_assert(LDS_BYTES <= (NW_ == 4 ? 80 : 160) * 1024, "LDS budget");
 };
@@ -63,6 +64,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int n0 = blockIdx.x * C::BN;
   constexpr int UN = C::UN;
+  // token tile blockIdx.y (the sample pass of 129 ... 256 tokens runs two 128-token tiles per feature block: twice the
+  // workgroups on a launch that has few, and its 16 MB of weights are cheap to stream twice)
+  const int m0 = blockIdx.y * C::BM;
+  T = T - m0 < C::BM ? T - m0 : C::BM;                 // tokens of THIS tile
+  op.A += (size_t)m0 * op.ldA;
+  if (op.Ao) op.Ao += (size_t)m0 * 128;
 
   // ---- epilogue constants of this tile's rows / columns (registers now, LDS after the k-loop; as gemm_kernel)
   float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
@@ -73,11 +80,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   if (tid < C::BM) {
     const int t = tid;
     if constexpr (!DENSE) {
-      const float v = (t < T) ? ep.tau_vals[(size_t)t * ep.tau_ld + ep.tau_col] : 0.f;
+      const float v = (t < T) ? ep.tau_vals[(size_t)(m0 + t) * ep.tau_ld + ep.tau_col] : 0.f;
       side0 = (v > 0.f) ? v : __builtin_inff();       // degenerate / padded token: emit nothing
     }
     if (t < T) {
-      const f32x4 rc = ep.rowc[t];
+      const f32x4 rc = ep.rowc[m0 + t];
       side1 = rc[0];
       side3 = rc[2];
       side4 = 1.f;
@@ -238,22 +245,29 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   f32x16 acc[C::MI][1];
   {
     constexpr int TP = C::BN + 4;                        // row pitch in ints: the 4 row groups of a store land 16 banks apart
-    static_assert(C::BM * TP * 4 <= C::LDS_RING_BYTES, "tile image fits the A buffers");
+    // the image of 128 token rows at a time (BM = 256: two halves through the same LDS)
+    constexpr int HR = C::BM < 128 ? C::BM : 128, NH = C::BM / HR;
+    static_assert(HR * TP * 4 <= C::LDS_RING_BYTES, "tile image fits the A buffers");
     int *timg = reinterpret_cast<int *>(smem);
-    __syncthreads();                                     // every wave is done with the A buffers
 #pragma unroll
-    for (int tg = 0; tg < TG; ++tg)
+    for (int h = 0; h < NH; ++h) {
+      __syncthreads();                                   // every wave is done with the A buffers / the previous half
 #pragma unroll
-      for (int fg = 0; fg < 2; ++fg)
+      for (int tg = h * (HR / 16); tg < (h + 1) * (HR / 16); ++tg)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) timg[(tg * 16 + lg * 4 + r) * TP + wave * 32 + fg * 16 + l15] = acc16[tg][fg][r];
-    __syncthreads();
+        for (int fg = 0; fg < 2; ++fg)
 #pragma unroll
-    for (int i = 0; i < C::MI; ++i) {
-      i32x16 v;
+          for (int r = 0; r < 4; ++r)
+            timg[((tg - h * (HR / 16)) * 16 + lg * 4 + r) * TP + wave * 32 + fg * 16 + l15] = acc16[tg][fg][r];
+      __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = timg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * TP + wave * 32 + l31];
-      acc[i][0] = __builtin_bit_cast(f32x16, v);
+      for (int i = h * (HR / 32); i < (h + 1) * (HR / 32); ++i) {
+        i32x16 v;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          v[e] = timg[((i - h * (HR / 32)) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * TP + wave * 32 + l31];
+        acc[i][0] = __builtin_bit_cast(f32x16, v);
+      }
     }
   }
 
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
     }
     side[5 * C::NT + tid] = side5;
   }
-  gemm_epilogue<C, DENSE>(acc, ep, T, 0, n0, 0, wave, lane, smem, side, [] {});
+  gemm_epilogue<C, DENSE>(acc, ep, m0 + T, m0, n0, 0, wave, lane, smem, side, [] {});
 }
 
 // Host launcher: A = xq row-major [>= BM rows][d]; B = Wq fragment-major (op.packed = 3); optional
@@ -285,17 +299,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
 template <int BM, int NW, bool DENSE>
 inline int gemm_skinny_launch_nw(const GemmOperands &op, int T, int d, int N, const GemmEpilogue &ep, hipStream_t s) {
   using C = SkinnyCfg<BM, NW>;
-  if (T > BM || N % C::BN || d % C::KC || op.packed != 3 || op.ldA != (size_t)d) return MSAE_EINVAL;
+  const int m_tiles = (T + BM - 1) / BM;               // token tiles (A must hold m_tiles * BM rows)
+  if (T <= 0 || m_tiles > 2 || N % C::BN || d % C::KC || op.packed != 3 || op.ldA != (size_t)d) return MSAE_EINVAL;
   auto kern = gemm_skinny_kernel<BM, NW, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-  hipLaunchKernelGGL(kern, dim3(N / C::BN), dim3(C::NT), C::LDS_BYTES, s, op, T, d, ep);
+  hipLaunchKernelGGL(kern, dim3(N / C::BN, m_tiles), dim3(C::NT), C::LDS_BYTES, s, op, T, d, ep);
   return (int)hipGetLastError();
 }
 // The sample pass (DENSE, few tiles) runs 4-wave workgroups, two per CU: twice the workgroups and their prologue / epilogue
 // phases overlap.  The main pass (THRESH) runs one 8-wave workgroup per CU: every workgroup streams the tokens' rows (xq, out
 // of L2) once per 32 features of each wave, so wider workgroups halve that traffic (T = 64: 0.139 -> 0.129 ms).
+// 129 ... 256 tokens (BM = 256): the main pass keeps ONE tile of 256 tokens per feature block (Wq from HBM once: 16 token groups x
+// 2 feature groups of accumulators per wave, a 256-byte A chunk, B batches of one k-step); the sample pass runs the 128-token
+// kernel on two token tiles.
 template <int BM, bool DENSE>
 inline int gemm_skinny_launch(const GemmOperands &op, int T, int d, int N, const GemmEpilogue &ep, hipStream_t s) {
-  if (DENSE) return gemm_skinny_launch_nw<BM, 4, DENSE>(op, T, d, N, ep, s);
-  return gemm_skinny_launch_nw<BM, 8, DENSE>(op, T, d, N, ep, s);
+  if constexpr (DENSE) return gemm_skinny_launch_nw<(BM > 128 ? 128 : BM), 4, DENSE>(op, T, d, N, ep, s);
+  else return gemm_skinny_launch_nw<BM, 8, DENSE>(op, T, d, N, ep, s);
 }

@@ -342,14 +342,16 @@ def test_fused_encode_hook_edits(dev, coarse):
     assert torch.equal(i, ei) and torch.equal(v, ev)
 
 
-@pytest.mark.parametrize("T", [17, 40, 64, 65, 100, 128, 129])
-def test_weight_stream_kernel_batches(dev, T):
-    """17 ... 128 tokens: both candidate passes run on the weight-stream kernel (csrc/gemm_skinny.h: 64- / 128-token tiles,
-    fragment-major Wq, the sample features' candidates from the sample pass); 129 is the first batch back on the 256-row
-    tiles.  Outputs == the exact path, with and without hook edits (a hot sample feature included)."""
+@pytest.mark.parametrize("T,d", [(17, 1024), (40, 1024), (64, 1024), (65, 1024), (100, 1024), (128, 1024), (129, 1024),
+                                 (192, 1024), (255, 1024), (256, 1024), (257, 1024), (200, 4096), (256, 4096)])
+def test_weight_stream_kernel_batches(dev, T, d):
+    """17 ... 256 tokens: both candidate passes run on the weight-stream kernel (csrc/gemm_skinny.h: 64- / 128- / 256-token
+    tiles -- the sample pass of 129 ... 256 tokens as two 128-token tiles --, fragment-major Wq, the sample features'
+    candidates from the sample pass); 257 is the first batch on gemm_mfma.h's 256-row tiles.  Outputs == the exact path,
+    with and without hook edits (a hot sample feature included)."""
     from msae import ops
 
-    d, N, k = 1024, 16384, 32
+    N, k = 16384, 32
     W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 31)
     x = _rand_x(dev, T, d, 32 + T)
     prepared = ops.prepare_encoder(W_enc)

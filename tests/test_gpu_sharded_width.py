@@ -56,6 +56,7 @@ def c2(dev):
         sae.encoder.weight.copy_(W); sae.encoder.bias.copy_(b); sae.b_dec.copy_(bd)
         sae.W_dec.copy_(W / (W.norm(dim=1, keepdim=True) + 1e-6))
     del W
+    sae.requires_grad_(False)
     prepared = ops.prepare_encoder(sae.encoder.weight)
     single = {}
     for k in (32, 256):
