@@ -1,0 +1,166 @@
+// encode_defs.h -- constants, the prepared-encoder layout, per-call options and the error-band arithmetic shared by the kernels
+// of the fused encoder (encode_prep.h, encode_rescore.h, encode_small.h) and its host dispatch (encode_fused.hip).
+#pragma once
+#include <cstddef>
+#include <cstdlib>
+
+#include "common.h"
+#include "tuning.h"
+
+namespace {
+
+constexpr int SAMPLE_STRIDE = 32, SAMPLE_OFF = 13;
+// Tokens one pass of the in-call exact fallback absorbs: its dense scratch rows are budgeted at 1 GiB
+// (2048 rows at N = 131072), never fewer than 128 and never more than the call has tokens.  The
+// exact kernels take the flagged count from device memory and loop over it; ceil(T / capacity) passes
+// are enqueued (the ones without work exit at once), so EVERY flagged token is recomputed inside the
+// call whatever their number -- no host round trip, no "unresolved" leftovers.
+constexpr size_t FB_BUDGET_BYTES = (size_t)1 << 30;
+inline int fallback_capacity(int T, int N) {
+  size_t cap = FB_BUDGET_BYTES / ((size_t)N * 4);
+  const size_t t128 = ((size_t)T + 127) / 128 * 128;
+  if (cap > t128) cap = t128;
+  if (cap < 128) cap = 128;
+  return (int)(cap / 128 * 128);
+}
+constexpr int EXACT_T_MAX = 0;      // fused path for every T (T=1: 1 GiB bf16 stream beats the f32 tile 4x)
+
+// ---- prepared encoder ------------------------------------------------------------------------
+struct Prepared {
+  unsigned magic;
+  int N, d, S;
+  size_t off_wb, off_ws, off_wstat, off_wstat_s, off_colbf, off_colbf_s, off_wq, off_wqs, off_wqp, off_wqsp, off_wqf, off_wqsf, bytes;
+  // Which operand groups hold the CURRENT weights (PREP_* bits).  msae_encoder_refresh[_for] rebuilds only what the following
+  // encode reads and clears the bits of everything else; every fused path's prep kernel tests the bits of the operands ITS
+  // candidate pass is about to read and, when one is missing, hands all its tokens to the exact path (reason 128) -- stale
+  // operands cost time, never a wrong top-k, and nothing about them lives on the host.
+  unsigned valid;
+};
+constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
+constexpr unsigned PREP_BF16 = 1u;   // W_bf16 + bf16 sample rows
+constexpr unsigned PREP_I8 = 2u;     // Wq row-major, tile-major (+ sample copies)
+constexpr unsigned PREP_FRAG = 4u;   // Wq fragment-major (+ sample copy): the weight-stream kernels of <= 128 tokens
+
+__host__ __device__ inline bool fast_shape_ok(int N, int d) {
+  return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/32 must tile by BN = 256
+}
+__host__ __device__ inline bool i8_shape_ok(int N, int d) { return fast_shape_ok(N, d) && d % 128 == 0; }
+
+// The tile-major operand of the main candidate pass leaves the sample rows out (the sample pass has scored them: their
+// candidates are taken from its output, sample_push_kernel): -1/32 of the pass's matrix work and operand traffic.  Row n of W
+// (n not a sample row) is row main_row(n) of that operand; column c of the pass is feature gemm_feature(c).  31/32 N tiles by
+// 256 whenever the sample width does (fast_shape_ok).  (tuning.h: MSAE_FULL_MAIN_PASS keeps all rows in.)
+constexpr bool MAIN_SKIPS_SAMPLE = msae_tuning::MAIN_SKIPS_SAMPLE;
+__host__ __device__ inline int main_row(int n) { return n - n / SAMPLE_STRIDE - ((n % SAMPLE_STRIDE) > SAMPLE_OFF ? 1 : 0); }
+
+// 256-B header | W_bf16 [N][d] | sample rows bf16 [S][d] | row statistics (sw, Q_i8, |W_n|^2, Q_bf) f32x4 [N]
+// and [S] | bf16-pass column constants (1, Q_bf, 0, 0) f32x4 [N] and [S] | Wq int8 [N][d] | sample int8 [S][d]
+// | Wq fragment-major [N/16][d/64][64 lanes][16 B] | sample fragment-major (the weight-stream kernel's operand, gemm_skinny.h)
+// | Wq tile-major [N/256][d/128][256][128] | sample tile-major (the candidate GEMM's operands, gemm_mfma.h; the
+// row-major copies feed the S = 1 weight streams and the outlier-column gather)
+inline Prepared make_prepared(int N, int d) {
+  Prepared p{};
+  p.magic = PREP_MAGIC;
+  p.N = N; p.d = d;
+  p.S = fast_shape_ok(N, d) ? N / SAMPLE_STRIDE : 0;
+  size_t o = 256;
+  auto take = [&](size_t b) { size_t at = o; o += msae_align_up(b, 256); return at; };
+  p.off_wb = take(p.S ? (size_t)N * d * 2 : 0);
+  p.off_ws = take((size_t)p.S * d * 2);
+  const bool q = p.S && i8_shape_ok(N, d);
+  p.off_wstat = take(p.S ? (size_t)N * 16 : 0);
+  p.off_wstat_s = take((size_t)p.S * 16);
+  p.off_colbf = take(p.S ? (size_t)N * 16 : 0);
+  p.off_colbf_s = take((size_t)p.S * 16);
+  p.off_wq = take(q ? (size_t)N * d : 0);
+  p.off_wqs = take(q ? (size_t)p.S * d : 0);
+  p.off_wqp = take(q ? (size_t)N * d : 0);
+  p.off_wqsp = take(q ? (size_t)p.S * d : 0);
+  p.off_wqf = take(q ? (size_t)N * d : 0);
+  p.off_wqsf = take(q ? (size_t)p.S * d : 0);
+  p.bytes = o;
+  return p;
+}
+
+// ---- per-call options (msae_options, include/msae.h), resolved once per entry-point call.  The library holds no
+// mutable state: the environment only supplies DEFAULTS (read at the call, never cached), everything else travels
+// with the call.
+struct ProfState;
+struct CallOpts {
+  int mode;          // coarse-pass operand type: 0 = bf16, 1 = int8
+  float z;           // width of the error band: u = coarse + z*sigma
+  int detail;        // status = 1 | reason << 8 for tokens recomputed in the call
+  ProfState *prof;   // stage timing handle or null
+  int exact;         // every token by the exact path (msae_options::exact)
+  int32_t *rows_out; // per-token re-score statistics (msae_options::rows_rescored) or null
+};
+inline bool resolve_opts(const msae_options *o, CallOpts &c) {
+  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr; c.exact = 0; c.rows_out = nullptr;
+  if (o) {
+    // `size` is the caller's sizeof: a caller compiled against ABI 2's header (no `exact`) is served with exact = 0
+    if (o->size < offsetof(msae_options, exact)) return false;
+    c.mode = o->coarse_mode; c.z = o->guard_z; c.detail = o->status_detail ? 1 : 0;
+    c.prof = static_cast<ProfState *>(o->profile);
+    if (o->size >= offsetof(msae_options, exact) + sizeof(int32_t)) c.exact = o->exact ? 1 : 0;
+    if (o->size >= offsetof(msae_options, rows_rescored) + sizeof(void *)) c.rows_out = o->rows_rescored;
+  }
+  if (c.mode < 0) {
+    const char *e = getenv("MSAE_COARSE");
+    c.mode = (e && e[0] == 'b') ? 0 : 1;
+  }
+  if (c.mode != 0 && c.mode != 1) return false;
+  if (c.z == 0.f) {
+    const char *e = getenv("MSAE_GUARD_Z");
+    const float v = e ? (float)atof(e) : 0.f;
+    c.z = (v >= 0.25f && v <= 64.f) ? v : 7.f;
+  }
+  return c.z >= 0.25f && c.z <= 64.f;
+}
+
+unsigned long long *g_timeline = nullptr;   // tuning builds only (msae_tuning::GEMM_TIMELINE)
+constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
+// Deterministic per-token guard of the int8 pass.  The x-side residual is modelled as independent rounding
+// noise of variance sx^2 / 12 per dim.  The dims that round to ZERO are the exception: their residual is the
+// activation itself, i.e. structured -- a feature whose weights correlate with that part of the token (cosine c) is off by
+// up to c sqrt(E0) |W_n|, E0 = their energy, against an x-side band of z sx |W_n| / sqrt(12) = 2.02 sx |W_n| at the default
+// z = 7.  For a well-scaled Gaussian token sqrt(E0) = 2.06 sx (one band); a token whose scale is dictated by an isolated
+// large dim that the batch-level outlier list did not take rounds most of its dims to zero and sqrt(E0) approaches the
+// token's whole norm.  Tokens with sqrt(E0) > GUARD_E0_SX * sx (4 default bands: a feature would need a cosine above
+// 0.25 with the zeroed part to leave its band) are not trusted to the statistical model: they are flagged (reason 128)
+// and recomputed by the exact path inside the call.  The test does not move with msae_options::guard_z.
+constexpr float GUARD_E0_SX = 4.f * 7.f * 0.288675f;   // 4 bands of z = 7: 8.08
+constexpr float GUARD_ZETA = MSAE_GUARD_ZETA;   // first round reaches zeta sigma below the k-th coarse value
+constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
+
+// index output of one call: 32-bit (msae_encode_topk), 64-bit (msae_encode_topk_i64), never both null
+struct IdxOut { int32_t *i32; int64_t *i64; };
+
+// z^2 sigma^2 of one (token, feature) pair; rc = (sx, m, P, -), cc = (sw, Q, Si, So).  Same expression as the
+// GEMM epilogue (gemm_mfma.h).
+__device__ __forceinline__ float band_sq(const f32x4 rc, const f32x4 cc, float zz12, bool i8) {
+  if (!i8) return rc[2] * cc[1];
+  const float rz = rc[0] * rc[0] * zz12;
+  return __builtin_fmaf(rc[2], cc[1], __builtin_fmaf(rz * rc[1] * rc[1], cc[3], rz * cc[2]));
+}
+
+// ---- per-row statistics + int8 operands ---------------------------------------------------------------
+// Tile-major int8 operand of the candidate GEMM (GemmOperands::packed): byte offset of the 16-B chunk at column c
+// (c % 16 == 0) of row r, with the LDS image's chunk permutation applied (gemm_swz).  d % 128 == 0.
+__host__ __device__ __forceinline__ size_t packed_off(size_t r, int c, int d, int layout = 1) {
+  (void)layout;
+  const size_t rt = r >> 8, ri = r & 255;
+  const int kt = c >> 7, ch = (c >> 4) & 7;
+  return ((rt * (size_t)(d >> 7) + kt) * 256 + ri) * 128 + (size_t)((ch ^ (int)((ri >> 1) & 7)) << 4);
+}
+// Fragment-major int8 operand of the weight-stream kernel (gemm_skinny.h): the 16 B at column c (c % 16 == 0) of row r sit where
+// lane 16 ((c % 64) / 16) + r % 16 of a v_mfma_i32_16x16x64_i8 B fragment reads them -- one k-step of a 16-row block is ONE
+// contiguous kilobyte, lane l at byte 16 l.
+__host__ __device__ __forceinline__ size_t frag_off(size_t r, int c, int d) {
+  return ((((r >> 4) * (size_t)(d >> 6) + (size_t)(c >> 6)) << 6) + (size_t)((((c >> 4) & 3) << 4) + (int)(r & 15))) << 4;
+}
+// which operand layout the candidate GEMM reads: 1 = tile-major, 128-byte k-tiles in a 2-slot ring (default); 0 =
+// row-major (environment MSAE_GEMM_ROWMAJOR=1, for A/B runs).  Read at every call: an immutable property of the process
+// environment (prepare and encode must agree).
+inline int gemm_layout() { return getenv("MSAE_GEMM_ROWMAJOR") ? 0 : 1; }
+
+}  // namespace

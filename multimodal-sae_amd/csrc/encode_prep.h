@@ -1,0 +1,486 @@
+// encode_prep.h -- kernels in front of the candidate GEMM of the fused encoder: weight preparation (bf16 copy, per-row
+// statistics, int8 operands in three layouts), per-call activation preparation (a32 = x - b_dec, column maxima, outlier
+// dims, per-token int8 quantisation + band constants, outlier tile of Wq), the sample features' candidates, list compaction.
+// Host dispatch: encode_fused.hip.
+#pragma once
+#include "encode_defs.h"
+
+namespace {
+
+// W_bf16[n][c] = bf16(W[n][c]); sample row j = row j*SAMPLE_STRIDE + SAMPLE_OFF.  grid-stride over 8-element groups.
+__global__ __launch_bounds__(256) void prepare_weights_kernel(const float *__restrict__ W, int N,
+                                                              int d, unsigned short *__restrict__ wb,
+                                                              unsigned short *__restrict__ ws) {
+  const size_t groups = (size_t)N * d / 8;
+  for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (size_t)gridDim.x * 256) {
+    const size_t e = g * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(W + e);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(W + e + 4);
+    u16x8 o;
+    o[0] = f32_to_bf16_bits(a[0]); o[1] = f32_to_bf16_bits(a[1]);
+    o[2] = f32_to_bf16_bits(a[2]); o[3] = f32_to_bf16_bits(a[3]);
+    o[4] = f32_to_bf16_bits(b[0]); o[5] = f32_to_bf16_bits(b[1]);
+    o[6] = f32_to_bf16_bits(b[2]); o[7] = f32_to_bf16_bits(b[3]);
+    *reinterpret_cast<u16x8 *>(wb + e) = o;
+    const size_t n = e / d, c = e % d;
+    if (n % SAMPLE_STRIDE == SAMPLE_OFF)
+      *reinterpret_cast<u16x8 *>(ws + (n / SAMPLE_STRIDE) * d + c) = o;
+  }
+}
+
+// a32[t][c] = (float)x[t][c] - b_dec[c] (the exact f32 SAE input, sae.py:174) and
+// xb[t][c] = bf16(a32[t][c]) for t < T; xb rows up to Tp are zero.
+template <int DT>
+__global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
+                                                     const float *__restrict__ b_dec, int T, int Tp,
+                                                     int d, unsigned short *__restrict__ xb,
+                                                     float *__restrict__ a32) {
+  const size_t groups = (size_t)Tp * d / 4;
+  for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (size_t)gridDim.x * 256) {
+    const size_t e = g * 4;
+    const size_t t = e / d, c = e % d;
+    u16x4 o = {0, 0, 0, 0};
+    if ((int)t < T) {
+      f32x4 v = load_x4<DT>(x, e);
+      if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+      *reinterpret_cast<f32x4 *>(a32 + e) = v;
+      o[0] = f32_to_bf16_bits(v[0]); o[1] = f32_to_bf16_bits(v[1]);
+      o[2] = f32_to_bf16_bits(v[2]); o[3] = f32_to_bf16_bits(v[3]);
+    }
+    if (xb) *reinterpret_cast<u16x4 *>(xb + e) = o;   // the int8 coarse pass quantises a32 itself
+  }
+}
+
+// W side (once per weight load), one 256-thread workgroup per row:
+//   sw[n] = max|W[n][:]| / 127,  |W_n|^2,  |W_n|_4^2 = sqrt(sum w^4)   -> wstat[n] = (sw, Q_i8, |W_n|^2, Q_bf)
+//   Wq[n][c] = rint(W[n][c] / sw[n])   (QUANT; d % 128 == 0)
+// A row whose rms lies below one step (max > 127 rms: its bulk quantises to 0, +-1) would leave a
+// STRUCTURED residual (the bulk itself), so such rows are rounded stochastically with a hash dither:
+// floor(s + r(n, c)), r uniform in [0, 1) -- unbiased for any activation direction, residual variance
+// <= 1/4 step^2 instead of 1/12: Q_i8 = 3 sw^2 for them.
+__device__ __forceinline__ float hash01(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
+}
+template <bool QUANT>
+__global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__restrict__ W, int N, int d,
+                                                              f32x4 *__restrict__ wstat, f32x4 *__restrict__ wstat_s,
+                                                              f32x4 *__restrict__ colbf, f32x4 *__restrict__ colbf_s,
+                                                              signed char *__restrict__ wq,
+                                                              signed char *__restrict__ wqs,
+                                                              signed char *__restrict__ wqp,
+                                                              signed char *__restrict__ wqsp,
+                                                              signed char *__restrict__ wqf,
+                                                              signed char *__restrict__ wqsf, int layout) {
+  __shared__ float red[3][4];
+  const int n = blockIdx.x;
+  const float *row = W + (size_t)n * d;
+  float m = 0.f, s2 = 0.f, s4 = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float q = v[e] * v[e];
+      m = fmaxf(m, fabsf(v[e]));
+      s2 += q;
+      s4 = __builtin_fmaf(q, q, s4);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, off, 64));
+    s2 += __shfl_xor(s2, off, 64);
+    s4 += __shfl_xor(s4, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s4; }
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  s4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  const float scale = m > 0.f ? m / 127.f : 0.f;          // an all-zero row: coarse value = bias exactly, no band
+  const bool dither = s2 < scale * scale * (float)d;       // rms below one step
+  const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
+  if (threadIdx.x == 0) {
+    const float q_bf = __builtin_sqrtf(s4);
+    const f32x4 st = {scale, scale * scale * (dither ? 3.f : 1.f), s2, q_bf};
+    const f32x4 cb = {1.f, q_bf, 0.f, 0.f};
+    wstat[n] = st;
+    colbf[n] = cb;
+    if (samp) { wstat_s[n / SAMPLE_STRIDE] = st; colbf_s[n / SAMPLE_STRIDE] = cb; }
+  }
+  if constexpr (QUANT) {
+    const float inv = m > 0.f ? 1.f / scale : 0.f;
+    for (int c = threadIdx.x * 16; c < d; c += 4096) {
+      i32x4 packed;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q);
+        unsigned w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sv = v[e] * inv;
+          int iv = dither ? (int)floorf(sv + hash01((unsigned long long)n * (unsigned)d + (unsigned)(c + 4 * q + e)))
+                          : (int)rintf(sv);
+          iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
+          w |= ((unsigned)iv & 0xFFu) << (8 * e);
+        }
+        packed[q] = (int)w;
+      }
+      *reinterpret_cast<i32x4 *>(wq + (size_t)n * d + c) = packed;
+      if (layout == 1 && MAIN_SKIPS_SAMPLE) {
+        if (!samp) *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)main_row(n), c, d, 1)) = packed;
+      } else {
+        *reinterpret_cast<i32x4 *>(wqp + packed_off((size_t)n, c, d, layout)) = packed;
+      }
+      if (wqf) {                                   // (null: msae_encoder_refresh_for a large batch)
+        if (MAIN_SKIPS_SAMPLE) { if (!samp) *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)main_row(n), c, d)) = packed; }
+        else *reinterpret_cast<i32x4 *>(wqf + frag_off((size_t)n, c, d)) = packed;
+      }
+      if (samp) {
+        *reinterpret_cast<i32x4 *>(wqs + (size_t)(n / SAMPLE_STRIDE) * d + c) = packed;
+        *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
+        if (wqsf) *reinterpret_cast<i32x4 *>(wqsf + frag_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
+      }
+    }
+  }
+}
+
+// x side (every call).  Massive-activation dims would dictate the per-token scale and wipe out
+// the resolution of all other dims, so they are split off: colmax -> outlier dim list ->
+// per-token quantisation with the outliers in their own 128-wide k-tile at scale m[t]*sx[t].
+// int8 pass: prep_x and colmax in one sweep -- a thread owns four columns (b_dec in registers) and walks its
+// rows: a32 = x - b_dec is written once and never read back for the maxima.
+constexpr int COLMAX_PARTS = 8;   // copies of the column maxima (see prep_colmax_kernel)
+template <int DT, bool WRITE_A32>
+__global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
+                                                          int T, int d, float *__restrict__ a32,
+                                                          unsigned *__restrict__ colmax_bits) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= d) return;
+  const int rows_per = (T + gridDim.y - 1) / gridDim.y;
+  const int t0 = blockIdx.y * rows_per, t1 = min(T, t0 + rows_per);
+  const f32x4 bd = b_dec ? *reinterpret_cast<const f32x4 *>(b_dec + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int t = t0; t < t1; ++t) {
+    f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
+    if (b_dec) v = v - bd;
+    if constexpr (WRITE_A32) *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
+    m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
+    m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
+  }
+  // (blockIdx.y % COLMAX_PARTS: one copy of the maxima for all row chunks means T / 16 atomics on every column's word -- hundreds of
+  // same-address atomics, ~45 ns each: 20 us of this 60 us kernel at T = 8192; pick_outliers_kernel folds the copies)
+  unsigned *cm = colmax_bits + (size_t)(blockIdx.y % COLMAX_PARTS) * d;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) atomicMax(cm + c + e, __float_as_uint(m[e]));  // values >= 0
+}
+
+constexpr int MAX_OUT = 128;   // outlier dims fit one int8 k-tile
+// single workgroup: dims whose column max exceeds 8x the mean column max (threshold raised until
+// at most MAX_OUT qualify).  odims[0..MAX_OUT) = dim or -1, is_out[d] byte flags.
+__global__ __launch_bounds__(1024) void pick_outliers_kernel(unsigned *__restrict__ colmax_bits, int d,
+                                                             int *__restrict__ odims,
+                                                             unsigned char *__restrict__ is_out) {
+  __shared__ float red[16];
+  __shared__ int s_cnt;
+  for (int c = threadIdx.x; c < d; c += 1024) {          // fold the COLMAX_PARTS copies into the first (same thread reads it below)
+    unsigned m = colmax_bits[c];
+#pragma unroll
+    for (int q = 1; q < COLMAX_PARTS; ++q) { const unsigned v = colmax_bits[(size_t)q * d + c]; m = v > m ? v : m; }
+    colmax_bits[c] = m;
+  }
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < d; c += 1024) sum += __uint_as_float(colmax_bits[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  sum = 0.f;
+  for (int w = 0; w < 16; ++w) sum += red[w];
+  float thr = 8.f * sum / d;
+  for (int iter = 0; iter < 64; ++iter) {
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int c_loc = 0;
+    for (int c = threadIdx.x; c < d; c += 1024) c_loc += (__uint_as_float(colmax_bits[c]) > thr) ? 1 : 0;
+    if (c_loc) atomicAdd(&s_cnt, c_loc);
+    __syncthreads();
+    const int cnt = s_cnt;
+    __syncthreads();
+    if (cnt <= MAX_OUT) break;
+    thr *= 1.5f;
+  }
+  for (int j = threadIdx.x; j < MAX_OUT; j += 1024) odims[j] = -1;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 1024) {
+    const bool o = __uint_as_float(colmax_bits[c]) > thr;
+    is_out[c] = o ? 1 : 0;
+    if (o) odims[atomicAdd(&s_cnt, 1)] = c;   // order is irrelevant: A and B use the same list
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) odims[MAX_OUT] = s_cnt;   // the list is compact: the GEMM multiplies only ceil(count / 32) k-steps of the outlier tile
+}
+
+// one workgroup per token row (rows >= T of the padded tile are zero): per-token scales, int8 rows and
+// the row constants of the error band, rowc[t] = (sx, m, P = z^2 |a_t|^2 / 12, 0)
+// SRC = MSAE_F32 with x == a32 and b_dec == nullptr reads the prepared f32 activations; a shard of a feature-sharded
+// group (nobody re-scores there) reads x - b_dec straight from the input instead and never writes a32.
+template <int SRC, bool FROM_X>
+__global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x, const float *__restrict__ b_dec, int T, int d,
+                                                      const int *__restrict__ odims,
+                                                      const unsigned char *__restrict__ is_out,
+                                                      signed char *__restrict__ xq,
+                                                      signed char *__restrict__ xqo,
+                                                      f32x4 *__restrict__ rowc, float zz12, int tile_major,
+                                                      const unsigned *__restrict__ valid, unsigned need) {
+  __shared__ float red[3][4];
+  const int t = blockIdx.x;
+  auto xq_at = [&](int c) { return xq + (tile_major ? packed_off((size_t)t, c, d, tile_major) : (size_t)t * d + c); };
+  if (t >= T) {
+    for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(xq_at(c)) = i32x4{0, 0, 0, 0};
+    if (threadIdx.x < 8) *reinterpret_cast<i32x4 *>(xqo + (size_t)t * MAX_OUT + threadIdx.x * 16) = i32x4{0, 0, 0, 0};
+    if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
+    return;
+  }
+  const float *__restrict__ row32 = static_cast<const float *>(x) + (size_t)t * d;   // SRC == MSAE_F32 && !FROM_X: a32
+  auto load4 = [&](int c) {
+    if constexpr (!FROM_X) {
+      return *reinterpret_cast<const f32x4 *>(row32 + c);
+    } else {
+      f32x4 v = load_x4<SRC>(x, (size_t)t * d + c);
+      if (b_dec) v = v - *reinterpret_cast<const f32x4 *>(b_dec + c);
+      return v;
+    }
+  };
+  float m_in = 0.f, m_out = 0.f, ss = 0.f;
+  // a thread owns 16 consecutive dims of every 4096 (the 16 int8 it packs below); up to d = 8192 the row stays in registers
+  // between the two passes
+  constexpr int KEEP = 2;
+  f32x4 keep[KEEP][4];
+  unsigned keep_f[KEEP][4];
+  const bool resident = d <= KEEP * 4096;
+  {
+    int it = 0;
+    for (int c = threadIdx.x * 16; c < d; c += 4096, ++it) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = load4(c + 4 * q);
+        const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q);
+        if (resident && it < KEEP) {
+          if (it == 0) { keep[0][q] = v; keep_f[0][q] = flags; } else { keep[1][q] = v; keep_f[1][q] = flags; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = fabsf(v[e]);
+          ss = __builtin_fmaf(av, av, ss);
+          if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else m_in = fmaxf(m_in, av);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m_in = fmaxf(m_in, __shfl_xor(m_in, off, 64));
+    m_out = fmaxf(m_out, __shfl_xor(m_out, off, 64));
+    ss += __shfl_xor(ss, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m_in; red[1][threadIdx.x >> 6] = m_out; red[2][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  m_in = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  m_out = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  ss = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  const float scale = m_in > 0.f ? m_in / 127.f : (m_out > 0.f ? m_out / 127.f : 1.f);
+  int m = (int)ceilf(m_out / (127.f * scale));
+  m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
+  const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
+  float e0 = 0.f;                              // energy of the non-outlier dims that round to zero (GUARD_E0_BANDS)
+  int it2 = 0;
+  for (int c = threadIdx.x * 16; c < d; c += 4096, ++it2) {
+    i32x4 packed;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+      unsigned flags;
+      if (resident) { v = it2 == 0 ? keep[0][q] : keep[1][q]; flags = it2 == 0 ? keep_f[0][q] : keep_f[1][q]; }
+      else { v = load4(c + 4 * q); flags = *reinterpret_cast<const unsigned *>(is_out + c + 4 * q); }
+      unsigned w = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool outl = ((flags >> (8 * e)) & 0xFFu) != 0;
+        int iv = outl ? 0 : (int)rintf(v[e] * inv);
+        iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
+        e0 += (!outl && iv == 0) ? v[e] * v[e] : 0.f;
+        w |= ((unsigned)iv & 0xFFu) << (8 * e);
+      }
+      packed[q] = (int)w;
+    }
+    *reinterpret_cast<i32x4 *>(xq_at(c)) = packed;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) e0 += __shfl_xor(e0, off, 64);
+  __syncthreads();                             // red[] of the first reduction has been consumed
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = e0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    e0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    // (stale operands, Prepared::valid: the candidate pass would read old weights -- every token to the exact path)
+    const float guard = (e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale || (*valid & need) != need) ? 1.f : 0.f;
+    rowc[t] = f32x4{scale, (float)m, zz12 * ss, guard};
+  }
+  if (threadIdx.x < MAX_OUT) {
+    const int dim = odims[threadIdx.x];
+    float av = 0.f;
+    if (dim >= 0) {
+      if constexpr (!FROM_X) av = row32[dim];
+      else av = load_x1<SRC>(x, (size_t)t * d + dim) - (b_dec ? b_dec[dim] : 0.f);
+    }
+    int iv = dim >= 0 ? (int)rintf(av * inv_o) : 0;
+    iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
+    xqo[(size_t)t * MAX_OUT + threadIdx.x] = (signed char)iv;
+  }
+}
+
+// bf16 pass: rowc[t] = (1, 1, P = z^2 * 5.5e-6 * |a_t|_4^2, 0); one 256-thread workgroup per token
+__global__ __launch_bounds__(256) void row_p4_kernel(const float *__restrict__ a32, int T, int d,
+                                                     f32x4 *__restrict__ rowc, float z2,
+                                                     const unsigned *__restrict__ valid) {
+  __shared__ float red[4];
+  const int t = blockIdx.x;
+  const float *row = a32 + (size_t)t * d;
+  float s4 = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float q = v[e] * v[e]; s4 = __builtin_fmaf(q, q, s4); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s4 += __shfl_xor(s4, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s4;
+  __syncthreads();
+  s4 = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) rowc[t] = f32x4{1.f, 1.f, z2 * BF16_REL_VAR2 * __builtin_sqrtf(s4), (*valid & PREP_BF16) ? 0.f : 1.f};
+}
+
+// Wq_o[n][j] = Wq[n][odims[j]] (0 where odims[j] < 0) for every feature row, and for the sample rows;
+// with it the column constants of the error band for THIS batch's outlier dims:
+//   colc[n] = (sw, Q, Si = |W_n|^2 - So, So = sum over outlier dims of (sw Wq)^2)   (colc_p: the same in main_row order)
+__global__ __launch_bounds__(256) void gather_wo_kernel(const signed char *__restrict__ wq, int N, int d,
+                                                        const int *__restrict__ odims,
+                                                        const f32x4 *__restrict__ wstat,
+                                                        signed char *__restrict__ wqo,
+                                                        signed char *__restrict__ wqos,
+                                                        f32x4 *__restrict__ colc, f32x4 *__restrict__ colc_s,
+                                                        f32x4 *__restrict__ colc_p, int skip) {
+  __shared__ int s_dims[MAX_OUT];
+  if (threadIdx.x < MAX_OUT) s_dims[threadIdx.x] = odims[threadIdx.x];
+  __syncthreads();
+  const int n = blockIdx.x * 32 + (threadIdx.x >> 3);   // 8 threads per row, 16 bytes each (N % 32 == 0)
+  const int j0 = (threadIdx.x & 7) * 16;
+  // the tile is compact from column 0 and its readers stop after the k-steps that hold dims (32-B steps in gemm_mfma.h,
+  // 64-B steps in gemm_skinny.h): columns from ceil(n_out / 64) * 64 on are neither gathered nor written
+  const bool used = j0 < ((odims[MAX_OUT] + 63) & ~63);
+  i32x4 packed = {0, 0, 0, 0};
+  int sq = 0;
+#pragma unroll
+  for (int q = 0; q < 4 && used; ++q) {
+    unsigned w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int dim = s_dims[j0 + 4 * q + e];
+      const int v = dim >= 0 ? (int)wq[(size_t)n * d + dim] : 0;
+      sq += v * v;
+      w |= ((unsigned)v & 0xFFu) << (8 * e);
+    }
+    packed[q] = (int)w;
+  }
+  sq += __shfl_xor(sq, 1, 64);
+  sq += __shfl_xor(sq, 2, 64);
+  sq += __shfl_xor(sq, 4, 64);
+  const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
+  // skip: the main pass runs over the non-sample rows only (main_row); its outlier operand and column constants in that order
+  if (used) {
+    if (!skip) *reinterpret_cast<i32x4 *>(wqo + (size_t)n * MAX_OUT + j0) = packed;
+    else if (!samp) *reinterpret_cast<i32x4 *>(wqo + (size_t)main_row(n) * MAX_OUT + j0) = packed;
+    if (samp) *reinterpret_cast<i32x4 *>(wqos + (size_t)(n / SAMPLE_STRIDE) * MAX_OUT + j0) = packed;
+  }
+  if ((threadIdx.x & 7) == 0) {
+    const f32x4 st = wstat[n];
+    const float so = st[0] * st[0] * (float)sq;
+    const f32x4 cc = {st[0], st[1], fmaxf(st[2] - so, 0.f), so};
+    colc[n] = cc;
+    if (samp) colc_s[n / SAMPLE_STRIDE] = cc;
+    else if (skip) colc_p[main_row(n)] = cc;
+  }
+}
+
+// The main pass leaves the sample features out (main_row): their candidates are the sample pass's own upper values above the
+// token's threshold -- the entries the main pass's flush would have written for them (same u, same key).  One workgroup per token.
+__global__ __launch_bounds__(256) void sample_push_kernel(const float *__restrict__ sample, int S,
+                                                          const float *__restrict__ tau_vals, int tau_ld, int tau_col,
+                                                          int skip_a, int skip_b, int *__restrict__ cnt,
+                                                          unsigned long long *__restrict__ cand, int cap, int cnt_stride,
+                                                          int row_stride) {
+  const int t = blockIdx.x;
+  const float tv = tau_vals[(size_t)t * tau_ld + tau_col];
+  if (!(tv > 0.f)) return;                               // degenerate token: the main pass emits nothing either
+  const float *row = sample + (size_t)t * S;
+  for (int j = threadIdx.x * 4; j < S; j += 1024) {      // S % 256 == 0
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(row + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!(u[e] > tv)) continue;
+      const int feat = (j + e) * SAMPLE_STRIDE + SAMPLE_OFF;
+      if (feat == skip_a || feat == skip_b) continue;
+      const int slot = atomicAdd(cnt + (size_t)t * cnt_stride, 1);
+      if (slot < cap) cand[(size_t)t * row_stride + slot] = ((unsigned long long)f32_order_key(u[e]) << 32) | (unsigned)(0x7FFFFFFF - feat);
+    }
+  }
+}
+
+// Segmented candidate lists (GemmEpilogue::segs, batches of few tokens) -> the contiguous list the consumers read.  One wave per
+// token; a segment that overflowed reports cap + 1 (the consumers' "list overflow").
+__global__ __launch_bounds__(64) void compact_candidates_kernel(const int *__restrict__ seg_cnt,
+                                                                const unsigned long long *__restrict__ seg_cand, int segs,
+                                                                int cap, int *__restrict__ cnt,
+                                                                unsigned long long *__restrict__ cand) {
+  const int t = blockIdx.x, lane = threadIdx.x, scap = cap / segs;
+  int at = 0;
+  bool over = false;
+  for (int sg = 0; sg < segs; ++sg) {
+    const int c = seg_cnt[(size_t)t * segs + sg];
+    over |= c > scap;
+    const int n = c < scap ? c : scap;
+    for (int i = lane; i < n; i += 64) cand[(size_t)t * cap + at + i] = seg_cand[(size_t)t * cap + (size_t)sg * scap + i];
+    at += n;
+  }
+  if (lane == 0) cnt[t] = over ? cap + 1 : at;
+}
+
+// Reference feature of the GEMM's separable band bound: refs = mean (Q, Si, So) over the sample rows'
+// column constants (any positive triple is CORRECT -- the bound h_n B_t >= z sigma(t, n) holds by
+// construction; a typical one makes it tight).  One workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void band_refs_kernel(const f32x4 *__restrict__ colc_s, int S, float *__restrict__ refs) {
+  __shared__ float red[3][16];
+  float q = 0.f, si = 0.f, so = 0.f;
+  for (int j = threadIdx.x; j < S; j += 1024) {
+    const f32x4 c = colc_s[j];
+    q += c[1]; si += c[2]; so += c[3];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    q += __shfl_xor(q, off, 64); si += __shfl_xor(si, off, 64); so += __shfl_xor(so, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = q; red[1][threadIdx.x >> 6] = si; red[2][threadIdx.x >> 6] = so; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+    refs[threadIdx.x] = fmaxf(t / (float)S, 1e-30f);
+  }
+}
+
+}  // namespace

@@ -1,0 +1,526 @@
+// encode_rescore.h -- behind the candidate GEMM: per-token candidate select + exact f32 re-score + verification
+// (select_rescore_kernel), the feature-sharded group's record packing (pack_candidates_kernel), and their launchers.
+// Host dispatch: encode_fused.hip.
+#pragma once
+#include <type_traits>
+
+#include "encode_defs.h"
+
+namespace {
+
+// ---- candidate select + exact re-score ----------------------------------------------------------
+static_assert(MSAE_RESCORE_U * 4 == 64, "one re-scoring batch must be the 64 floats fast_shape_ok() guarantees");
+struct RescoreArgs {
+  const float *a32; const float *W_enc, *b_enc;
+  const float *tau_vals; int tau_ld, tau_col;
+  const int *cnt; const unsigned long long *cand; int cap;
+  int T, d, N, k, r_max;
+  int set_feature; float set_value; int zero_feature;
+  const f32x4 *rowc, *colc;           // error-band constants per token / per feature
+  float zz12, z2; int i8;
+  float *vals; int32_t *idx; int64_t *idx64; int32_t *status;   // idx / idx64: either may be null
+  int *flagged; int *n_flagged; int fb_cap;
+  int32_t *rows_out;                  // optional diagnostics (msae_options::rows_rescored)
+  // EXT (feature-sharded group, msae_rescore_candidates): the candidate lists come as the shards' records
+  // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
+  const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
+  int lpr;   // lanes per row in the first round (1, 2, 4): small batches need the extra bytes in flight (rescore_shape)
+};
+
+// One shard's record of a token (msae_shard_candidates): C keys (order key of the upper value u | 0x7FFFFFFF -
+// GLOBAL feature, 0 = empty), C times z sigma of that (token, feature) pair, tau = the largest u any feature of
+// the shard NOT in the record can have (+inf: the shard could not bound it -> the token is recomputed exactly).
+__host__ __device__ inline int shard_record_bytes(int C) { return C * 12 + 8; }
+
+// Wave-wide bitonic sort (descending) of n = power-of-two u64 keys in LDS by ONE 64-lane wave.
+template <int NT>
+__device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n, int lane) {
+  for (int size = 2; size <= n; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = lane; i < (n >> 1); i += NT) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = s[lo], y = s[hi];
+        if ((x < y) == desc) { s[lo] = y; s[hi] = x; }
+      }
+    }
+  __syncthreads();
+}
+
+// number of keys (sorted descending, value in the upper 32 bits as an order key) whose value is >= v
+__device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, float v) {
+  const unsigned tk = f32_order_key(v);
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((unsigned)(keys[mid] >> 32) >= tk) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ONE WAVE per token (64-thread workgroup; 4 waves for k > 64).  dynamic LDS: keys[cap] u64 | res[nrp] u64.
+//
+// The candidate list is ordered by the UPPER value u = coarse + z*sigma; lane c re-scores candidate c
+// with the exact ascending-k f32 chain: it walks row f of W_enc with two software-pipelined batches
+// of 16 x 16-B loads (256 B = two lines per batch) while the token's f32 activation vector a32[t][:]
+// arrives through wave-uniform scalar loads.  No LDS staging of operands: the data in flight lives in
+// VGPRs (7 waves x ~45 lanes x 512 B per CU), which is what keeps the HBM pipe full -- streaming the
+// rows through LDS instead caps it at the ring size and measured 2.5 ms vs 1.4.
+// HBM-bound: ~42 rows x d x 4 B per token.
+//
+// Rounds.  Needed are exactly the candidates with u >= v_k (the exact k-th value): everything else
+// has p <= u < v_k.  v_k is not known beforehand, so round 1 takes the candidates with
+//     u >= (k-th largest coarse value among the first NT) - zeta * (their median sigma)
+// (the lanes look up the band of "their" candidate to get coarse = u - z*sigma), which is the needed
+// set plus about one row in 96 % of the tokens; the exact v_k of round 1 is a lower bound of the final
+// one, so ONE extension to every u >= v_k completes the rest.  A token verifies when
+//     all candidates with u >= v_k are re-scored  and  v_k > tau  (non-candidates have u <= tau)
+// and no re-scored pair contradicted the error model (|p - coarse| <= 6 sigma).  Tokens that fail (or
+// overflowed their list / have tau <= 0 / more than r_max rows to read) go to the exact path.
+// EXT: the list is the union of the shards' records; keys[] then carries the list POSITION in its low word
+// (feature and z sigma are looked up by position: ef[], ezs[]).
+// LDSA (small batches, p.lpr > 1): the token's activations are copied to LDS once and every lane reads the 16 B that
+// belong to ITS piece of the row (ds_read_b128, counted waits) -- the scalar loads of the default path return out of
+// order, so each pair of them is a full lgkmcnt(0) round trip (128 per pass), which nothing hides when a token's
+// waves are alone on their SIMDs.
+template <int NW, bool EXT = false, bool LDSA = false>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
+__global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
+                                                            const float *__restrict__ W_enc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+  const int nrp = next_pow2(p.r_max + 1);
+  unsigned long long *res = keys + p.cap;
+  [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
+  [[maybe_unused]] int *ef = reinterpret_cast<int *>(ezs + p.cap);        // EXT only: [cap] global feature by position
+  [[maybe_unused]] float *a_lds = EXT ? reinterpret_cast<float *>(ef + p.cap) : ezs;   // LDSA only: [d]
+  constexpr int NT = 64 * NW;
+  __shared__ float s_cc[NT], s_zs[NT], s_pick[2];
+  __shared__ int s_n;
+  __shared__ unsigned s_tau;
+  const int lane = threadIdx.x;   // thread index within the token's workgroup
+  const int t = blockIdx.x;
+  if constexpr (EXT) { if (t >= p.ext_valid) return; }
+  int cnt, n;
+  float tau;
+  MSAE_RTL(0);
+  const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
+  if constexpr (LDSA) {                                   // published by the barriers of the list sort below
+    for (int i = 4 * (int)threadIdx.x; i < p.d; i += 4 * 64 * NW)
+      *reinterpret_cast<f32x4 *>(a_lds + i) = *reinterpret_cast<const f32x4 *>(a + i);
+  }
+  f32x4 rc = {0.f, 0.f, 0.f, 0.f};
+  const bool i8 = p.i8 != 0;
+  int np;
+  if constexpr (EXT) {
+    const int M = p.ext_G * p.ext_C;
+    np = next_pow2(M > 2 ? M : 2);
+    if (lane == 0) { s_n = 0; s_tau = 0u; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = lane; i < np; i += NT) {
+      unsigned long long kv = 0ull;
+      if (i < M) {
+        const int g = i / p.ext_C, j = i - g * p.ext_C;
+        const unsigned char *rec = p.ext + ((size_t)g * p.ext_T + t) * p.ext_stride;
+        const unsigned long long key = reinterpret_cast<const unsigned long long *>(rec)[j];
+        if (key != 0ull) {
+          kv = (key & 0xFFFFFFFF00000000ull) | (unsigned)(0x7FFFFFFF - i);
+          ef[i] = rank_key_index(key);
+          ezs[i] = reinterpret_cast<const float *>(rec + (size_t)p.ext_C * 8)[j];
+          ++mine;
+        }
+      }
+      keys[i] = kv;
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    for (int g = lane; g < p.ext_G; g += NT) {   // tau = the largest bound of ALL shards (order keys: +inf dominates, NaN never enters)
+      const unsigned char *rec = p.ext + ((size_t)g * p.ext_T + t) * p.ext_stride;
+      atomicMax(&s_tau, f32_order_key(*reinterpret_cast<const float *>(rec + (size_t)p.ext_C * 12)));
+    }
+    __syncthreads();
+    n = cnt = s_n;
+    tau = f32_from_order_key(s_tau);
+  } else {
+    cnt = p.cnt[t];
+    n = cnt < p.cap ? cnt : p.cap;
+    tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+    rc = p.rowc[t];
+    np = next_pow2(n > 2 ? n : 2);
+  }
+  for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
+  MSAE_RTL(1);
+  // keys[0, n_sorted) hold the n_sorted largest keys in descending order (upper value desc, index asc on ties).
+  // PARTIAL: of a list of ~650 candidates a token uses the first 40-60, so one wave first SELECTS its PRE_LO..PRE_HI
+  // largest (keys in registers, bisection on the value word with ballot counts, a handful of steps) and sorts only
+  // those 128 slots; whoever then needs a candidate behind them (count_needed, the target check of a round) gets the
+  // full sort after all -- the presorted prefix is the same keys in the same places.
+  constexpr int PRE_LO = 96, PRE_HI = 128, PRE_MIN = 192, PRE_PK = 32;
+  int n_sorted = n;
+  bool partial = false;
+  auto full_sort = [&]() {
+    if constexpr (!EXT) {
+      __syncthreads();
+      for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+    }
+    wave_sort_desc_u64<NT>(keys, np, lane);
+  };
+  if constexpr (!EXT && NW == 1) {
+    if (msae_tuning::RESCORE_PRESELECT && n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
+      const int nj = (n + 63) >> 6;
+      unsigned long long kreg[PRE_PK];
+#pragma unroll
+      for (int j = 0; j < PRE_PK; ++j) {
+        const int i = j * 64 + lane;
+        kreg[j] = (j < nj && i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+      }
+      unsigned lo = 0u, hi = 0xFFFFFFFFu;     // count(value word >= lo) > PRE_HI, count(>= hi) < PRE_LO
+      int c_sel = -1;
+      unsigned thr = 0u;
+      while (hi - lo > 1u) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int jb = 0; jb < PRE_PK; jb += 8) {             // one branch per eight key slots (empty slots hold 0)
+          if (jb < nj) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j)
+              c += __builtin_popcountll(__builtin_amdgcn_ballot_w64((unsigned)(kreg[j] >> 32) >= mid));
+          }
+        }
+        if (c > PRE_HI) lo = mid;
+        else if (c < PRE_LO) hi = mid;
+        else { c_sel = c; thr = mid; break; }
+      }
+      if (c_sel > 0) {                                       // (ties across the window: no such threshold -> full sort)
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < PRE_PK; ++j) {
+          if (j < nj) {
+            const bool take = (unsigned)(kreg[j] >> 32) >= thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            if (take) keys[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = kreg[j];
+            base += __builtin_popcountll(m);
+          }
+        }
+        for (int i = c_sel + lane; i < PRE_HI; i += NT) keys[i] = 0ull;
+        wave_sort_desc_u64<NT>(keys, PRE_HI, lane);
+        partial = true;
+        n_sorted = c_sel;
+      }
+    }
+  }
+  if (!partial) full_sort();
+  auto need_full = [&]() { full_sort(); partial = false; n_sorted = n; };
+  auto count_needed = [&](float v) {         // candidates with u >= v (over the whole list)
+    int c = count_ge(keys, n_sorted, v);
+    if (partial && c >= n_sorted) { need_full(); c = count_ge(keys, n, v); }
+    return c;
+  };
+  MSAE_RTL(2);
+  const int has_set = p.set_feature >= 0 ? 1 : 0;
+  if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
+
+  // ---- size of the first round ------------------------------------------------------------------
+  const int lim = n < p.r_max ? n : p.r_max;
+  int target = lim;
+  {
+    const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
+    const int mt = n < mt_max ? n : mt_max;
+    float my_cc = -__builtin_inff(), my_zs = 0.f;
+    if (lane < mt) {
+      const unsigned long long key = keys[lane];
+      if constexpr (EXT) my_zs = ezs[rank_key_index(key)];
+      else my_zs = __builtin_sqrtf(band_sq(rc, p.colc[rank_key_index(key)], p.zz12, i8));
+      my_cc = f32_from_order_key((unsigned)(key >> 32)) - my_zs;
+    }
+    s_cc[lane] = my_cc;
+    s_zs[lane] = my_zs;
+    if (lane < 2) s_pick[lane] = lane == 0 ? -__builtin_inff() : 0.f;
+    __syncthreads();
+    const int kk = p.k - has_set;
+    if (lane < mt && kk >= 1 && kk <= mt) {
+      int rank_c = 0, rank_z = 0;
+      for (int j = 0; j < mt; ++j) {
+        const float cj = s_cc[j], zj = s_zs[j];
+        rank_c += (cj > my_cc || (cj == my_cc && j < lane)) ? 1 : 0;
+        rank_z += (zj < my_zs || (zj == my_zs && j < lane)) ? 1 : 0;
+      }
+      if (rank_c == kk - 1) s_pick[0] = my_cc;
+      if (rank_z == mt / 2) s_pick[1] = my_zs;
+    }
+    __syncthreads();
+    if (kk >= 1 && kk <= mt && p.z2 > 0.f) {
+      const float thr1 = s_pick[0] - GUARD_ZETA * s_pick[1] * __builtin_amdgcn_rsqf(p.z2);
+      int n1 = count_needed(thr1);
+      if (n1 < p.k + 4) n1 = p.k + 4;
+      target = n1 < lim ? n1 : lim;
+    }
+  }
+  if constexpr (LDSA) {   // small batch: one pass reads 64 NW / lpr rows whatever the target -- fill it (fewer second rounds)
+    const int rpp = p.lpr > 0 ? NT / p.lpr : NT;
+    const int fill = rpp < lim ? rpp : lim;
+    if (target < fill) target = fill;
+  }
+
+  MSAE_RTL(3);
+  const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
+  const bool guarded = !EXT && rc[3] != 0.f;     // the token's shape is outside the noise model (quant_x_kernel): exact path
+  if (guarded) target = 0;                       // (no row is read for it here)
+  int done = 0;                                  // candidates re-scored so far (wave-uniform)
+  bool ok = false, viol = false;
+  int rounds = 0;
+  const int first_target = target;
+  for (;;) {
+    ++rounds;
+    int my_viol = 0;
+    // LPR = 1: lane c streams row c (16 B per lane and instruction).  LPR = 4 (tuning builds): four lanes share a
+    // row, lane q loading bytes [16 q, 16 q + 16) of every 64-B piece -- four times fewer cache lines per
+    // instruction, but only 16 rows per pass, i.e. three row-streaming latencies per round instead of one.  The
+    // chain stays one serial ascending-k sequence: sub-step q multiplies the group's lane-q piece (every lane
+    // executes it on its own registers; only lane q's is the true partial sum) and a quad rotate hands the
+    // accumulator on.  The activations are wave-uniform scalar operands either way.
+    auto run_pass = [&](auto lpr_tag) {
+      constexpr int LPR = decltype(lpr_tag)::value;
+      constexpr int RPP = NT / LPR;                  // rows per pass
+      constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U * LPR;   // floats of a row per batch
+      const int rq = lane / LPR, q = lane % LPR;
+      for (int c0 = done; c0 < target; c0 += RPP) {
+        const int c = c0 + rq;
+        const bool active = c < target;
+        const unsigned long long key = active ? keys[c] : keys[c0];
+        int f = rank_key_index(key);
+        float ext_zs = 0.f;
+        f32x4 cc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EXT) { ext_zs = ezs[f]; f = ef[f]; }     // list position -> (z sigma, global feature)
+        else cc = p.colc[f];
+        const float upper = f32_from_order_key((unsigned)(key >> 32));
+        const float *__restrict__ w = W_enc + (size_t)f * p.d + 4 * q;
+        float acc = 0.f;
+        // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
+        // other is in flight, so the lane never drains its loads
+        f32x4 wa[RS_U], wb[RS_U];
+        auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
+#pragma unroll
+          for (int u = 0; u < RS_U; ++u) dst[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * LPR * u);
+        };
+        auto consume = [&](const f32x4 (&src)[RS_U], int kk) {
+#pragma unroll
+          for (int u = 0; u < RS_U; ++u) {
+            [[maybe_unused]] f32x4 av;                   // LDSA: the activations of this lane's own piece
+            if constexpr (LDSA) av = *reinterpret_cast<const f32x4 *>(a_lds + kk + 4 * LPR * u + 4 * q);
+#pragma unroll
+            for (int qq = 0; qq < LPR; ++qq) {
+              const int k0 = kk + 4 * LPR * u + 4 * qq;
+              if constexpr (LDSA) {                      // only sub-step qq == q carries the true partial sum
+                acc = __builtin_fmaf(av[0], src[u][0], acc);
+                acc = __builtin_fmaf(av[1], src[u][1], acc);
+                acc = __builtin_fmaf(av[2], src[u][2], acc);
+                acc = __builtin_fmaf(av[3], src[u][3], acc);
+              } else {
+                acc = __builtin_fmaf(a[k0 + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
+                acc = __builtin_fmaf(a[k0 + 1], src[u][1], acc);
+                acc = __builtin_fmaf(a[k0 + 2], src[u][2], acc);
+                acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
+              }
+              if constexpr (LPR == 4)   // quad_perm:[3,0,1,2] -- lane i takes lane i - 1's value, lane 0 lane 3's
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xF, 0xF, false));
+              if constexpr (LPR == 2)   // quad_perm:[1,0,3,2] -- the two lanes of a pair swap
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xB1, 0xF, 0xF, false));
+            }
+          }
+        };
+        fetch(wa, 0);
+        for (int kk = 0; kk < p.d; kk += 2 * RS_B) {     // d % RS_B == 0 (fast_shape_ok / the caller's choice of LPR)
+          const bool has_b = kk + RS_B < p.d;
+          if (has_b) fetch(wb, kk + RS_B);
+          consume(wa, kk);
+          if (kk + 2 * RS_B < p.d) fetch(wa, kk + 2 * RS_B);
+          if (has_b) consume(wb, kk + RS_B);
+        }
+        const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
+        if (active && q == 0) {                          // whole pieces done: the sum is back in the group's lane 0
+          res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
+          // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
+          const float zs2 = EXT ? ext_zs * ext_zs : band_sq(rc, cc, p.zz12, i8);
+          const float diff = pre - (upper - __builtin_sqrtf(zs2));
+          if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
+        }
+      }
+    };
+    // A follow-up round re-scores a handful of rows: with a lane per row each of them is a latency chain (16 KB at
+    // 512 B in flight = 32 round trips, ~60 us whatever the load); four lanes per row carry 2 KB in flight each.
+    // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
+    // p.lpr lanes per row and as many waves per token.
+    if (partial && target > n_sorted) need_full();          // wave-uniform
+    const bool few = rounds > 1 && target - done <= NT / 4;
+    int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
+    while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
+    if (lpr == 4) run_pass(std::integral_constant<int, 4>());
+    else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
+    else run_pass(std::integral_constant<int, 1>());
+    done = target;
+    viol = viol || (__syncthreads_or(my_viol) != 0);
+    MSAE_RTL(2 + 2 * rounds);
+    {   // res[] is zero (= empty, the smallest key) behind the slots written so far: sort the filled prefix only
+      const int filled = next_pow2(done + has_set > 2 ? done + has_set : 2);
+      wave_sort_desc_u64<NT>(res, filled < nrp ? filled : nrp, lane);
+    }
+    MSAE_RTL(3 + 2 * rounds);
+    const bool have_k = done + has_set >= p.k;
+    const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
+    const int needed = have_k ? count_needed(v_k) : n;          // candidates with u >= v_k
+    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f && !guarded;
+    if (ok || viol || guarded || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
+    target = needed > done ? needed : done + 1;
+    if (target > lim) target = lim;
+    __syncthreads();
+  }
+
+  MSAE_RTL(14);
+  MSAE_RTL_VALUE(15, ((unsigned long long)rounds << 32) | (unsigned)done);
+  for (int j = lane; j < p.k; j += NT) {
+    const unsigned long long key = res[j];
+    const int fi = key ? rank_key_index(key) : 0;
+    if (p.idx) p.idx[(size_t)t * p.k + j] = fi;
+    if (p.idx64) p.idx64[(size_t)t * p.k + j] = fi;
+    p.vals[(size_t)t * p.k + j] = key ? f32_from_order_key((unsigned)(key >> 32)) : 0.f;
+  }
+  if (lane == 0) {
+    // not verified: 2 | reason bits (4 list overflow, 8 tau <= 0, 16 fewer than k candidates,
+    // 32 more than r_max rows needed / v_k not above tau, 64 a re-scored pair contradicted the error
+    // model); the exact fallback rewrites it to 1 once it has recomputed t
+    const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
+                       (done + has_set < p.k ? 16 : 0) | (guarded ? 128 : (viol ? 64 : 32));
+    if (p.status) p.status[t] = ok ? 0 : reason;
+    // msae_options::rows_rescored: rounds << 24 | first-round rows << 12 | rows of W_enc this token read (0: not verified here)
+    if (p.rows_out) p.rows_out[t] = ok ? (rounds << 24) | (first_target << 12) | done : 0;
+    if (!ok) {
+      const int slot = atomicAdd(p.n_flagged, 1);
+      if (slot < p.fb_cap) p.flagged[slot] = t;
+    }
+  }
+}
+
+// Feature-sharded group, sender side: the C best candidates of THIS shard per token by upper value, as the
+// record shard_record_bytes() describes (global feature ids).  One wave per token.
+struct PackArgs {
+  const int *cnt; const unsigned long long *cand; int cap;
+  const float *tau_vals; int tau_ld, tau_col;
+  const f32x4 *rowc, *colc; float zz12; int i8;
+  int C, row_offset, stride;
+  unsigned char *recs;
+};
+template <int PK>   // key slots per lane: the list (<= cap <= 64 PK keys) lives in registers
+__global__ __launch_bounds__(64) void pack_candidates_kernel(PackArgs p) {
+  // The C largest of ~512 keys are a selection, not a sort: the keys sit in registers (PK per lane) and a bisection
+  // on the 64-bit key -- unique: the feature id is its low word -- finds the C-th largest with one ballot count
+  // per key slot and step; the survivors are compacted with ballot prefix counts (any order: the owner sorts).
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int cnt = p.cnt[t];
+  const int n = cnt < p.cap ? cnt : p.cap;
+  const float tau = p.tau_vals[(size_t)t * p.tau_ld + p.tau_col];
+  // list complete, a real threshold behind it, and a token the noise model describes (rowc[3]: quant_x_kernel's guard)
+  const bool bounded = cnt <= p.cap && tau > 0.f && p.rowc[t][3] == 0.f;
+  const int nj = bounded ? (n + 63) >> 6 : 0;            // key slots in use (wave-uniform)
+  unsigned long long kreg[PK];
+#pragma unroll
+  for (int j = 0; j < PK; ++j) {
+    const int i = j * 64 + lane;
+    kreg[j] = (j < nj && i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
+  }
+  unsigned long long lo = 0ull, hi = ~0ull;              // count(key >= lo) >= C  (or everything is taken), count(>= hi) < C
+  if (n > p.C) {
+    while (hi - lo > 1ull) {
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int jb = 0; jb < PK; jb += 8) {               // one branch per eight key slots (empty slots hold 0 < mid)
+        if (jb < nj) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kreg[j] >= mid));
+        }
+      }
+      if (c >= p.C) lo = mid; else hi = mid;
+    }
+  } else {
+    lo = 1ull;                                           // every (non-empty) key
+  }
+  unsigned char *rec = p.recs + (size_t)t * p.stride;
+  unsigned long long *okeys = reinterpret_cast<unsigned long long *>(rec);
+  float *ozs = reinterpret_cast<float *>(rec + (size_t)p.C * 8);
+  const f32x4 rc = p.rowc[t];
+  int base = 0;
+  unsigned long long below = 0ull;                       // largest key NOT taken
+#pragma unroll
+  for (int j = 0; j < PK; ++j) {
+    if (j < nj) {
+      const unsigned long long key = kreg[j];
+      const bool take = key >= lo && key != 0ull;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+      if (take) {
+        const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const int f = rank_key_index(key);
+        okeys[pos] = (key & 0xFFFFFFFF00000000ull) | (unsigned)(0x7FFFFFFF - (f + p.row_offset));
+        ozs[pos] = __builtin_sqrtf(band_sq(rc, p.colc[f], p.zz12, p.i8 != 0));
+      } else {
+        below = key > below ? key : below;
+      }
+      base += __builtin_popcountll(m);
+    }
+  }
+  for (int jj = base + lane; jj < p.C; jj += 64) { okeys[jj] = 0ull; ozs[jj] = 0.f; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(below, off, 64);
+    below = o > below ? o : below;
+  }
+  if (lane == 0) {
+    // what the shard's other features can reach: the best candidate left behind, else the threshold every
+    // non-candidate stayed below; +inf when the shard cannot tell (overflowed list, degenerate token)
+    float b = __builtin_inff();
+    if (bounded) b = below != 0ull ? f32_from_order_key((unsigned)(below >> 32)) : tau;
+    float *tail = reinterpret_cast<float *>(rec + (size_t)p.C * 12);
+    tail[0] = b;
+    tail[1] = 0.f;
+  }
+}
+
+// waves per token and lanes per row of the first round: k > 64 -> 4 waves (longer lists); batches that cannot fill
+// 256 CUs x 8 waves with a lane per row get 2 or 4 lanes per row (and waves per token) instead
+inline void rescore_shape(int T, int k, int &nw, int &lpr) {
+  // k > 64: 4 waves per token, a lane per row.  k = 256 reads ~350 rows per token (profiles/r03_rescore_stats_k256.txt),
+  // i.e. a second, mostly idle pass -- but 6 waves per token (one pass) measured SLOWER, 9.65 vs 8.0 ms: the kernel's
+  // ~230 VGPRs allow 8 waves per CU, and workgroups of 6 waves leave two of those slots empty
+  // (profiles/r03_k256_nw6.txt); the stage is HBM-bound at 5.8 TB/s either way.
+  nw = k <= 64 ? 1 : 4;
+  lpr = 1;
+  if (k <= 64) {
+    const long lanes = (long)T * (k + 13);
+    if (lanes * 4 <= 131072) lpr = 4;
+    else if (lanes * 2 <= 131072) lpr = 2;
+    nw = lpr;
+  }
+}
+template <bool EXT>
+inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, const float *a32, const float *W_enc,
+                                 hipStream_t s) {
+  int nw;
+  rescore_shape(T, k, nw, ra.lpr);
+  const bool ldsa = ra.lpr > 1 && smem + (size_t)ra.d * 4 <= 96 * 1024;      // small batch: activations in LDS
+  if (ldsa) smem += (size_t)ra.d * 4;
+#define MSAE_RS_LAUNCH(NWV, LDSAV)                                                                                   \
+  do {                                                                                                               \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT, LDSAV>,                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                        \
+    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
+  } while (0)
+  if (ldsa) { if (nw == 2) MSAE_RS_LAUNCH(2, true); else MSAE_RS_LAUNCH(4, true); }
+  else if (nw == 1) MSAE_RS_LAUNCH(1, false);
+  else if (nw == 2) MSAE_RS_LAUNCH(2, false);
+  else MSAE_RS_LAUNCH(4, false);
+#undef MSAE_RS_LAUNCH
+  return 0;
+}
+
+}  // namespace

@@ -56,6 +56,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
@@ -77,25 +78,8 @@ struct GemmEpilogue {
   const f32x4 *rowc, *colc;
   const float *refs;             // (Qr, Sir, Sor): the reference feature of the separable bound
   float zz12;                    // z^2 / 12
-#ifdef MSAE_GEMM_TIMELINE        // tuning builds: s_memtime stamps of workgroup 0 / wave 0, 8 per output tile
-  unsigned long long *timeline;
-#endif
+  unsigned long long *timeline;  // tuning builds (tuning.h, MSAE_TL): s_memtime stamps of workgroup 0 / wave 0; null in the product
 };
-#if defined(MSAE_GEMM_TIMELINE) && MSAE_GEMM_TIMELINE != 2
-#define MSAE_TL(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && ep.timeline && tl_tile < 64) \
-    ep.timeline[tl_tile * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MSAE_TL(slot) do { } while (0)
-#endif
-#if defined(MSAE_GEMM_TIMELINE) && MSAE_GEMM_TIMELINE == 2   // inside k-tile 8 of every output tile (wave MSAE_TLK_WAVE)
-#ifndef MSAE_TLK_WAVE
-#define MSAE_TLK_WAVE 0
-#endif
-#define MSAE_TLK(cond, slot) do { if ((cond) && blockIdx.x == 0 && threadIdx.x == 64 * MSAE_TLK_WAVE && ep.timeline && tl_tile < 64) \
-    ep.timeline[tl_tile * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MSAE_TLK(cond, slot) do { } while (0)
-#endif
 
 // Operands of one launch.  A rows are tokens, B rows are features; ld* in BYTES.
 struct GemmOperands {
@@ -291,9 +275,6 @@ __device__ __forceinline__ void gemm_read_frags(i32x4 (&a)[C::MI], i32x4 (&b)[C:
 // `mid` runs behind the MFMAs of k-step AT (default: between k-steps 1 and 2, the reads of k-steps 2 and 3 in flight
 // across it): the waves that issue the next k-tile's LDS-DMA there instead of before their first MFMA (gemm_kernel:
 // stagger)
-#ifndef MSAE_GEMM_STAGGER_AT
-#define MSAE_GEMM_STAGGER_AT 1
-#endif
 template <class C, class F>
 __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                                  int wr, int wc, int l31, int kh, F &&mid) {
@@ -486,9 +467,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
     c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
   }
   // C[i][n] of a 32x32 block: n = lane&31, i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#ifdef MSAE_ABL_NOEPI      // tuning builds only (tools/build_dbg.sh): skip the element loop
-  if (!DENSE && ep.cap != -12345) { asm volatile("" ::"v"(acc[0][0][0])); } else
-#endif
+  if (msae_tuning::ABL_NOEPI && !DENSE && ep.cap != -12345) { asm volatile("" ::"v"(acc[0][0][0])); } else   // (tuning builds: skip the element loop)
   // THRESH.  One pass over the wave's MI x NI blocks without any LDS round trip: the value v replaces the accumulator in its register,
   // the sign of (v + h_n B_t) - tau goes through a 1-instruction shift register (v_alignbit) into a 16-bit hit mask per block.
   // Then ONE queue reservation per lane for all its hits of this tile, then the pushes (v picked out of the 16 registers
@@ -599,11 +578,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
   MSAE_TL(4);
   if constexpr (!DENSE) {
     __syncthreads();
-#ifdef MSAE_ABL_NOFLUSH     // tuning builds only: drop the queue instead of flushing it
-    const unsigned nq = 0;
-#else
-    const unsigned nq = *q_count < QCAP ? *q_count : QCAP;
-#endif
+    const unsigned nq = msae_tuning::ABL_NOFLUSH ? 0u : (*q_count < QCAP ? *q_count : QCAP);
     for (unsigned q = threadIdx.x; q < nq; q += C::NT) {
       const unsigned long long e = queue[q];
       const int row = (int)((e >> 16) & 0xFFFFu), col = (int)(e & 0xFFFFu);
@@ -754,19 +729,14 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (kt + 1 < ntiles) stage(m0, n0, kt + 1, (seq + 1) & 1);
       else if (has_next) stage(m0n, n0n, 0, (seq + 1) & 1);
     };
-#ifndef MSAE_GEMM_STAGGER
-#define MSAE_GEMM_STAGGER 1   // round 3: on by default (-4 % on the main pass together with tile-major operands, two boxes:
-#endif                        // profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt); 0 = off, 2 = odd waves
-#if MSAE_GEMM_STAGGER
+    // (MSAE_GEMM_STAGGER, tuning.h: on by default since round 3 -- -4 % on the main pass together with tile-major operands, two
+    // boxes: profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt; 0 = off, 2 = odd waves)
     // Waves w and w + 4 share a SIMD.  If both issue their eight LDS-DMA pieces right behind the barrier (~700
     // cycles of issue each) the SIMD's MFMA pipe idles for that long in every k-tile; so the upper four waves
     // start with MFMAs on the data already in LDS and issue their pieces between k-steps 1 and 2, while their
     // partners -- done issuing -- keep the pipe busy.  ONE copy of the MFMA code: the two roles differ only in
     // which of the two stage_next() call sites is taken.
-    const bool late = (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m && nM > 1;
-#else
-    constexpr bool late = false;
-#endif
+    const bool late = MSAE_GEMM_STAGGER != 0 && (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m && nM > 1;
     if constexpr (!C::ABL_NOSTAGE) {
       if (!late) stage_next();
     }

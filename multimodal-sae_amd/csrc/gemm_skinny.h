@@ -16,23 +16,6 @@
 #pragma once
 #include "gemm_mfma.h"
 
-#ifdef MSAE_SK_PLAIN          // tuning builds
-#define MSAE_SK_LOAD(p) (*(p))
-#else
-#define MSAE_SK_LOAD(p) __builtin_nontemporal_load(p)
-#endif
-#ifndef MSAE_SK_UN
-#define MSAE_SK_UN 4
-#endif
-#ifndef MSAE_SK_ABL
-#define MSAE_SK_ABL 0   // tuning builds: 1 no A chunk traffic, 2 no B loads, 4 no MFMAs / fragment reads (results invalid)
-#endif
-#ifdef MSAE_SK_NOFENCE
-#define MSAE_SK_FENCE() do { } while (0)
-#else
-#define MSAE_SK_FENCE() __builtin_amdgcn_sched_barrier(0)   // a batch of loads is issued as a batch, where it is written
-#endif
-
 template <int BM_, int NW_ = 4>
 struct SkinnyCfg {
   // NW waves per workgroup, 32 features each.  NW = 4: two workgroups share a CU (80 KB of LDS, 2 waves per SIMD at ~200

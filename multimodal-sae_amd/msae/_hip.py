@@ -25,7 +25,7 @@ class MsaeOptions(ctypes.Structure):
     """struct msae_options of include/msae.h: the per-call options of the fused encoder."""
     _fields_ = [("size", ctypes.c_uint32), ("coarse_mode", ctypes.c_int32), ("guard_z", ctypes.c_float),
                 ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p), ("exact", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("rows_rescored", ctypes.c_void_p)]
 
 
 c_opts_p = ctypes.POINTER(MsaeOptions)

@@ -96,6 +96,7 @@ class Options:
                  profile: Optional[StageProfile] = None, exact: bool = False):
         self.coarse, self.guard_z, self.status_detail, self.profile = coarse, guard_z, status_detail, profile
         self.exact = exact
+        self.rows_rescored: Optional[Tensor] = None     # device int32 [T] (msae_options::rows_rescored) or None
 
     def struct(self) -> "_hip.MsaeOptions":
         o = _hip.MsaeOptions()
@@ -105,6 +106,7 @@ class Options:
         o.status_detail = int(bool(self.status_detail))
         o.profile = self.profile.handle if self.profile is not None else None
         o.exact = int(bool(self.exact))
+        o.rows_rescored = self.rows_rescored.data_ptr() if self.rows_rescored is not None else None
         return o
 
     def ref(self):
@@ -138,13 +140,15 @@ def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = Fal
     z = guard_z if guard_z > 0.0 else _defaults.guard_z
     detail = bool(status_detail or _defaults.status_detail)
     exact = bool(exact or _defaults.exact)
-    prof = _defaults.profile
-    key = (coarse, z, detail, id(prof) if prof is not None else 0, exact)
+    prof, rows = _defaults.profile, _defaults.rows_rescored
+    key = (coarse, z, detail, id(prof) if prof is not None else 0, exact, rows.data_ptr() if rows is not None else 0)
     ref = _OPTS_CACHE.get(key)
     if ref is None or ref.profile is not prof:
         if len(_OPTS_CACHE) > 64:
             _OPTS_CACHE.clear()
-        ref = _OPTS_CACHE[key] = _OptsRef(Options(coarse, z, detail, prof, exact))
+        o = Options(coarse, z, detail, prof, exact)
+        o.rows_rescored = rows
+        ref = _OPTS_CACHE[key] = _OptsRef(o)
     return ref
 
 
@@ -167,6 +171,19 @@ def profiling(profile: StageProfile):
         yield profile
     finally:
         _defaults.profile = prev
+
+
+@contextlib.contextmanager
+def rescore_rows(buf: Tensor):
+    """Fused encodes of <= buf.numel() tokens issued inside the block write their per-token re-score statistics
+    (msae_options::rows_rescored: rounds << 24 | first-round rows << 12 | rows of W_enc read; 0 = not verified by the
+    large-batch re-score) into `buf` (device int32)."""
+    assert buf.is_cuda and buf.dtype == torch.int32 and buf.is_contiguous()
+    prev, _defaults.rows_rescored = _defaults.rows_rescored, buf
+    try:
+        yield buf
+    finally:
+        _defaults.rows_rescored = prev
 
 
 _DEBUG_BOUNDS = os.environ.get("MSAE_DEBUG_BOUNDS", "0") not in ("", "0")

@@ -1,6 +1,6 @@
 #!/bin/sh
-# Instrumented build of the library (tools/bin/libmsae_dbg.so, not shipped): -DMSAE_RESCORE_DEBUG makes the
-# re-score kernel report (rounds << 24 | first-round rows << 12 | rows) in `status` of verified tokens.
+# Instrumented / ablation builds of the library (tools/bin/<MSAE_DBG_NAME>, not shipped): MSAE_DBG_FLAGS carries the -D flags of
+# multimodal-sae_amd/csrc/tuning.h (e.g. -DMSAE_GEMM_TIMELINE, -DMSAE_RESCORE_TL, -DMSAE_ABL_NOEPI, -DMSAE_GEMM_STAGGER=0).
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/../multimodal-sae_amd/csrc"
@@ -9,7 +9,7 @@ OBJ="$OUT/obj_$$"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 NAME="${MSAE_DBG_NAME:-libmsae_dbg.so}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function ${MSAE_DBG_FLAGS--DMSAE_RESCORE_DEBUG}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function ${MSAE_DBG_FLAGS-}"
 OBJS=""
 for f in capi decode topk sparsify encode_f32 encode_fused train; do
   "$HIPCC" $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" &

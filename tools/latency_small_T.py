@@ -6,7 +6,7 @@ from msae import ops
 dev = torch.device('cuda:0'); d, N, k = 4096, 131072, 32
 W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, 4096, d, N)
 prep = ops.prepare_encoder(W_enc)
-for T in (1, 2, 4, 8, 16, 17, 32, 33, 64, 128, 256, 1024, 2880):
+for T in (1, 2, 4, 8, 16, 17, 32, 33, 64, 128, 129, 192, 256, 257, 1024, 2880):
     xs = x[:T].contiguous()
     res = {}
     for name, fn in (("fused", lambda: ops.encode_topk(xs, W_enc, b_enc, b_dec, prep, k)),

@@ -8,7 +8,7 @@ north_star: "outputs match ... on identical cached LLaVA-NeXT layer-24 activatio
 Neither exists in the offline build image; until they do the same check runs on the synthetic
 "trained_like" SAE (tests/hostile.py) -- which is what this command does without arguments.  Output (JSON, also
 written to --out): tokens, verified-but-wrong tokens (must be 0), status histogram and fallback reasons,
-fused and exact tokens/s.  Rows read per token: MSAE_HIP_LIB=tools/bin/libmsae_dbg.so tools/rescore_stats.py.
+fused and exact tokens/s.  Rows read per token: tools/rescore_stats.py (msae_options::rows_rescored).
 """
 import sys
 from pathlib import Path

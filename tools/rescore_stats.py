@@ -1,7 +1,6 @@
-"""Rows / rounds of the re-scoring stage per token.  Needs the instrumented library (tools/build_dbg.sh,
--DMSAE_RESCORE_DEBUG), which reports (rounds << 24 | first-round rows << 12 | rows) in `status`:
+"""Rows / rounds of the re-scoring stage per token, from msae_options::rows_rescored (rounds << 24 | first-round rows << 12 | rows):
 
-    MSAE_HIP_LIB=tools/bin/libmsae_dbg.so python tools/rescore_stats.py [bench|trained_like|lognorm|...]
+    python tools/rescore_stats.py [bench|trained_like|lognorm|...]        (K=256 in the environment: k = 256)
 """
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,15 +20,17 @@ for kind in kinds:
     for mode in ("int8", "bf16"):
         ops.set_coarse_mode(mode)
         prep = ops.prepare_encoder(W_enc)
-        v, i, s = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, k)
+        buf = torch.zeros(T, dtype=torch.int32, device=dev)
+        with ops.rescore_rows(buf):
+            v, i, st = ops.encode_topk(x, W_enc, b_enc, b_dec, prep, k)
         torch.cuda.synchronize()
-        s = s.cpu()
+        s, st = buf.cpu(), st.cpu()
         ok = s >= (1 << 24)
         rounds, first, rows = s[ok] >> 24, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
         print(f"k={k} {kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
               f"mean rows {rows.float().mean():.1f} (first round {first.float().mean():.1f})  "
               f"rows p50/p99/max {int(rows.float().quantile(0.5))}/{int(rows.float().quantile(0.99))}/{int(rows.max())}  "
-              f"not verified: {torch.unique(s[~ok], return_counts=True)}", flush=True)
+              f"not verified: {torch.unique(st[~ok], return_counts=True)}", flush=True)
         del prep
     ops.set_coarse_mode("int8")
     del W_enc
