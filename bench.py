@@ -129,6 +129,63 @@ def cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, sample_T=256, reps=5):
                       f"{t * 1e3:.0f} ms/call"}
 
 
+class ClockSampler:
+    """Shader clock and package power of the benched GPU, sampled from amdgpu's hwmon files beside the timed loop (a host
+    thread reading two sysfs files every ~2 ms: nothing is enqueued on the device).  The candidate GEMM runs at the
+    package power limit (profiles/r03_power.txt), so the clock the loop actually got is part of the measurement."""
+
+    def __init__(self, dev):
+        import glob
+
+        self.freq = self.power = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        hit = [c for c in cards if want and want in os.path.realpath(c)] or (cards if len(cards) == 1 else [])
+        for c in hit[:1]:
+            f = glob.glob(c + "/hwmon/hwmon*/freq1_input")
+            pw = glob.glob(c + "/hwmon/hwmon*/power1_average") or glob.glob(c + "/hwmon/hwmon*/power1_input")
+            self.freq, self.power = (f[0] if f else None), (pw[0] if pw else None)
+        self.samples, self._stop, self._th = [], threading.Event(), None
+
+    def _read(self, path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            f = self._read(self.freq) if self.freq else None
+            w = self._read(self.power) if self.power else None
+            self.samples.append((f, w))
+            time.sleep(0.002)
+
+    def __enter__(self):
+        if self.freq or self.power:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th is not None:
+            self._th.join()
+        return False
+
+    def summary(self):
+        f = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        return {"effective_sclk_mhz": (sum(f) / len(f) / 1e6) if f else None,
+                "avg_power_w": (sum(w) / len(w) / 1e6) if w else None, "samples": len(self.samples),
+                "source": "amdgpu hwmon freq1_input / power1_average sampled every ~2 ms beside the timed loop (whole "
+                          "step: ~2/3 candidate GEMM at the package power limit, ~1/3 HBM-bound stages at the full clock)"}
+
+
 def load_traffic(kernel: str):
     """Counter bytes per launch of the dominant kernel from the COMMITTED PMC summary (separate rocprofv3 --pmc passes
     of an earlier run of this command, tools/gpu_pmc.sh) -- not measured in this run.  -> (bytes or None, source)."""
@@ -150,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tokens", type=int, default=8192, help="tokens per step (whole job)")
     ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--batches", type=int, default=4, help="distinct activation batches rotated through the timed loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-replicas", action="store_true",
                     help="N > 1: skip the second (token-sharded replicas, weak scaling) measurement")
@@ -215,9 +273,22 @@ def main():
             data = "user-supplied files: " + ", ".join(f"{n}={v}" for n, v in (("sae", args.sae_path), ("acts", args.acts)) if v)
         engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
 
+    def more_batches(x0, seed0):
+        """The timed loop streams DISTINCT activation batches (round-3 verdict: one batch fed to every step keeps its
+        quantised copy, its a32 and the rows its tokens gather resident in the Infinity Cache): x0 + args.batches - 1
+        more of the same distribution.  User-supplied activations are split into that many batches when they are long
+        enough, else reused."""
+        if args.acts:
+            return [x0]
+        return [x0] + [make_inputs(dev, T, d, 8192, seed=seed0 + 7919 * j)[4] for j in range(1, args.batches)]
+
+    rows_buf = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
+    sampler_out = {}
+
     def timed(eng, xin, steps, warmup, profile):
-        for _ in range(warmup):
-            eng.forward(xin, async_gather=eng.collective)
+        xs = xin if isinstance(xin, list) else [xin]
+        for i in range(warmup):
+            eng.forward(xs[i % len(xs)], async_gather=eng.collective)
         eng.synchronize()
         torch.cuda.synchronize()
         dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -229,15 +300,18 @@ def main():
         if ddp:
             dist.barrier()
         torch.cuda.synchronize()
+        sampler = ClockSampler(dev)
         t0 = time.perf_counter()
-        with ops.profiling(prof):
-            for _ in range(steps):
-                out = eng.forward(xin, async_gather=eng.collective)
-        eng.synchronize()
-        torch.cuda.synchronize()
+        with sampler, ops.profiling(prof), ops.rescore_rows(rows_buf):
+            for i in range(steps):
+                out = eng.forward(xs[i % len(xs)], async_gather=eng.collective)
+            eng.synchronize()
+            torch.cuda.synchronize()
         if ddp:
             dist.barrier()
         el = time.perf_counter() - t0
+        sampler_out.clear()
+        sampler_out.update(sampler.summary())
         stage, dec_ms = np.zeros((0, 6)), float("nan")
         if profile:
             stage = prof.read().astype(np.float64)
@@ -310,16 +384,24 @@ def main():
         res["decode_algorithmic_gbs"] = {"achieved": bytes_dec / (dec_ms * 1e-3) / 1e9, "unit": "GB/s",
                                          "bytes_per_token": k * d * 4 + k * 8 + d * 4}
         res["fast_path_verified_frac"] = float((out["status"] == 0).float().mean().item())
+        # msae_options::rows_rescored of the LAST step's encode: f32 rows of W_enc read per verified token (floor: k)
+        rb = rows_buf[: out["status"].shape[0]] if out["status"].shape[0] <= rows_buf.shape[0] else rows_buf
+        got = rb[rb > 0]
+        if got.numel():
+            res["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())
+            res["rescore_rounds_per_token"] = float((got >> 24).float().mean().item())
+        res["clock"] = dict(sampler_out)
 
     workload = ("BASELINE configs[1]: d_model=%d width=%d k=%d, %%s %s activations/step resident in HBM, %s" % (
         d, N, k, str(x.dtype).replace("torch.", "").replace("bfloat16", "bf16").replace("float", "f"),
         ("f32 weights of the checkpoint " + args.sae_path) if args.sae_path else "random-init unit-norm f32 weights"))
 
     if not sharded:
-        elapsed, out, stage, dec_ms = timed(engine, x, args.steps, args.warmup, profile=True)
+        xs = more_batches(x, rank)
+        elapsed, out, stage, dec_ms = timed(engine, xs, args.steps, args.warmup, profile=True)
         res.update(ms_per_step=elapsed / args.steps * 1e3, value=T * args.steps / elapsed,
                    config={"workload": workload % ("T=%d" % T), "tokens_per_step": T, "k": k,
-                           "parallelism": "single GPU"})
+                           "parallelism": "single GPU", "distinct_batches": len(xs)})
         if len(stage):
             roofline_fields(stage, dec_ms, out, N, T, with_traffic=True)
     else:
@@ -328,7 +410,8 @@ def main():
         # it can wedge.  It is the PROVISIONAL headline: if a feature-sharded leg below raises or stalls on this node,
         # the printed line still carries a measured whole-job number and names the leg that failed.
         if not args.no_replicas:
-            _, _, _, _, x_own = make_inputs(dev, T, d, 8192, seed=1 + rank)        # this rank's own batch
+            _, _, _, _, x_own = make_inputs(dev, T, d, 8192, seed=1 + rank)        # this rank's own batches
+            x_own = more_batches(x_own, 1 + rank)
             rep = ShardedSae(W_full, b_full, W_dec, b_dec, k)
             el_r, out_r, stage_r, dec_r = timed(rep, x_own, args.steps, args.warmup, profile=True)
             del rep, x_own
@@ -346,7 +429,9 @@ def main():
         # exchange schemes are timed; the headline is the faster one whose first 256 tokens are bit-identical to a
         # single-GPU encode of the same tokens.
         shard_modes = res["shard_modes"] = {}
-        chk_v, chk_i, _ = ops.encode_topk(x[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
+        xs = more_batches(x, 0)                      # the same batches on every rank
+        x_last = xs[(args.steps - 1) % len(xs)]      # the batch of the step whose outputs are checked
+        chk_v, chk_i, _ = ops.encode_topk(x_last[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
         same = lambda o: bool(torch.equal(chk_i, o["top_indices"][:256]) and torch.equal(chk_v, o["top_acts"][:256]))
         best = None
         legs = [("per_shard_topk", engine, "per-shard exact top-%d, RCCL all-gather + merge" % engine.k_loc)]
@@ -356,7 +441,7 @@ def main():
                          "owner against the replicated W_enc, all-gather of the results" % engine_cand.n_cand))
         for name, eng, desc in legs:
             try:
-                el, o, st, dm = timed(eng, x, args.steps, args.warmup, profile=True)
+                el, o, st, dm = timed(eng, xs, args.steps, args.warmup, profile=True)
             except Exception as e:
                 shard_modes[name] = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
                 fail(f"feature-sharded leg {name} raised on rank {rank}")
