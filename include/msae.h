@@ -233,11 +233,13 @@ int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const fl
  * pair are zero; no pre-zeroing needed).  Pairs are grouped by feature with a counting sort and
  * summed in ascending pair order (segments are sorted whatever their length), so the result is bit-reproducible.
  * Pairs whose index lies outside [0, N) contribute nothing and are flagged in `status` (int32[1], optional).
- * d % 4 == 0. */
+ * d % 4 == 0.  row_sumsq (optional, f32[N]) receives |g_W_dec[n][:]|^2 per row while the row is in registers: the
+ * gradient-norm pass of clip_grad_norm_ (train/sae/sae/trainer.py:390) without re-reading the 2 GiB gradient
+ * (msae_sum_f32 adds the rows up in a fixed order). */
 size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N);
 int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
-                             int k, int N, int d, float *g_W_dec, int32_t *status, void *ws, size_t ws_bytes,
-                             void *stream);
+                             int k, int N, int d, float *g_W_dec, float *row_sumsq, int32_t *status, void *ws,
+                             size_t ws_bytes, void *stream);
 
 /* ---- feature-cache sparsify ------------------------------------------------------------------
  * From the per-token top-k (vals/idx[B*S][k], any order) produce the reference cache's COO
@@ -280,6 +282,21 @@ int msae_merge_topk_masked(const int32_t *gathered, int T, int G, int kl, int k,
  *                          weight decay, trainer.py:139-146,395) on W, M, V in place, `step` >= 1.
  *                          G is read only. */
 int msae_unit_norm_rows_f32(float *W, int N, int d, float eps, void *stream);
+/* *accum += v[0] + ... + v[n - 1], summed in a fixed order (bit-reproducible): the total of row_sumsq. */
+int msae_sum_f32(const float *v, size_t n, float *accum, void *stream);
+/* msae_adam_rows_f32 with the NEXT step's passes over the same matrix folded into the one sweep:
+ *   renorm_eps >= 0  rows of W are divided by their norm + renorm_eps after the update -- the trainer's
+ *                    set_decoder_norm_to_unit_norm at the top of the next step (sae.py:249-255, trainer.py:352), bit for
+ *                    bit what msae_unit_norm_rows_f32 would produce from the updated matrix; < 0: off
+ *   prepared != NULL W is the ENCODER weight [N = rows][d]: its coarse-pass operands for the next encode of T_next
+ *                    tokens (T_next <= 0: any batch size) are rebuilt from the updated rows, bit for bit what
+ *                    msae_encoder_refresh_for / msae_encoder_refresh would build (opts: the coarse mode)
+ * Both save a read (+ write) of the 2 GiB matrix per step.  Shapes the fused kernel does not take (d % 4 != 0, d > 8192)
+ * run the separate passes. */
+int msae_adam_rows_fused_f32(float *W, const float *G, float *M, float *V, int rows, int d,
+                             const float *total_sumsq, float max_norm, int project, float lr, float beta1,
+                             float beta2, float eps, int step, float renorm_eps, void *prepared, int T_next,
+                             const msae_options *opts, void *stream);
 int msae_grad_sumsq_f32(const float *g, size_t n, float *accum, void *stream);
 int msae_adam_rows_f32(float *W, const float *G, float *M, float *V, int rows, int d,
                        const float *total_sumsq, float max_norm, int project, float lr, float beta1,

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
                                                           const float *__restrict__ grad_out,
                                                           const int *__restrict__ offsets,
                                                           int *__restrict__ perm, int k, int N, int d,
-                                                          float *__restrict__ g_W) {
+                                                          float *__restrict__ g_W, float *__restrict__ rowsq) {
   __shared__ int s_seg[4][WGRAD_LDS_SEG];
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
+  float ss = 0.f;                                      // this lane's share of |g_W[n]|^2 (rowsq)
   for (int c0 = lane * 4; c0 < d; c0 += 256 * 4) {     // 4 column chunks in flight per pass
     f32x4 acc[4];
 #pragma unroll
@@ -287,8 +288,16 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = c0 + u * 256;
-      if (c < d) *reinterpret_cast<f32x4 *>(g_W + (size_t)n * d + c) = acc[u];
+      if (c < d) {
+        *reinterpret_cast<f32x4 *>(g_W + (size_t)n * d + c) = acc[u];
+        ss += acc[u][0] * acc[u][0] + acc[u][1] * acc[u][1] + acc[u][2] * acc[u][2] + acc[u][3] * acc[u][3];
+      }
     }
+  }
+  if (rowsq) {   // the gradient-norm pass of clip_grad_norm_ (trainer.py:390) for free: the row is in registers, fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane == 0) rowsq[n] = ss;
   }
 }
 
@@ -350,7 +359,7 @@ extern "C" size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N) {
 
 extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
                                         const float *grad_out, int A, int k, int N, int d,
-                                        float *g_W_dec, int32_t *status, void *ws, size_t ws_bytes,
+                                        float *g_W_dec, float *row_sumsq, int32_t *status, void *ws, size_t ws_bytes,
                                         void *stream) {
   if (A < 0 || k <= 0 || N <= 0 || d <= 0 || d % 4 != 0) return MSAE_EINVAL;
   if (!ws || ws_bytes < msae_decode_bwd_wdec_ws_bytes(A, k, N)) return MSAE_EWS;
@@ -372,6 +381,6 @@ extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
     hipLaunchKernelGGL(wgrad_zero_kernel, dim3(256), dim3(256), 0, s, offsets, N + 1);
   }
   hipLaunchKernelGGL(wgrad_accum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, acts, grad_out, offsets, perm,
-                     k, N, d, g_W_dec);
+                     k, N, d, g_W_dec, row_sumsq);
   return msae_launch_status();
 }

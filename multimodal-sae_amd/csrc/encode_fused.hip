@@ -624,7 +624,7 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
   if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
   Prepared p = make_prepared(N, d);
   // what this call rebuilds is valid, everything else is stale from now on (the weights have changed)
-  p.valid = ((modes & 1) ? PREP_BF16 : 0u) | (((modes & 2) && i8_shape_ok(N, d)) ? (PREP_I8 | ((modes & 4) ? 0u : PREP_FRAG)) : 0u);
+  p.valid = prep_valid_bits(modes, N, d);
   MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
   if (p.S) {
     if (!msae_aligned(W_enc, 16)) return MSAE_EALIGN;
@@ -633,19 +633,12 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
       hipLaunchKernelGGL(prepare_weights_kernel, dim3(4096), dim3(256), 0, s, W_enc, N, d,
                          reinterpret_cast<unsigned short *>(base + p.off_wb),
                          reinterpret_cast<unsigned short *>(base + p.off_ws));
-    f32x4 *wstat = reinterpret_cast<f32x4 *>(base + p.off_wstat), *wstat_s = reinterpret_cast<f32x4 *>(base + p.off_wstat_s);
-    f32x4 *colbf = reinterpret_cast<f32x4 *>(base + p.off_colbf), *colbf_s = reinterpret_cast<f32x4 *>(base + p.off_colbf_s);
-    if ((modes & 2) && i8_shape_ok(N, d))   // row statistics (both passes' error bands) + int8 operands
-      hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
-                         colbf_s, reinterpret_cast<signed char *>(base + p.off_wq),
-                         reinterpret_cast<signed char *>(base + p.off_wqs), reinterpret_cast<signed char *>(base + p.off_wqp),
-                         reinterpret_cast<signed char *>(base + p.off_wqsp),
-                         (modes & 4) ? (signed char *)nullptr : reinterpret_cast<signed char *>(base + p.off_wqf),
-                         (modes & 4) ? (signed char *)nullptr : reinterpret_cast<signed char *>(base + p.off_wqsf), gemm_layout() == 2 ? 2 : 1);
+    const bool i8 = i8_shape_ok(N, d);
+    const RowQuantOut ro = row_quant_out(base, p, modes, i8);
+    if ((modes & 2) && i8)   // row statistics (both passes' error bands) + int8 operands
+      hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
     else
-      hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, wstat, wstat_s, colbf,
-                         colbf_s, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr, (signed char *)nullptr,
-                         (signed char *)nullptr, (signed char *)nullptr, 1);
+      hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
   }
   return msae_launch_status();
 }

@@ -64,18 +64,20 @@ __device__ __forceinline__ float hash01(unsigned long long z) {
   z ^= z >> 31;
   return (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
 }
+// The work of one 256-thread workgroup on row n (also the tail of the fused optimiser pass of csrc/train.hip, which calls it
+// on the row it has just updated: the operands of the NEXT step's encode without another sweep over W_enc).
+struct RowQuantOut {
+  f32x4 *wstat, *wstat_s, *colbf, *colbf_s;
+  signed char *wq, *wqs, *wqp, *wqsp, *wqf, *wqsf;
+  int layout;
+};
 template <bool QUANT>
-__global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__restrict__ W, int N, int d,
-                                                              f32x4 *__restrict__ wstat, f32x4 *__restrict__ wstat_s,
-                                                              f32x4 *__restrict__ colbf, f32x4 *__restrict__ colbf_s,
-                                                              signed char *__restrict__ wq,
-                                                              signed char *__restrict__ wqs,
-                                                              signed char *__restrict__ wqp,
-                                                              signed char *__restrict__ wqsp,
-                                                              signed char *__restrict__ wqf,
-                                                              signed char *__restrict__ wqsf, int layout) {
-  __shared__ float red[3][4];
-  const int n = blockIdx.x;
+__device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W, int n, int d, const RowQuantOut &o,
+                                                    float (&red)[3][4]) {
+  f32x4 *__restrict__ wstat = o.wstat, *__restrict__ wstat_s = o.wstat_s, *__restrict__ colbf = o.colbf, *__restrict__ colbf_s = o.colbf_s;
+  signed char *__restrict__ wq = o.wq, *__restrict__ wqs = o.wqs, *__restrict__ wqp = o.wqp, *__restrict__ wqsp = o.wqsp;
+  signed char *__restrict__ wqf = o.wqf, *__restrict__ wqsf = o.wqsf;
+  const int layout = o.layout;
   const float *row = W + (size_t)n * d;
   float m = 0.f, s2 = 0.f, s4 = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
@@ -145,6 +147,32 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
       }
     }
   }
+}
+template <bool QUANT>
+__global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__restrict__ W, int N, int d, RowQuantOut o) {
+  __shared__ float red[3][4];
+  row_stats_quant_row<QUANT>(W, blockIdx.x, d, o, red);
+}
+
+// pointers into a prepared buffer for the operand groups `modes` rebuilds (bit 1: int8 operands, bit 2: without the
+// fragment-major copies); stats are rebuilt by every mode
+inline RowQuantOut row_quant_out(unsigned char *base, const Prepared &p, int modes, bool i8) {
+  RowQuantOut o{};
+  o.wstat = reinterpret_cast<f32x4 *>(base + p.off_wstat); o.wstat_s = reinterpret_cast<f32x4 *>(base + p.off_wstat_s);
+  o.colbf = reinterpret_cast<f32x4 *>(base + p.off_colbf); o.colbf_s = reinterpret_cast<f32x4 *>(base + p.off_colbf_s);
+  o.layout = 1;
+  if ((modes & 2) && i8) {
+    o.wq = reinterpret_cast<signed char *>(base + p.off_wq); o.wqs = reinterpret_cast<signed char *>(base + p.off_wqs);
+    o.wqp = reinterpret_cast<signed char *>(base + p.off_wqp); o.wqsp = reinterpret_cast<signed char *>(base + p.off_wqsp);
+    if (!(modes & 4)) {
+      o.wqf = reinterpret_cast<signed char *>(base + p.off_wqf); o.wqsf = reinterpret_cast<signed char *>(base + p.off_wqsf);
+    }
+  }
+  return o;
+}
+// which operand groups a prepare / refresh of `modes` leaves valid (Prepared::valid)
+inline unsigned prep_valid_bits(int modes, int N, int d) {
+  return ((modes & 1) ? PREP_BF16 : 0u) | (((modes & 2) && i8_shape_ok(N, d)) ? (PREP_I8 | ((modes & 4) ? 0u : PREP_FRAG)) : 0u);
 }
 
 // x side (every call).  Massive-activation dims would dictate the per-token scale and wipe out

@@ -58,8 +58,6 @@
 #include "common.h"
 #include "tuning.h"
 
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 struct GemmEpilogue {
   const float *bias;             // b_enc

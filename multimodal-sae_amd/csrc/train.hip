@@ -13,6 +13,8 @@
 // ~38 GB.  All HBM-bound streaming kernels: 16-B accesses, one workgroup per row so the row's
 // second touch (projection / scale) is an L2 hit.
 #include "common.h"
+#include "encode_defs.h"
+#include "encode_prep.h"
 
 namespace {
 
@@ -141,7 +143,120 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float *__restrict__ W, c
   }
 }
 
+// *accum += sum(v[0 .. n)) in a FIXED order (one workgroup: per-thread strided partial sums, then block_sum): the total of
+// the per-row squared gradient norms the weight-gradient kernel wrote (msae_decode_bwd_wdec_f32: row_sumsq)
+__global__ __launch_bounds__(1024) void sum_fixed_kernel(const float *__restrict__ v, size_t n, float *__restrict__ accum) {
+  __shared__ float red[16];
+  float ss = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) ss += v[i];
+  const float t = block_sum(ss, red);
+  if (threadIdx.x == 0) *accum += t;
+}
+
+// adam_rows_kernel with the NEXT step's passes over the same matrix folded in (d % 4 == 0; the updated row stays in registers
+// for d <= 8192):
+//   renorm_eps >= 0   W[r] /= |W[r]| + eps after the update: the trainer's set_decoder_norm_to_unit_norm at the top of the next
+//                     step (sae.py:249-255, trainer.py:352) -- same arithmetic, reduction order and bits as unit_norm_rows_kernel,
+//                     without its read + write of the 2 GiB matrix
+//   REFRESH 1 / 2     the coarse-pass operands of the updated encoder row (int8: row statistics + quantised copies, as
+//                     row_stats_quant_kernel<true>; bf16: statistics + the bf16 copy) into the prepared buffer -- what
+//                     msae_encoder_refresh_for would rebuild with another sweep over W_enc before the next encode
+struct FusedTail {
+  float renorm_eps;
+  RowQuantOut rq;
+  unsigned short *wb, *ws;      // REFRESH 2: bf16 copy + bf16 sample rows
+};
+template <int REFRESH>
+__global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict__ W, const float *__restrict__ G,
+                                                              float *__restrict__ M, float *__restrict__ V,
+                                                              int d, const float *__restrict__ total_sumsq,
+                                                              AdamArgs a, FusedTail ft) {
+  __shared__ float red[4];
+  __shared__ float red3[3][4];
+  const size_t base = (size_t)blockIdx.x * d;
+  float clip = 1.f;
+  if (total_sumsq) {
+    const float c = a.max_norm / (sqrtf(*total_sumsq) + 1e-6f);
+    clip = c < 1.f ? c : 1.f;
+  }
+  float along = 0.f;
+  if (a.project) {
+    float dot = 0.f;
+    for (int c = threadIdx.x * 4; c < d; c += 1024) {
+      const f32x4 g = *reinterpret_cast<const f32x4 *>(G + base + c);
+      const f32x4 w = *reinterpret_cast<const f32x4 *>(W + base + c);
+      dot += (g[0] * clip) * w[0] + (g[1] * clip) * w[1] + (g[2] * clip) * w[2] + (g[3] * clip) * w[3];
+    }
+    along = block_sum(dot, red);
+  }
+  const bool renorm = ft.renorm_eps >= 0.f;
+  constexpr int KEEP = 8;                         // d <= 8192 (checked by the host)
+  f32x4 keep[KEEP];
+  float ss = 0.f;
+  {
+    int it = 0;
+    for (int c = threadIdx.x * 4; c < d; c += 1024, ++it) {
+      const f32x4 g = *reinterpret_cast<const f32x4 *>(G + base + c);     // L2 hit when projecting
+      f32x4 w = *reinterpret_cast<const f32x4 *>(W + base + c);
+      f32x4 m = *reinterpret_cast<const f32x4 *>(M + base + c);
+      f32x4 v = *reinterpret_cast<const f32x4 *>(V + base + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float ge = g[e] * clip, we = w[e], me = m[e], ve = v[e];
+        if (a.project) ge -= along * we;
+        adam_update(we, ge, me, ve, a);
+        w[e] = we; m[e] = me; v[e] = ve;
+      }
+      *reinterpret_cast<f32x4 *>(M + base + c) = m;
+      *reinterpret_cast<f32x4 *>(V + base + c) = v;
+      if (renorm) {
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) if (q == it) keep[q] = w;
+        ss += w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
+      } else {
+        *reinterpret_cast<f32x4 *>(W + base + c) = w;
+      }
+    }
+  }
+  if (renorm) {
+    const float inv = 1.f / (sqrtf(block_sum(ss, red)) + ft.renorm_eps);
+    int it = 0;
+    for (int c = threadIdx.x * 4; c < d; c += 1024, ++it) {
+      f32x4 v = keep[0];
+#pragma unroll
+      for (int q = 1; q < KEEP; ++q) if (q == it) v = keep[q];
+      v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+      *reinterpret_cast<f32x4 *>(W + base + c) = v;
+    }
+  }
+  if constexpr (REFRESH != 0) {
+    __threadfence_block();
+    __syncthreads();                              // the whole updated row is visible to the workgroup (same CU, same L1)
+    const int n = blockIdx.x;
+    if constexpr (REFRESH == 1) {
+      row_stats_quant_row<true>(W, n, d, ft.rq, red3);
+    } else {
+      row_stats_quant_row<false>(W, n, d, ft.rq, red3);
+      const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
+      for (int c = threadIdx.x * 4; c < d; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(W + base + c);
+        u16x4 o;
+        o[0] = f32_to_bf16_bits(v[0]); o[1] = f32_to_bf16_bits(v[1]); o[2] = f32_to_bf16_bits(v[2]); o[3] = f32_to_bf16_bits(v[3]);
+        *reinterpret_cast<u16x4 *>(ft.wb + base + c) = o;
+        if (samp) *reinterpret_cast<u16x4 *>(ft.ws + (size_t)(n / SAMPLE_STRIDE) * d + c) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int msae_sum_f32(const float *v, size_t n, float *accum, void *stream) {
+  if (!v || !accum) return MSAE_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, accum);
+  return msae_launch_status();
+}
 
 extern "C" int msae_unit_norm_rows_f32(float *W, int N, int d, float eps, void *stream) {
   if (!W || N <= 0 || d <= 0) return MSAE_EINVAL;
@@ -173,5 +288,58 @@ extern "C" int msae_adam_rows_f32(float *W, const float *G, float *M, float *V, 
   a.project = project ? 1 : 0;
   hipLaunchKernelGGL(adam_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, W, G, M, V, d,
                      total_sumsq, a);
+  return msae_launch_status();
+}
+
+extern "C" int msae_adam_rows_fused_f32(float *W, const float *G, float *M, float *V, int rows, int d,
+                                        const float *total_sumsq, float max_norm, int project, float lr,
+                                        float beta1, float beta2, float eps, int step, float renorm_eps,
+                                        void *prepared, int T_next, const msae_options *opts, void *stream) {
+  if (!W || !G || !M || !V || rows <= 0 || d <= 0 || step < 1) return MSAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool renorm = renorm_eps >= 0.f;
+  if ((d & 3) != 0 || d > 8192) {                  // shapes the fused kernel does not take: the separate passes
+    int rc = msae_adam_rows_f32(W, G, M, V, rows, d, total_sumsq, max_norm, project, lr, beta1, beta2, eps, step, stream);
+    if (rc) return rc;
+    if (renorm) { rc = msae_unit_norm_rows_f32(W, rows, d, renorm_eps, stream); if (rc) return rc; }
+    if (prepared) return T_next > 0 ? msae_encoder_refresh_for(W, rows, d, prepared, T_next, opts, stream)
+                                    : msae_encoder_refresh(W, rows, d, prepared, opts, stream);
+    return 0;
+  }
+  if (!(msae_aligned(W, 16) && msae_aligned(G, 16) && msae_aligned(M, 16) && msae_aligned(V, 16))) return MSAE_EALIGN;
+  AdamArgs a{};
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.project = project ? 1 : 0;
+  FusedTail ft{};
+  ft.renorm_eps = renorm ? renorm_eps : -1.f;
+  int refresh = 0;
+  if (prepared) {
+    CallOpts co;
+    if (!resolve_opts(opts, co)) return MSAE_EINVAL;
+    if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
+    const int N = rows;
+    Prepared p = make_prepared(N, d);
+    if (p.S) {
+      const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
+      const int modes = (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0);     // as msae_encoder_refresh[_for]
+      p.valid = prep_valid_bits(modes, N, d);
+      MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
+      unsigned char *base = static_cast<unsigned char *>(prepared);
+      ft.rq = row_quant_out(base, p, modes, i8);
+      ft.wb = reinterpret_cast<unsigned short *>(base + p.off_wb);
+      ft.ws = reinterpret_cast<unsigned short *>(base + p.off_ws);
+      refresh = i8 ? 1 : 2;
+    } else {
+      MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));   // no fused path for this shape: header only
+    }
+  }
+  if (refresh == 1)
+    hipLaunchKernelGGL(adam_rows_fused_kernel<1>, dim3(rows), dim3(256), 0, s, W, G, M, V, d, total_sumsq, a, ft);
+  else if (refresh == 2)
+    hipLaunchKernelGGL(adam_rows_fused_kernel<2>, dim3(rows), dim3(256), 0, s, W, G, M, V, d, total_sumsq, a, ft);
+  else
+    hipLaunchKernelGGL(adam_rows_fused_kernel<0>, dim3(rows), dim3(256), 0, s, W, G, M, V, d, total_sumsq, a, ft);
   return msae_launch_status();
 }

@@ -380,17 +380,46 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
 
 
 _TRAIN_PREPARED: dict = {}
+_TRAIN_FRESH: dict = {}      # key -> (weight version, coarse mode, covers batches of <= 256 tokens)
+
+
+def _train_key(W_enc: Tensor):
+    return (W_enc.device, W_enc.data_ptr(), tuple(W_enc.shape))
+
+
+def train_operand_buffer(W_enc: Tensor) -> Tensor:
+    """The per-parameter operand buffer of the training loop (allocated on first use): what `adam_rows_(refresh=...)`
+    rebuilds inside the optimiser pass and `_refresh_train_operands` hands to the next encode."""
+    key = _train_key(W_enc)
+    buf = _TRAIN_PREPARED.get(key)
+    if buf is None:
+        nbytes = _hip.load().msae_encoder_prepared_bytes(W_enc.shape[0], W_enc.shape[1])
+        if len(_TRAIN_PREPARED) > 8:
+            _TRAIN_PREPARED.clear(); _TRAIN_FRESH.clear()
+        buf = _TRAIN_PREPARED[key] = torch.empty(nbytes, dtype=torch.uint8, device=W_enc.device)
+    return buf
+
+
+def mark_train_operands_fresh(W_enc: Tensor, tokens_next: int) -> None:
+    """The optimiser pass has just rebuilt train_operand_buffer(W_enc) from the updated weight (its version as of now)."""
+    _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, _defaults.coarse, tokens_next <= 256)
 
 
 def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
     """Per-step operands of a weight that changes every step: one buffer per parameter, rebuilt in
     place for the coarse mode in force and for the batch size of the ONE encode that follows (it runs in that mode on
-    `tokens` tokens; the buffer is rebuilt before it is read again)."""
-    key = (W_enc.device, W_enc.data_ptr(), tuple(W_enc.shape))
+    `tokens` tokens; the buffer is rebuilt before it is read again) -- unless the optimiser pass that produced this
+    version of the weight has already rebuilt it (adam_rows_(refresh=...): no second sweep over W_enc)."""
+    key = _train_key(W_enc)
+    fresh = _TRAIN_FRESH.get(key)
+    if fresh is not None and fresh == (W_enc._version, _defaults.coarse, fresh[2]) and (tokens > 256 or fresh[2]) \
+            and key in _TRAIN_PREPARED:
+        return _TRAIN_PREPARED[key]
     buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True, tokens_next=tokens)
     if len(_TRAIN_PREPARED) > 8 and key not in _TRAIN_PREPARED:
-        _TRAIN_PREPARED.clear()
+        _TRAIN_PREPARED.clear(); _TRAIN_FRESH.clear()
     _TRAIN_PREPARED[key] = buf
+    _TRAIN_FRESH[key] = (W_enc._version, _defaults.coarse, tokens <= 256)
     return buf
 
 
@@ -520,6 +549,23 @@ def _(top_indices, top_acts, W_dec, b_dec):
     return top_acts.new_empty(*top_acts.shape[:-1], W_dec.shape[1], dtype=torch.float32)
 
 
+_WGRAD_COLLECT: Optional[dict] = None
+
+
+@contextlib.contextmanager
+def collect_wgrad_sumsq():
+    """Weight-gradient kernels launched inside the block also write the squared norm of every gradient row (while it is in
+    registers) and record it: {weight data_ptr: [calls, gradient data_ptr, row_sumsq f32 [N]]}.  The trainer's
+    clip_grad_norm_ total (train/sae/sae/trainer.py:390) is then a 512-KB sum instead of another read of the 2 GiB
+    gradient -- valid for a parameter whose .grad IS the one recorded tensor (exactly one call, no accumulation)."""
+    global _WGRAD_COLLECT
+    prev, _WGRAD_COLLECT = _WGRAD_COLLECT, {}
+    try:
+        yield _WGRAD_COLLECT
+    finally:
+        _WGRAD_COLLECT = prev
+
+
 @torch.library.custom_op("msae::decode_bwd", mutates_args=())
 def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: Tensor,
                need_acts: bool, need_w: bool) -> Tuple[Tensor, Tensor]:
@@ -539,9 +585,15 @@ def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: T
                                                     _hip.ptr(g_acts), _hip.ptr(flag), st), "msae_decode_bwd_acts_f32")
         if need_w:
             ws = _workspace(dev, lib.msae_decode_bwd_wdec_ws_bytes(A, k, N))
+            rowsq = torch.empty(N, dtype=torch.float32, device=dev) if _WGRAD_COLLECT is not None else None
             _hip.check(lib.msae_decode_bwd_wdec_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(g), A, k, N,
-                                                    d, _hip.ptr(g_w), _hip.ptr(flag), _hip.ptr(ws), ws.numel(), st),
+                                                    d, _hip.ptr(g_w), _hip.ptr(rowsq), _hip.ptr(flag), _hip.ptr(ws),
+                                                    ws.numel(), st),
                        "msae_decode_bwd_wdec_f32")
+            if rowsq is not None:
+                ent = _WGRAD_COLLECT.setdefault(W_dec.data_ptr(), [0, 0, None])
+                ent[0] += 1
+                ent[1], ent[2] = g_w.data_ptr(), rowsq
     _check_bounds(flag, "msae_decode_bwd")
     return g_acts, g_w
 
@@ -787,12 +839,27 @@ def grad_sumsq_(accum: Tensor, g: Tensor) -> Tensor:
     return accum
 
 
+def sum_into_(accum: Tensor, v: Tensor) -> Tensor:
+    """accum (f32 device scalar) += sum(v), summed in a fixed order (msae_sum_f32): the total of a weight gradient's
+    per-row squared norms (collect_wgrad_sumsq)."""
+    dev = _hip.require_device(accum, v)
+    assert v.dtype == torch.float32 and v.is_contiguous() and accum.dtype == torch.float32 and accum.numel() == 1
+    with torch.cuda.device(dev):
+        _hip.check(_hip.load().msae_sum_f32(_hip.ptr(v), v.numel(), _hip.ptr(accum), _hip.stream_of(v)), "msae_sum_f32")
+    return accum
+
+
 def adam_rows_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, *,
                total_sumsq: Optional[Tensor] = None, max_norm: float = 1.0, project: bool = False,
-               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
+               betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, renorm_eps: Optional[float] = None,
+               refresh: Optional[Tensor] = None, tokens_next: int = 0) -> None:
     """One fused pass: clip by the global gradient norm, optionally remove the component of each
-    gradient row parallel to the parameter row (sae.py:257-271), Adam update of p, m, v in place."""
-    dev = _hip.require_device(p, g, m, v)
+    gradient row parallel to the parameter row (sae.py:257-271), Adam update of p, m, v in place.
+    `renorm_eps` (the decoder): rows divided by their norm + eps after the update -- the NEXT step's
+    set_decoder_norm_to_unit_norm (sae.py:249-255), same bits, no extra sweep.  `refresh` (the encoder weight; a
+    train_operand_buffer): the coarse-pass operands of the updated rows for the next encode of `tokens_next` tokens,
+    as prepare_encoder(..., active_mode_only=True, tokens_next=...) would rebuild them (msae_adam_rows_fused_f32)."""
+    dev = _hip.require_device(p, g, m, v, refresh)
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == p.shape
     if p.dim() == 2:
@@ -802,6 +869,15 @@ def adam_rows_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
         d = 1024 if p.numel() % 1024 == 0 else p.numel()
         rows = p.numel() // d
     with torch.cuda.device(dev):
+        if renorm_eps is not None or refresh is not None:
+            assert p.dim() == 2, "renorm / refresh are row operations on a [rows, d] matrix"
+            _hip.check(_hip.load().msae_adam_rows_fused_f32(
+                _hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), rows, d,
+                _hip.ptr(total_sumsq) if total_sumsq is not None else None, float(max_norm), int(project),
+                float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                float(renorm_eps) if renorm_eps is not None else -1.0, _hip.ptr(refresh), int(tokens_next),
+                _opts().ref(), _hip.stream_of(p)), "msae_adam_rows_fused_f32")
+            return
         _hip.check(_hip.load().msae_adam_rows_f32(
             _hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), rows, d,
             _hip.ptr(total_sumsq) if total_sumsq is not None else None, float(max_norm), int(project),

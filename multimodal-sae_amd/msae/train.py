@@ -13,6 +13,14 @@ MI355X-side design:
   * clip, parallel-component removal and Adam run as ONE pass per parameter (csrc/train.hip: ~38 GB of HBM
     traffic per step at C2 instead of ~67 GB of separate torch ops); the global gradient norm stays on the
     device, so a step never synchronises with the host (statistics are returned as device tensors);
+  * passes that would re-read a matrix another kernel has just produced are folded into the producer
+    (`fuse_next_step`, round 4): the squared gradient norm of the two weight gradients is accumulated per row by
+    the weight-gradient kernel itself (row in registers; a fixed-order 512-KB sum replaces two 2-GiB reads), the
+    NEXT step's decoder renormalisation and the next encode's int8 / bf16 operands of the encoder are produced
+    by the Adam pass from the row it has just updated (same bits as the separate passes; ~11 GB less traffic per
+    step).  Between steps `W_dec` therefore holds unit-norm rows (the reference renormalises at the top of the
+    next step, trainer.py:352 -- the same values one kernel later; a checkpoint written between steps differs from
+    the reference's by that normalisation, ~1e-5 relative);
   * data parallel: each parameter's gradient all-reduce (RCCL, ReduceOp.AVG -- no division pass) is
     launched ASYNCHRONOUSLY from a post-accumulate-grad hook the moment autograd has finished that
     parameter, so the 2 GiB W_dec exchange over xGMI overlaps the encoder backward, and the W_enc
@@ -62,7 +70,7 @@ class SaeTrainStep:
     def __init__(self, sae: Sae, lr: Optional[float] = None, auxk_alpha: float = 0.0,
                  dead_feature_threshold: int = 10_000_000, group=None, grad_acc_steps: int = 1,
                  micro_acc_steps: int = 1, lr_warmup_steps: int = 0, total_steps: Optional[int] = None,
-                 init_b_dec: bool = False):
+                 init_b_dec: bool = False, fuse_next_step: bool = True):
         self.sae, self.auxk_alpha, self.group = sae, auxk_alpha, group
         self.dead_feature_threshold = dead_feature_threshold
         if lr is None:  # trainer.py:131: 2e-4 scaled by 1/sqrt(N / 2^14)
@@ -82,6 +90,11 @@ class SaeTrainStep:
         self._tokens_in_step = torch.zeros((), dtype=torch.long, device=sae.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._pending, self._reduce_now = [], False
+        # round 4: gradient norm from the weight-gradient kernels, next step's renorm + encoder operands from the Adam pass
+        self.fuse_next_step = fuse_next_step
+        self._normed_version = None        # W_dec._version whose rows the Adam pass left unit-norm
+        self._wgrad_sumsq: dict = {}
+        self._chunk_tokens = 0
         self._avg_op = None
         if self.world > 1:
             # AVG exists on nccl (RCCL) only; gloo (CPU tests) sums and divides
@@ -129,6 +142,9 @@ class SaeTrainStep:
         return self.sae(hiddens, dead_mask)
 
     def _renorm_decoder(self) -> None:
+        W = self.sae.W_dec
+        if self._normed_version is not None and W._version == self._normed_version:
+            return                          # the previous step's Adam pass has already normalised these rows
         self.sae.set_decoder_norm_to_unit_norm()
 
     def _clip_in_place(self) -> None:
@@ -139,17 +155,38 @@ class SaeTrainStep:
         """clip_grad_norm_(1.0) -> remove_gradient_parallel_to_decoder_directions -> Adam, fused."""
         sae = self.sae
         self._sumsq.zero_()
+        # the squared norm of a weight gradient that came out of exactly ONE weight-gradient kernel call and was not
+        # touched since (no accumulation, no all-reduce) is what that kernel recorded per row
+        single = self.world == 1 and self.grad_acc_steps * self.micro_acc_steps == 1
         for p in self.params:
-            if p.grad is not None:
+            if p.grad is None:
+                continue
+            ent = self._wgrad_sumsq.get(p.data_ptr()) if single else None
+            if ent is not None and ent[0] == 1 and ent[1] == p.grad.data_ptr():
+                ops.sum_into_(self._sumsq, ent[2])
+            else:
                 ops.grad_sumsq_(self._sumsq, p.grad)
+        self._wgrad_sumsq = {}
+        fuse = self.fuse_next_step and sae.W_dec.is_cuda
         for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq):
             if p.grad is None:
                 continue
+            kw = {}
+            is_dec = p is sae.W_dec
+            is_enc = p is sae.encoder.weight
+            if fuse and is_dec and sae.cfg.normalize_decoder:
+                kw["renorm_eps"] = torch.finfo(p.dtype).eps          # sae.py:252
+            if fuse and is_enc and self._chunk_tokens > 0:
+                kw["refresh"], kw["tokens_next"] = ops.train_operand_buffer(p), self._chunk_tokens
             ops.adam_rows_(p.data, p.grad, m, v, self.t, lr, total_sumsq=self._sumsq,
                            max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps,
-                           project=sae.cfg.normalize_decoder and p is sae.W_dec)
+                           project=sae.cfg.normalize_decoder and is_dec, **kw)
             p.grad = None
             torch.autograd.graph.increment_version(p)    # p changed behind autograd's back: caches keyed on it go stale
+            if "renorm_eps" in kw:
+                self._normed_version = p._version
+            if "refresh" in kw:
+                ops.mark_train_operands_fresh(p, self._chunk_tokens)
 
     # ---- one batch ---------------------------------------------------------------------------------------------
     def step(self, hiddens: Tensor) -> dict:
@@ -172,9 +209,14 @@ class SaeTrainStep:
         chunks = hiddens.chunk(self.micro_acc_steps)
         for ci, chunk in enumerate(chunks):
             self._reduce_now = self.world > 1 and ci == len(chunks) - 1
+            self._chunk_tokens = chunk.shape[0]
             out = self._forward(chunk, dead_mask)
             loss = out.fvu + self.auxk_alpha * out.auxk_loss + out.multi_topk_fvu / 8
-            loss.div(acc_steps).backward()
+            if hiddens.is_cuda:
+                with ops.collect_wgrad_sumsq() as self._wgrad_sumsq:
+                    loss.div(acc_steps).backward()
+            else:
+                loss.div(acc_steps).backward()
             stats += torch.stack([out.fvu.detach(), out.auxk_loss.detach(), out.multi_topk_fvu.detach()])
             self._did_fire[out.latent_indices.flatten()] = True
         self._reduce_now = False
