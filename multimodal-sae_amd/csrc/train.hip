@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float *__restrict__ W, c
 __global__ __launch_bounds__(1024) void sum_fixed_kernel(const float *__restrict__ v, size_t n, float *__restrict__ accum) {
   __shared__ float red[16];
   float ss = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 1024) ss += v[i];
+  const size_t n4 = n / 4;                               // (v comes from the caching allocator: 16-B aligned)
+  for (size_t i = threadIdx.x; i < n4; i += 1024) {
+    const f32x4 q = reinterpret_cast<const f32x4 *>(v)[i];
+    ss += (q[0] + q[1]) + (q[2] + q[3]);
+  }
+  for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) ss += v[i];
   const float t = block_sum(ss, red);
   if (threadIdx.x == 0) *accum += t;
 }
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict_
 
 extern "C" int msae_sum_f32(const float *v, size_t n, float *accum, void *stream) {
   if (!v || !accum) return MSAE_EINVAL;
+  if (!msae_aligned(v, 16)) return MSAE_EALIGN;
   if (n == 0) return 0;
   hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, accum);
   return msae_launch_status();

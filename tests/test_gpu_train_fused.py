@@ -69,7 +69,10 @@ def test_adam_pass_with_the_encoder_operand_refresh_equals_the_two_passes(dev, m
     try:
         W, G, M, V, ss = _state(dev, N, d, 5)
         W2, M2, V2 = W.clone(), M.clone(), V.clone()
-        buf_a, buf_b = ops.prepare_encoder(W), ops.prepare_encoder(W)      # both start from the OLD weights' operands
+        # both buffers start zero-filled (the layout has padding nobody writes) with the OLD weights' operands
+        nbytes = ops.prepare_encoder(W).numel()
+        buf_a = ops.prepare_encoder(W, out=torch.zeros(nbytes, dtype=torch.uint8, device=dev))
+        buf_b = ops.prepare_encoder(W, out=torch.zeros(nbytes, dtype=torch.uint8, device=dev))
         assert torch.equal(buf_a, buf_b)
         ops.adam_rows_(W, G, M, V, 2, 1e-3, total_sumsq=ss)
         ops.prepare_encoder(W, out=buf_a, active_mode_only=True, tokens_next=tokens)

@@ -357,11 +357,19 @@ __global__ __launch_bounds__(256) void gemm4w_v2_kernel(const unsigned char *__r
   }
 }
 
-__global__ void fill(unsigned char *p, size_t n, unsigned seed) {
+// sigma <= 0: small values -3 .. 3 (round 2's fill: hardly any switching activity); sigma > 0: round(N(0, sigma)) clamped to
+// +-127 -- what a quantised residual stream / encoder row looks like to the multipliers (round 4: the power / clock comparison
+// against the product's kernel, tools/gpu_r04_power.sh)
+__global__ void fill(unsigned char *p, size_t n, unsigned seed, float sigma) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
-    p[i] = (unsigned char)(signed char)((int)(z % 7) - 3);
+    if (sigma <= 0.f) { p[i] = (unsigned char)(signed char)((int)(z % 7) - 3); continue; }
+    z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    float g = 0.f;
+    for (int q = 0; q < 4; ++q) g += (float)((z >> (16 * q)) & 0xFFFF) / 65536.f - 0.5f;   // variance 4/12
+    int v = (int)rintf(g * 1.7320508f * sigma);
+    p[i] = (unsigned char)(signed char)(v > 127 ? 127 : (v < -127 ? -127 : v));
   }
 }
 
@@ -375,7 +383,8 @@ void run(const unsigned char *A, const unsigned char *B, int T, int N, int d, in
   for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
-  for (int i = 0; i < 5; ++i) {
+  const int reps = getenv("G4W_REPS") ? atoi(getenv("G4W_REPS")) : 5;     // many: long enough for rocm-smi's power / clock samples
+  for (int i = 0; i < reps; ++i) {
     CK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(kern, dim3(256), dim3(256), smem, 0, A, B, (size_t)d, nM, nN, nk, out, N);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -400,13 +409,26 @@ int main() {
   const int T = 8192, N = 131072, d = 4096;
   unsigned char *A, *B; int *out;
   CK(hipMalloc(&A, (size_t)T * d)); CK(hipMalloc(&B, (size_t)N * d)); CK(hipMalloc(&out, 4096));
-  fill<<<2048, 256>>>(A, (size_t)T * d, 1); fill<<<2048, 256>>>(B, (size_t)N * d, 2);
+  const float sigma = getenv("G4W_SIGMA") ? (float)atof(getenv("G4W_SIGMA")) : 0.f;
+  fill<<<2048, 256>>>(A, (size_t)T * d, 1, sigma); fill<<<2048, 256>>>(B, (size_t)N * d, 2, sigma);
+  if (sigma > 0.f) printf("int8 operands: round(N(0, %.0f))\n", sigma);
   CK(hipDeviceSynchronize());
   // host copies of the rows the check touches (tiles 0 and 1: a few rows of A and B)
   signed char *hA = (signed char *)malloc((size_t)T * d), *hB = (signed char *)malloc((size_t)2048 * d * 4);
   CK(hipMemcpy(hA, A, (size_t)T * d, hipMemcpyDeviceToHost));
   signed char *hBfull = (signed char *)malloc((size_t)N * d);
   CK(hipMemcpy(hBfull, B, (size_t)N * d, hipMemcpyDeviceToHost));
+  if (getenv("G4W_ONLY")) {                    // one variant, many repetitions: power sampling
+    switch (atoi(getenv("G4W_ONLY"))) {
+      case 0: run<0>(A, B, T, N, d, out, hA, hBfull); break;
+      case 3: run<3>(A, B, T, N, d, out, hA, hBfull); break;
+      case 4: run<4>(A, B, T, N, d, out, hA, hBfull); break;
+      case 5: run<5>(A, B, T, N, d, out, hA, hBfull); break;
+      case 6: run<6>(A, B, T, N, d, out, hA, hBfull); break;
+      default: run<1>(A, B, T, N, d, out, hA, hBfull); break;
+    }
+    return 0;
+  }
   run<1>(A, B, T, N, d, out, hA, hBfull);
   run<0>(A, B, T, N, d, out, hA, hBfull);     // "0 set(s)" = the hand-scheduled kernel
   run<3>(A, B, T, N, d, out, hA, hBfull);     // "3 set(s)" = v2: AGPR-pinned accumulators, two staging sets

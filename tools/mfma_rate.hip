@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -83,18 +84,43 @@ int main() {
   // small magnitudes: finite in every format.  MFMA_RATE_SIGNED=i8: random signs in two's complement (what the int8 pass sees);
   // MFMA_RATE_SIGNED=fp: random sign BITS (sign-magnitude: what an fp8 / fp6 / fp4 pass would see)
   const char *sg = getenv("MFMA_RATE_SIGNED");
+  // MFMA_RATE_GAUSS=i8: round(N(0, 32)) in two's complement -- the int8 pass's operands (per-row scale max / 127, max ~ 4 sigma);
+  // MFMA_RATE_GAUSS=fp8: the e4m3 encoding of N(0, 1) * 448 / 4 -- the same data as an MX-scaled e4m3 pass would hold it (block
+  // maximum near the top binade, three random mantissa bits, random sign bit).  Round 4: the power-capped MFMA rate on the
+  // PRODUCT's operand statistics, the ceiling of what an fp8 candidate GEMM could gain (tools/gpu_r04_power.sh).
+  const char *gs = getenv("MFMA_RATE_GAUSS");
   { unsigned char *h = (unsigned char *)malloc(65536 * 4); unsigned z = 12345u;
     for (int i = 0; i < 65536 * 4; ++i) {
       z = z * 1664525u + 1013904223u;
       const unsigned m = (z >> 8) & 0x3Fu, sign = (z >> 20) & 1u;
       h[i] = !sg ? (unsigned char)m : (sg[0] == 'i' ? (unsigned char)(sign ? (unsigned char)(0u - m) : m) : (unsigned char)(sign << 7 | m));
+      if (gs) {
+        float g = 0.f;
+        for (int q = 0; q < 12; ++q) { z = z * 1664525u + 1013904223u; g += (float)(z >> 8) / 16777216.f; }
+        g -= 6.f;                                                            // ~N(0, 1)
+        if (gs[0] == 'i') {
+          int v = (int)rintf(g * 32.f);
+          h[i] = (unsigned char)(signed char)(v > 127 ? 127 : (v < -127 ? -127 : v));
+        } else {                                                             // e4m3: bias 7, max 448, subnormals below 2^-6
+          float a = fabsf(g) * 112.f;
+          if (a > 448.f) a = 448.f;
+          int e = 0; float mant = 0.f;
+          if (a >= 0.015625f) { e = (int)floorf(log2f(a)); if (e > 8) e = 8; mant = a / exp2f((float)e) - 1.f; }
+          int mi = (int)rintf(mant * 8.f), eb = e + 7;
+          if (a < 0.015625f) { eb = 0; mi = (int)rintf(a / 0.001953125f); }
+          if (mi == 8) { mi = 0; ++eb; }
+          if (eb > 15 || (eb == 15 && mi > 6)) { eb = 15; mi = 6; }
+          h[i] = (unsigned char)((g < 0.f ? 0x80 : 0) | (eb << 3) | mi);
+        }
+      }
     }
     CK(hipMemcpy(src, h, 65536 * 4, hipMemcpyHostToDevice)); free(h); }
-  if (sg) printf("operands: random signs, %s\n", sg[0] == 'i' ? "two's complement" : "sign bit");
+  if (gs) printf("operands: Gaussian, %s\n", gs[0] == 'i' ? "int8 round(N(0, 32))" : "e4m3 of N(0, 1) * 112");
+  else if (sg) printf("operands: random signs, %s\n", sg[0] == 'i' ? "two's complement" : "sign bit");
   float *out; CK(hipMalloc(&out, 256 * 512 * 4));
+  if (getenv("MFMA_RATE_ONLY_FP8")) { run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64); return 0; }
   run<-1>("int8 32x32x32", src, out, 2.0 * 32 * 32 * 32);
   if (getenv("MFMA_RATE_ONLY_I8")) return 0;
-  if (getenv("MFMA_RATE_ONLY_FP8")) { run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64); return 0; }
   run<0>("f8f6f4 32x32x64, fp8 e4m3", src, out, 2.0 * 32 * 32 * 64);
   run<2>("f8f6f4 32x32x64, fp6 e2m3", src, out, 2.0 * 32 * 32 * 64);
   run<4>("f8f6f4 32x32x64, fp4 e2m1", src, out, 2.0 * 32 * 32 * 64);
