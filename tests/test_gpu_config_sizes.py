@@ -304,6 +304,12 @@ def test_train_step_at_c2_matches_dense_torch_restatement(dev):
     ts = SaeTrainStep(sae, lr=lr)
     stats = ts.step(x)
     assert abs(float(stats["fvu"]) - float(fvu)) <= 1e-4 * float(fvu)
+    if ts.fuse_next_step:
+        # the Adam pass has already applied the NEXT step's set_decoder_norm_to_unit_norm (trainer.py:352, sae.py:249-255):
+        # compare with the restatement's decoder as the reference would hold it one kernel later
+        assert ts._normed_version == sae.W_dec._version
+        with torch.no_grad():
+            Wd.data /= Wd.data.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps
     for name, p, ref, p0 in zip(("W_enc", "b_enc", "W_dec", "b_dec"),
                                 (sae.encoder.weight, sae.encoder.bias, sae.W_dec, sae.b_dec),
                                 (We, be, Wd, bd), params0):

@@ -5,6 +5,9 @@ Emulation on the bench workload (d = 4096, N = 131072, k = 32), 256 tokens, torc
 code): operands rounded to the candidate format exactly as a candidate pass would hold them -- per-row / per-token scales, then
   int8   rint(v / s),  s = max|v| / 127      (outlier dims of x kept exact here: the product quantises them at their own scale)
   e4m3   float8_e4m3fn(v / s),  s = max|v| / 448
+  e4m3 + MX   the same element type with OCP MX scales: one power-of-two scale per 32 elements along k (round 4: what the
+         hardware's scaled MFMA takes; it absorbs dynamic range -- the massive-activation dims need no outlier tile -- but the
+         elements keep their 3 mantissa bits)
   bf16   bfloat16(v)
 -- coarse values c = q(a) . q(W_n) in float64, exact values p in float64.  Reported per format:
   * rms and max of (c - p) / sigma_model over all pairs near the top (the model's sigma: int8 as in encode_fused.hip; fp8 / bf16
@@ -47,6 +50,16 @@ def q_e4m3(v):
     return (v / s).to(torch.float8_e4m3fn).float() * s
 
 
+def q_e4m3_mx(v):
+    """OCP MX (what v_mfma_scale_f32_32x32x64_f8f6f4 consumes): blocks of 32 elements along k share a power-of-two scale
+    X = 2^(floor(log2(max|block|)) - 8) (e4m3's emax), elements e4m3(v / X) with saturation at +-448."""
+    blk = v.reshape(v.shape[0], -1, 32)
+    amax = blk.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+    X = torch.exp2(torch.floor(torch.log2(amax)) - 8.0)
+    q = (blk / X).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * X
+    return q.reshape(v.shape)
+
+
 def q_bf16(v):
     return v.to(torch.bfloat16).float()
 
@@ -61,7 +74,8 @@ def matmul64(A, B):      # [T, d] x [N, d]^T in float64, in row blocks of B
 p = matmul64(a, W) + b_enc.double()
 vk = torch.relu(p).topk(k, dim=1).values[:, -1:]
 print(f"T={T} d={d} N={N} k={k}: exact k-th value mean {vk.mean():.3f}")
-for name, qa, qw in (("int8", q_int8(a, inl), q_int8(W)), ("e4m3", q_e4m3(a), q_e4m3(W)), ("bf16", q_bf16(a), q_bf16(W))):
+for name, qa, qw in (("int8", q_int8(a, inl), q_int8(W)), ("e4m3", q_e4m3(a), q_e4m3(W)),
+                     ("e4m3 + MX per-32 scales", q_e4m3_mx(a), q_e4m3_mx(W)), ("bf16", q_bf16(a), q_bf16(W))):
     c = matmul64(qa, qw) + b_enc.double()
     err = c - p
     sig = err.pow(2).mean(dim=1, keepdim=True).sqrt()                 # empirical per-token rms over all features
