@@ -134,7 +134,7 @@ struct FusedPlan {
   bool fast, i8, small;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
-  size_t off_xq, off_xqo, off_rowc, off_p4, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
+  size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_segcnt, off_segcand, off_flag, off_fbdense, off_dense, bytes;
   int segs;   // > 1: the candidate passes append to segmented lists (compact_candidates_kernel joins them)
 };
@@ -177,7 +177,6 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_wqos = take((size_t)p.S * MAX_OUT);
     }
     p.off_rowc = take((size_t)p.Tp * 16);
-    p.off_p4 = take((size_t)p.Tp * 4);
     p.off_refs = take(256);
     if (p.small) {
       p.off_xhi = take((size_t)T * d);
@@ -407,10 +406,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
     if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
       hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
-                         valid, need, (float *)nullptr);
+                         valid, need);
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
-                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, reinterpret_cast<float *>(ws + pl.off_p4));
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need);
     skip_sample = MAIN_SKIPS_SAMPLE && w_packed;   // the tile-major main operand holds the non-sample rows only
     cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
@@ -527,8 +526,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.fb_cap = T;
     ra.rows_out = co.rows_out;
     if (pl.i8) {   // byte diet of the re-score: band rows from the bf16 copy when the buffer holds a current one (Prepared::valid)
-      ra.wb = wb; ra.valid = valid; ra.colbf = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
-      ra.p4 = reinterpret_cast<const float *>(ws + pl.off_p4);
+      ra.wb = wb; ra.valid = valid;
     }
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + 2 * nrp) * 8 + 64;   // keys | res | refu + redo

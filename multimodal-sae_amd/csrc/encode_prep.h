@@ -264,9 +264,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
                                                       signed char *__restrict__ xq,
                                                       signed char *__restrict__ xqo,
                                                       f32x4 *__restrict__ rowc, float zz12, int tile_major,
-                                                      const unsigned *__restrict__ valid, unsigned need,
-                                                      float *__restrict__ p4) {
-  __shared__ float red[4][4];
+                                                      const unsigned *__restrict__ valid, unsigned need) {
+  __shared__ float red[3][4];
   const int t = blockIdx.x;
   auto xq_at = [&](int c) { return xq + (tile_major ? packed_off((size_t)t, c, d, tile_major) : (size_t)t * d + c); };
   if (t >= T) {
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
   }
-  float s4 = 0.f;                                // sum a^4 -> p4[t] = |a_t|_4^2 (the re-score's bf16-plane band, encode_rescore.h)
+
   const float *__restrict__ row32 = static_cast<const float *>(x) + (size_t)t * d;   // SRC == MSAE_F32 && !FROM_X: a32
   auto load4 = [&](int c) {
     if constexpr (!FROM_X) {
@@ -307,7 +306,6 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
         for (int e = 0; e < 4; ++e) {
           const float av = fabsf(v[e]);
           ss = __builtin_fmaf(av, av, ss);
-          s4 = __builtin_fmaf(av * av, av * av, s4);
           if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else m_in = fmaxf(m_in, av);
         }
       }
@@ -318,11 +316,9 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     m_in = fmaxf(m_in, __shfl_xor(m_in, off, 64));
     m_out = fmaxf(m_out, __shfl_xor(m_out, off, 64));
     ss += __shfl_xor(ss, off, 64);
-    s4 += __shfl_xor(s4, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m_in; red[1][threadIdx.x >> 6] = m_out; red[2][threadIdx.x >> 6] = ss; red[3][threadIdx.x >> 6] = s4; }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m_in; red[1][threadIdx.x >> 6] = m_out; red[2][threadIdx.x >> 6] = ss; }
   __syncthreads();
-  if (p4 && threadIdx.x == 0) p4[t] = __builtin_sqrtf((red[3][0] + red[3][1]) + (red[3][2] + red[3][3]));
   m_in = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
   m_out = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
   ss = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);

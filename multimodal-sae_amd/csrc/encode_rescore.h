@@ -24,12 +24,12 @@ struct RescoreArgs {
   // byte diet (round 4, int8 pass only): candidates that are probably NOT in the top-k -- list positions behind the first nA, the
   // ones whose coarse value lies more than beta sigma below the k-th -- are read from the bf16 copy of W_enc (half the bytes) in
   // the SAME pass, by the lanes that would otherwise stream their f32 rows: f32 activations x bf16 weights gives c2 with
-  // |p - c2| <= z sigma2, sigma2^2 = 2.75e-6 |a|_4^2 |W_n|_4^2 (one relative bf16 rounding per weight), 7x tighter than the int8
-  // band.  c2 + z sigma2 < v_k proves the feature out; the rest (and every winner: its value must be exact) is re-scored in f32.
+  // |p - c2| <= z sigma2, sigma2^2 = 2.75e-6 sum_k (a_k w_k)^2 (one relative bf16 rounding per weight; the lane accumulates the
+  // sum of squares beside the dot product: the separable bound |a|_4^2 |W_n|_4^2 is 4x looser on tokens with massive dims), 7x
+  // tighter than the int8 band.  c2 + z sigma2 < v_k proves the feature out; the rest (and every winner: its value must be exact)
+  // is re-scored in f32.
   const unsigned short *wb;           // W_bf16 [N][d] of the prepared buffer, or null
   const unsigned *valid;              // ... and the buffer's validity word (PREP_BF16 must be set)
-  const f32x4 *colbf;                 // per feature (1, |W_n|_4^2, 0, 0)
-  const float *p4;                    // per token |a_t|_4^2 (quant_x_kernel)
   // EXT (feature-sharded group, msae_rescore_candidates): the candidate lists come as the shards' records
   // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
   const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   int target = lim;
   int n_exact_first = lim;                       // byte diet: list positions [0, n_exact_first) of round 1 are read in f32
   bool use_b = false;
-  if constexpr (DIET) use_b = MSAE_RESCORE_BETA >= 0.f && i8 && p.wb != nullptr && p.p4 != nullptr && (*p.valid & PREP_BF16) != 0u;
+  if constexpr (DIET) use_b = MSAE_RESCORE_BETA >= 0.f && i8 && p.wb != nullptr && (*p.valid & PREP_BF16) != 0u;
   {
     const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
     const int mt = n < mt_max ? n : mt_max;
@@ -297,8 +297,6 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   int n_f32 = 0, n_b16 = 0;                      // rows read so far, by plane (diagnostics)
   bool ok = false, viol = false;
   int rounds = 0;
-  [[maybe_unused]] float p4t = 0.f;
-  if constexpr (DIET) { if (use_b) p4t = p.p4[t]; }
   for (;;) {
     ++rounds;
     int my_viol = 0;
@@ -310,8 +308,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // chain stays one serial ascending-k sequence: sub-step q multiplies the group's lane-q piece (every lane
     // executes it on its own registers; only lane q's is the true partial sum) and a quad rotate hands the
     // accumulator on.  The activations are wave-uniform scalar operands either way.
-    auto run_pass = [&](auto lpr_tag) {
+    auto run_pass = [&](auto lpr_tag, auto ref_tag) {
       constexpr int LPR = decltype(lpr_tag)::value;
+      constexpr bool REF = DIET && LPR == 1 && decltype(ref_tag)::value;   // this pass may hold refining lanes
       constexpr int RPP = NT / LPR;                  // rows per pass
       constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U * LPR;   // floats of a row per batch
       const int rq = lane / LPR, q = lane % LPR;
@@ -329,14 +328,15 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         const float upper = f32_from_order_key((unsigned)(key >> 32));
         const float *__restrict__ w = W_enc + (size_t)f * p.d + 4 * q;
         // byte diet: this lane reads its row from the bf16 plane (LPR == 1 passes of round 1 only)
-        const bool refine = DIET && LPR == 1 && active && c >= n_refine_from;
+        const bool refine = REF && active && c >= n_refine_from;
         [[maybe_unused]] const unsigned short *__restrict__ wh = p.wb + (size_t)f * p.d;
         float acc = 0.f;
+        [[maybe_unused]] float s2 = 0.f;                 // REF: sum_k (a_k w_k)^2 of this lane's row
         // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
         // other is in flight, so the lane never drains its loads
         f32x4 wa[RS_U], wb[RS_U];
         auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
-          if constexpr (DIET && LPR == 1) {
+          if constexpr (REF) {
             if (refine) {                                // 8 B per element quad: (w0 | w1 << 16), (w2 | w3 << 16) in dst[u][0 .. 1]
 #pragma unroll
               for (int u = 0; u < RS_U; ++u) {
@@ -366,12 +366,15 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
                 acc = __builtin_fmaf(av[3], src[u][3], acc);
               } else {
                 float w0 = src[u][0], w1 = src[u][1], w2 = src[u][2], w3 = src[u][3];
-                if constexpr (DIET && LPR == 1) {          // a refining lane holds four bf16 weights in the first two words
+                if constexpr (REF) {                       // a refining lane holds four bf16 weights in the first two words
                   const unsigned h0 = __float_as_uint(src[u][0]), h1 = __float_as_uint(src[u][1]);
                   w0 = refine ? __uint_as_float(h0 << 16) : w0;
                   w1 = refine ? __uint_as_float(h0 & 0xFFFF0000u) : w1;
                   w2 = refine ? __uint_as_float(h1 << 16) : w2;
                   w3 = refine ? __uint_as_float(h1 & 0xFFFF0000u) : w3;
+                  const float t0 = a[k0 + 0] * w0, t1 = a[k0 + 1] * w1, t2 = a[k0 + 2] * w2, t3 = a[k0 + 3] * w3;
+                  s2 = __builtin_fmaf(t0, t0, s2); s2 = __builtin_fmaf(t1, t1, s2);
+                  s2 = __builtin_fmaf(t2, t2, s2); s2 = __builtin_fmaf(t3, t3, s2);
                 }
                 acc = __builtin_fmaf(a[k0 + 0], w0, acc);   // a[] is wave-uniform: SGPRs
                 acc = __builtin_fmaf(a[k0 + 1], w1, acc);
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         if (active && q == 0) {                          // whole pieces done: the sum is back in the group's lane 0
           if (refine) {
             // c2 = f32(a) . bf16(W_n) + b: the feature's pre-activation up to the weights' bf16 roundings
-            if constexpr (DIET) {
-              const float e2 = __builtin_sqrtf(p.z2 * BF16_REL_VAR1 * p4t * p.colbf[f][1]);
+            if constexpr (REF) {
+              const float e2 = __builtin_sqrtf(p.z2 * BF16_REL_VAR1 * s2);
               refu[c] = pre + e2 + 1e-6f * __builtin_fabsf(pre);
             }
           } else {
@@ -421,9 +424,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     const bool few = rounds > 1 && n_work <= NT / 4;
     int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
     while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
-    if (lpr == 4) run_pass(std::integral_constant<int, 4>());
-    else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
-    else run_pass(std::integral_constant<int, 1>());
+    if (lpr == 4) run_pass(std::integral_constant<int, 4>(), std::false_type());
+    else if (lpr == 2) run_pass(std::integral_constant<int, 2>(), std::false_type());
+    else if (n_refine_from != 0x7FFFFFFF) run_pass(std::integral_constant<int, 1>(), std::true_type());
+    else run_pass(std::integral_constant<int, 1>(), std::false_type());
     {
       const int refined = (lpr == 1 && target > n_refine_from) ? target - (done > n_refine_from ? done : n_refine_from) : 0;
       n_b16 += refined;
