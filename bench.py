@@ -388,8 +388,7 @@ def main():
         rb = rows_buf[: out["status"].shape[0]] if out["status"].shape[0] <= rows_buf.shape[0] else rows_buf
         got = rb[rb > 0]
         if got.numel():
-            res["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())          # f32 rows (16 KB each at d = 4096)
-            res["rows_refined_bf16_per_token"] = float(((got >> 12) & 0xFFF).float().mean().item())   # band rows from the bf16 copy (8 KB)
+            res["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())
             res["rescore_rounds_per_token"] = float((got >> 24).float().mean().item())
         res["clock"] = dict(sampler_out)
 

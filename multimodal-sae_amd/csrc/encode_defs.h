@@ -130,7 +130,6 @@ constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this 
 // and recomputed by the exact path inside the call.  The test does not move with msae_options::guard_z.
 constexpr float GUARD_E0_SX = 4.f * 7.f * 0.288675f;   // 4 bands of z = 7: 8.08
 constexpr float GUARD_ZETA = MSAE_GUARD_ZETA;   // first round reaches zeta sigma below the k-th coarse value
-constexpr float BF16_REL_VAR1 = 2.75e-6f; // variance of ONE relative bf16 rounding (the re-score's refined values: only the weights are rounded)
 constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
 
 // index output of one call: 32-bit (msae_encode_topk), 64-bit (msae_encode_topk_i64), never both null

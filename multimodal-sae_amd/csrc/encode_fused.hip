@@ -525,11 +525,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
     ra.rows_out = co.rows_out;
-    if (pl.i8) {   // byte diet of the re-score: band rows from the bf16 copy when the buffer holds a current one (Prepared::valid)
-      ra.wb = wb; ra.valid = valid;
-    }
     const int nrp = next_pow2(pl.r_max + 1);
-    const size_t smem = ((size_t)pl.cap + 2 * nrp) * 8 + 64;   // keys | res | refu + redo
+    const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
     const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
     if (lrc) return lrc;
   }

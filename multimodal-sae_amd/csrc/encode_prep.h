@@ -274,7 +274,6 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 1.f, 0.f, 0.f};
     return;
   }
-
   const float *__restrict__ row32 = static_cast<const float *>(x) + (size_t)t * d;   // SRC == MSAE_F32 && !FROM_X: a32
   auto load4 = [&](int c) {
     if constexpr (!FROM_X) {

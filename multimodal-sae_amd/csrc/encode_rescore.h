@@ -21,15 +21,6 @@ struct RescoreArgs {
   float *vals; int32_t *idx; int64_t *idx64; int32_t *status;   // idx / idx64: either may be null
   int *flagged; int *n_flagged; int fb_cap;
   int32_t *rows_out;                  // optional diagnostics (msae_options::rows_rescored)
-  // byte diet (round 4, int8 pass only): candidates that are probably NOT in the top-k -- list positions behind the first nA, the
-  // ones whose coarse value lies more than beta sigma below the k-th -- are read from the bf16 copy of W_enc (half the bytes) in
-  // the SAME pass, by the lanes that would otherwise stream their f32 rows: f32 activations x bf16 weights gives c2 with
-  // |p - c2| <= z sigma2, sigma2^2 = 2.75e-6 sum_k (a_k w_k)^2 (one relative bf16 rounding per weight; the lane accumulates the
-  // sum of squares beside the dot product: the separable bound |a|_4^2 |W_n|_4^2 is 4x looser on tokens with massive dims), 7x
-  // tighter than the int8 band.  c2 + z sigma2 < v_k proves the feature out; the rest (and every winner: its value must be exact)
-  // is re-scored in f32.
-  const unsigned short *wb;           // W_bf16 [N][d] of the prepared buffer, or null
-  const unsigned *valid;              // ... and the buffer's validity word (PREP_BF16 must be set)
   // EXT (feature-sharded group, msae_rescore_candidates): the candidate lists come as the shards' records
   // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
   const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
@@ -103,11 +94,6 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
   [[maybe_unused]] int *ef = reinterpret_cast<int *>(ezs + p.cap);        // EXT only: [cap] global feature by position
   [[maybe_unused]] float *a_lds = EXT ? reinterpret_cast<float *>(ef + p.cap) : ezs;   // LDSA only: [d]
-  // byte diet (never with EXT / LDSA): refu[c] = upper bound of p of list position c when it was only REFINED (bf16 row), -inf
-  // when it was re-scored exactly; redo[] = refined positions whose bound still reaches v_k (exact re-score in the next round)
-  [[maybe_unused]] float *refu = reinterpret_cast<float *>(res + nrp);
-  [[maybe_unused]] int *redo = reinterpret_cast<int *>(refu + nrp);
-  constexpr bool DIET = !EXT && !LDSA;
   constexpr int NT = 64 * NW;
   __shared__ float s_cc[NT], s_zs[NT], s_pick[2];
   __shared__ int s_n;
@@ -238,9 +224,6 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   // ---- size of the first round ------------------------------------------------------------------
   const int lim = n < p.r_max ? n : p.r_max;
   int target = lim;
-  int n_exact_first = lim;                       // byte diet: list positions [0, n_exact_first) of round 1 are read in f32
-  bool use_b = false;
-  if constexpr (DIET) use_b = MSAE_RESCORE_BETA >= 0.f && i8 && p.wb != nullptr && (*p.valid & PREP_BF16) != 0u;
   {
     const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
     const int mt = n < mt_max ? n : mt_max;
@@ -272,14 +255,6 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       int n1 = count_needed(thr1);
       if (n1 < p.k + 4) n1 = p.k + 4;
       target = n1 < lim ? n1 : lim;
-      n_exact_first = target;
-      if (use_b) {
-        // a candidate with the median band whose coarse value lies beta sigma below the k-th coarse value has
-        // u = c_k + z sigma - beta sigma: everything in front of it is (most probably) a winner and is read in f32 at once
-        int na = count_needed(s_pick[0] + s_pick[1] - MSAE_RESCORE_BETA * s_pick[1] * __builtin_amdgcn_rsqf(p.z2));
-        if (na < p.k + 2) na = p.k + 2;
-        n_exact_first = na < target ? na : target;
-      }
     }
   }
   if constexpr (LDSA) {   // small batch: one pass reads 64 NW / lpr rows whatever the target -- fill it (fewer second rounds)
@@ -292,34 +267,28 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
   const bool guarded = !EXT && rc[3] != 0.f;     // the token's shape is outside the noise model (quant_x_kernel): exact path
   if (guarded) target = 0;                       // (no row is read for it here)
-  int done = 0;                                  // list positions [0, done) are settled: re-scored exactly or refined (wave-uniform)
-  int n_redo = 0;                                // refined positions that need the exact re-score after all
-  int n_f32 = 0, n_b16 = 0;                      // rows read so far, by plane (diagnostics)
+  int done = 0;                                  // candidates re-scored so far (wave-uniform)
   bool ok = false, viol = false;
   int rounds = 0;
+  const int first_target = target;
   for (;;) {
     ++rounds;
     int my_viol = 0;
-    const int n_work = n_redo + (target - done);   // this round: redo[0 .. n_redo) then list positions [done, target)
-    const int n_refine_from = (DIET && use_b && rounds == 1) ? n_exact_first : 0x7FFFFFFF;
     // LPR = 1: lane c streams row c (16 B per lane and instruction).  LPR = 4 (tuning builds): four lanes share a
     // row, lane q loading bytes [16 q, 16 q + 16) of every 64-B piece -- four times fewer cache lines per
     // instruction, but only 16 rows per pass, i.e. three row-streaming latencies per round instead of one.  The
     // chain stays one serial ascending-k sequence: sub-step q multiplies the group's lane-q piece (every lane
     // executes it on its own registers; only lane q's is the true partial sum) and a quad rotate hands the
     // accumulator on.  The activations are wave-uniform scalar operands either way.
-    auto run_pass = [&](auto lpr_tag, auto ref_tag) {
+    auto run_pass = [&](auto lpr_tag) {
       constexpr int LPR = decltype(lpr_tag)::value;
-      constexpr bool REF = DIET && LPR == 1 && decltype(ref_tag)::value;   // this pass may hold refining lanes
       constexpr int RPP = NT / LPR;                  // rows per pass
       constexpr int RS_U = MSAE_RESCORE_U, RS_B = 4 * RS_U * LPR;   // floats of a row per batch
       const int rq = lane / LPR, q = lane % LPR;
-      for (int i0 = 0; i0 < n_work; i0 += RPP) {
-        const int wi = i0 + rq;
-        const bool active = wi < n_work;
-        int c = 0;                                       // list position of this lane's row
-        if (active) c = wi < n_redo ? redo[wi] : done + (wi - n_redo);
-        const unsigned long long key = keys[c];
+      for (int c0 = done; c0 < target; c0 += RPP) {
+        const int c = c0 + rq;
+        const bool active = c < target;
+        const unsigned long long key = active ? keys[c] : keys[c0];
         int f = rank_key_index(key);
         float ext_zs = 0.f;
         f32x4 cc = {0.f, 0.f, 0.f, 0.f};
@@ -327,27 +296,11 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         else cc = p.colc[f];
         const float upper = f32_from_order_key((unsigned)(key >> 32));
         const float *__restrict__ w = W_enc + (size_t)f * p.d + 4 * q;
-        // byte diet: this lane reads its row from the bf16 plane (LPR == 1 passes of round 1 only)
-        const bool refine = REF && active && c >= n_refine_from;
-        [[maybe_unused]] const unsigned short *__restrict__ wh = p.wb + (size_t)f * p.d;
         float acc = 0.f;
-        [[maybe_unused]] float s2 = 0.f;                 // REF: sum_k (a_k w_k)^2 of this lane's row
         // two batches of RS_U x 16 B per lane, software-pipelined: while one batch is consumed the
         // other is in flight, so the lane never drains its loads
         f32x4 wa[RS_U], wb[RS_U];
         auto fetch = [&](f32x4 (&dst)[RS_U], int kk) {
-          if constexpr (REF) {
-            if (refine) {                                // 8 B per element quad: (w0 | w1 << 16), (w2 | w3 << 16) in dst[u][0 .. 1]
-#pragma unroll
-              for (int u = 0; u < RS_U; ++u) {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 h = *reinterpret_cast<const u32x2 *>(wh + kk + 4 * u);
-                dst[u][0] = __uint_as_float(h[0]);
-                dst[u][1] = __uint_as_float(h[1]);
-              }
-              return;
-            }
-          }
 #pragma unroll
           for (int u = 0; u < RS_U; ++u) dst[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * LPR * u);
         };
@@ -365,21 +318,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
                 acc = __builtin_fmaf(av[2], src[u][2], acc);
                 acc = __builtin_fmaf(av[3], src[u][3], acc);
               } else {
-                float w0 = src[u][0], w1 = src[u][1], w2 = src[u][2], w3 = src[u][3];
-                if constexpr (REF) {                       // a refining lane holds four bf16 weights in the first two words
-                  const unsigned h0 = __float_as_uint(src[u][0]), h1 = __float_as_uint(src[u][1]);
-                  w0 = refine ? __uint_as_float(h0 << 16) : w0;
-                  w1 = refine ? __uint_as_float(h0 & 0xFFFF0000u) : w1;
-                  w2 = refine ? __uint_as_float(h1 << 16) : w2;
-                  w3 = refine ? __uint_as_float(h1 & 0xFFFF0000u) : w3;
-                  const float t0 = a[k0 + 0] * w0, t1 = a[k0 + 1] * w1, t2 = a[k0 + 2] * w2, t3 = a[k0 + 3] * w3;
-                  s2 = __builtin_fmaf(t0, t0, s2); s2 = __builtin_fmaf(t1, t1, s2);
-                  s2 = __builtin_fmaf(t2, t2, s2); s2 = __builtin_fmaf(t3, t3, s2);
-                }
-                acc = __builtin_fmaf(a[k0 + 0], w0, acc);   // a[] is wave-uniform: SGPRs
-                acc = __builtin_fmaf(a[k0 + 1], w1, acc);
-                acc = __builtin_fmaf(a[k0 + 2], w2, acc);
-                acc = __builtin_fmaf(a[k0 + 3], w3, acc);
+                acc = __builtin_fmaf(a[k0 + 0], src[u][0], acc);   // a[] is wave-uniform: SGPRs
+                acc = __builtin_fmaf(a[k0 + 1], src[u][1], acc);
+                acc = __builtin_fmaf(a[k0 + 2], src[u][2], acc);
+                acc = __builtin_fmaf(a[k0 + 3], src[u][3], acc);
               }
               if constexpr (LPR == 4)   // quad_perm:[3,0,1,2] -- lane i takes lane i - 1's value, lane 0 lane 3's
                 acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x93, 0xF, 0xF, false));
@@ -398,18 +340,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         }
         const float pre = acc + (p.b_enc ? p.b_enc[f] : 0.f);
         if (active && q == 0) {                          // whole pieces done: the sum is back in the group's lane 0
-          if (refine) {
-            // c2 = f32(a) . bf16(W_n) + b: the feature's pre-activation up to the weights' bf16 roundings
-            if constexpr (REF) {
-              const float e2 = __builtin_sqrtf(p.z2 * BF16_REL_VAR1 * s2);
-              refu[c] = pre + e2 + 1e-6f * __builtin_fabsf(pre);
-            }
-          } else {
-            res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
-            if constexpr (DIET) refu[c] = -__builtin_inff();
-          }
-          // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2  (a refined value serves as well:
-          // its own error is a tenth of a sigma)
+          res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);  // slots past the sorted prefix are 0
+          // model check: |p - coarse| <= 6 sigma  <=>  (p - coarse)^2 z^2 <= 36 (z sigma)^2
           const float zs2 = EXT ? ext_zs * ext_zs : band_sq(rc, cc, p.zz12, i8);
           const float diff = pre - (upper - __builtin_sqrtf(zs2));
           if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
@@ -421,54 +353,32 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
     // p.lpr lanes per row and as many waves per token.
     if (partial && target > n_sorted) need_full();          // wave-uniform
-    const bool few = rounds > 1 && n_work <= NT / 4;
+    const bool few = rounds > 1 && target - done <= NT / 4;
     int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
     while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
-    if (lpr == 4) run_pass(std::integral_constant<int, 4>(), std::false_type());
-    else if (lpr == 2) run_pass(std::integral_constant<int, 2>(), std::false_type());
-    else if (n_refine_from != 0x7FFFFFFF) run_pass(std::integral_constant<int, 1>(), std::true_type());
-    else run_pass(std::integral_constant<int, 1>(), std::false_type());
-    {
-      const int refined = (lpr == 1 && target > n_refine_from) ? target - (done > n_refine_from ? done : n_refine_from) : 0;
-      n_b16 += refined;
-      n_f32 += n_work - refined;
-    }
+    if (lpr == 4) run_pass(std::integral_constant<int, 4>());
+    else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
+    else run_pass(std::integral_constant<int, 1>());
     done = target;
     viol = viol || (__syncthreads_or(my_viol) != 0);
     MSAE_RTL(2 + 2 * rounds);
-    {   // res[] is zero (= empty, the smallest key) behind the slots written so far (and in the slots of refined positions): sort
-        // the prefix that can hold values
+    {   // res[] is zero (= empty, the smallest key) behind the slots written so far: sort the filled prefix only
       const int filled = next_pow2(done + has_set > 2 ? done + has_set : 2);
       wave_sort_desc_u64<NT>(res, filled < nrp ? filled : nrp, lane);
     }
     MSAE_RTL(3 + 2 * rounds);
-    const bool have_k = n_f32 + has_set >= p.k;                  // exact values in res[]
+    const bool have_k = done + has_set >= p.k;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
     const int needed = have_k ? count_needed(v_k) : n;          // candidates with u >= v_k
-    // refined positions whose bound still reaches v_k (a lower bound of the final k-th value: it only rises): exact re-score
-    n_redo = 0;
-    if constexpr (DIET) {
-      if (n_b16 > 0) {                                           // wave-uniform
-        if (lane == 0) s_n = 0;
-        __syncthreads();
-        for (int c0 = 0; c0 < done; c0 += NT) {
-          const int c = c0 + lane;
-          if (c < done && (!have_k || refu[c] >= v_k) && refu[c] > -__builtin_inff()) redo[atomicAdd(&s_n, 1)] = c;
-        }
-        __syncthreads();
-        n_redo = s_n;
-        __syncthreads();
-      }
-    }
-    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && n_redo == 0 && v_k > tau * 1.000001f && !guarded;
-    if (ok || viol || guarded || (done >= lim && n_redo == 0) || !(tau > 0.f) || cnt > p.cap) break;
-    target = needed > done ? needed : (n_redo > 0 ? done : done + 1);
+    ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f && !guarded;
+    if (ok || viol || guarded || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
+    target = needed > done ? needed : done + 1;
     if (target > lim) target = lim;
     __syncthreads();
   }
 
   MSAE_RTL(14);
-  MSAE_RTL_VALUE(15, ((unsigned long long)rounds << 32) | (unsigned)(n_f32 + n_b16));
+  MSAE_RTL_VALUE(15, ((unsigned long long)rounds << 32) | (unsigned)done);
   for (int j = lane; j < p.k; j += NT) {
     const unsigned long long key = res[j];
     const int fi = key ? rank_key_index(key) : 0;
@@ -481,10 +391,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // 32 more than r_max rows needed / v_k not above tau, 64 a re-scored pair contradicted the error
     // model); the exact fallback rewrites it to 1 once it has recomputed t
     const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
-                       (n_f32 + has_set < p.k ? 16 : 0) | (guarded ? 128 : (viol ? 64 : 32));
+                       (done + has_set < p.k ? 16 : 0) | (guarded ? 128 : (viol ? 64 : 32));
     if (p.status) p.status[t] = ok ? 0 : reason;
-    // msae_options::rows_rescored: rounds << 24 | rows read from the bf16 plane << 12 | f32 rows of W_enc read (0: not verified here)
-    if (p.rows_out) p.rows_out[t] = ok ? (rounds << 24) | ((n_b16 & 0xFFF) << 12) | (n_f32 & 0xFFF) : 0;
+    // msae_options::rows_rescored: rounds << 24 | first-round rows << 12 | rows of W_enc this token read (0: not verified here)
+    if (p.rows_out) p.rows_out[t] = ok ? (rounds << 24) | (first_target << 12) | done : 0;
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
       if (slot < p.fb_cap) p.flagged[slot] = t;

@@ -26,9 +26,6 @@
 #ifndef MSAE_RESCORE_LPR       // lanes that share a row of W_enc in the FIRST round's re-scoring stream: 1, or 4 (64-B pieces per
 #define MSAE_RESCORE_LPR 1     // row and instruction, 16 rows per pass: measured 1.61 ms against 1.17 -- not the default)
 #endif
-#ifndef MSAE_RESCORE_BETA      // re-score byte diet: candidates whose coarse value lies more than beta sigma below the k-th are
-#define MSAE_RESCORE_BETA 3.f  // first read from the bf16 plane (half the bytes); < 0 in a tuning build switches the diet off
-#endif
 #ifndef MSAE_GUARD_ZETA        // first re-score round reaches zeta sigma below the k-th coarse value
 #define MSAE_GUARD_ZETA 1.f
 #endif

@@ -1,4 +1,4 @@
-"""Rows / rounds of the re-scoring stage per token, from msae_options::rows_rescored (rounds << 24 | rows read from the bf16 plane << 12 | f32 rows):
+"""Rows / rounds of the re-scoring stage per token, from msae_options::rows_rescored (rounds << 24 | first-round rows << 12 | rows):
 
     python tools/rescore_stats.py [bench|trained_like|lognorm|...]        (K=256 in the environment: k = 256)
 """
@@ -28,7 +28,7 @@ for kind in kinds:
         ok = s >= (1 << 24)
         rounds, first, rows = s[ok] >> 24, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
         print(f"k={k} {kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
-              f"mean f32 rows {rows.float().mean():.1f} (+ bf16-plane rows {first.float().mean():.1f})  "
+              f"mean rows {rows.float().mean():.1f} (first round {first.float().mean():.1f})  "
               f"rows p50/p99/max {int(rows.float().quantile(0.5))}/{int(rows.float().quantile(0.99))}/{int(rows.max())}  "
               f"not verified: {torch.unique(st[~ok], return_counts=True)}", flush=True)
         del prep
