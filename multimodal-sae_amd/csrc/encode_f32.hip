@@ -96,10 +96,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void pre_acts_f32_kernel(
     int T, int d, int N, int relu, float *__restrict__ out, int ld_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (n_rows) T = min(T, *n_rows);
-  const int n0 = blockIdx.x * F_BN;
   constexpr int STAGE = (F_BM + F_BN) * F_PITCH;  // floats per stage: A tile then B tile
-  // row tiles blockIdx.y, +gridDim.y, ...: with a device-side row count the launch is sized for a
-  // few tiles only and a workgroup walks as many as the count needs (none -> it leaves at once)
+  // row tiles blockIdx.y, +gridDim.y, ... and column tiles blockIdx.x, +gridDim.x, ...: with a device-side row count the
+  // launch is sized for a few tiles only and a workgroup walks as many as the count needs (none -> it leaves at once: the
+  // empty launch of the in-call exact fallback is 512 workgroups, not N / 128 * 2)
+  for (int n0 = blockIdx.x * F_BN; n0 < N; n0 += gridDim.x * F_BN)
   for (int m0 = blockIdx.y * F_BM; m0 < T; m0 += gridDim.y * F_BM) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -169,8 +170,10 @@ int launch_dt(const void *x, const float *W, const float *b_enc, const float *b_
   const bool vec = (d % 4 == 0) && msae_aligned(x, xb) && msae_aligned(W, 16) &&
                    (!b_dec || msae_aligned(b_dec, 16));
   int tiles_m = (T + F_BM - 1) / F_BM;
-  if (n_rows && tiles_m > 2) tiles_m = 2;   // device-side count: workgroups loop over the row tiles
-  dim3 grid((N + F_BN - 1) / F_BN, tiles_m);
+  int tiles_n = (N + F_BN - 1) / F_BN;
+  if (n_rows && tiles_m > 2) tiles_m = 2;   // device-side count: workgroups loop over the row tiles ...
+  if (n_rows && tiles_n > 256) tiles_n = 256;   // ... and over the column tiles
+  dim3 grid(tiles_n, tiles_m);
   const size_t smem = F_LDS_FLOATS * sizeof(float);
   if (vec) {
     auto kern = pre_acts_f32_kernel<DT, true>;

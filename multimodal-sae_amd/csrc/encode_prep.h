@@ -323,7 +323,12 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   ss = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
   const float scale = m_in > 0.f ? m_in / 127.f : (m_out > 0.f ? m_out / 127.f : 1.f);
   int m = (int)ceilf(m_out / (127.f * scale));
-  m = m < 1 ? 1 : (m > 32768 ? 32768 : m);   // the GEMM multiplies by m with a 24-bit multiply
+  // the GEMM multiplies the outlier tile's int32 accumulator (|acc| <= 128 * 127 * 127 < 2^21) by m with a 24-bit multiply and
+  // keeps the product in int32: m <= M_MAX keeps it below 2^31.  A token whose outlier dims dwarf its inliers by more than that
+  // is clamped AND handed to the exact path (guard below): its coarse values would be wrong, not merely noisy.
+  constexpr int M_MAX = 1040;
+  const bool m_over = m > M_MAX;
+  m = m < 1 ? 1 : (m > M_MAX ? M_MAX : m);
   const float inv = 1.f / scale, inv_o = 1.f / (scale * (float)m);
   float e0 = 0.f;                              // energy of the non-outlier dims that round to zero (GUARD_E0_BANDS)
   int it2 = 0;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   if (threadIdx.x == 0) {
     e0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     // (stale operands, Prepared::valid: the candidate pass would read old weights -- every token to the exact path)
-    const float guard = (e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale || (*valid & need) != need) ? 1.f : 0.f;
+    const float guard = (e0 > GUARD_E0_SX * GUARD_E0_SX * scale * scale || (*valid & need) != need || m_over) ? 1.f : 0.f;
     rowc[t] = f32x4{scale, (float)m, zz12 * ss, guard};
   }
   if (threadIdx.x < MAX_OUT) {

@@ -753,7 +753,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     ++seq;
   };
   auto scale_by_m = [&]() {
-    // |acc| <= 128 * 127 * 127 < 2^23 here and m < 2^23: the full-rate 24-bit multiply is exact
+    // |acc| <= 128 * 127 * 127 < 2^21 here and m <= 1040 (quant_x_kernel clamps and hands larger multipliers' tokens to the exact
+    // path): the full-rate 24-bit multiply is exact and the product fits int32
     // (v_mul_lo_u32 is quarter rate: 128 of them per lane cost ~2 us per tile)
 #pragma unroll
     for (int i = 0; i < C::MI; ++i)

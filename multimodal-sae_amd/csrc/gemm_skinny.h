@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
         mfma(tg, *reinterpret_cast<const i32x4 *>(op.Ao + (size_t)(tg * 16 + l15) * 128 + ks * 64 + lg * 16), b);
     }
     __syncthreads();                                   // side_m written
-    if (lead_ks > 0) {                                 // |acc| < 2^23 and m < 2^23: the 24-bit multiply is exact
+    if (lead_ks > 0) {                                 // |acc| < 2^21 and m <= 1040 (quant_x_kernel: larger multipliers send the token to the exact path): the product fits int32
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg)
 #pragma unroll

@@ -5,6 +5,8 @@ Text feature caching, same command line as `sae_auto_interp.launch.cache.cache`
 concat.  The SAE work inside the forward hook runs on the fused HIP path."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -14,7 +16,7 @@ from ...utils import ddp_setup, load_filter, load_saes, maybe_load_llava_model, 
 
 
 def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "text", batch_docs: int = 2048,
-                       return_final_batch: bool = False):
+                       return_final_batch: bool = False, num_proc: int = 1):
     """GPT-style chunking with the reference's semantics (sae_auto_interp/sae/data.py:16-100), chunk for chunk:
 
       * documents are taken in batches of 2048 (`Dataset.map(batched=True, batch_size=2048)` there); the texts of a
@@ -24,8 +26,13 @@ def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "te
         returns one row per chunk (special tokens re-added on every row) -- both taken as they come;
       * the last chunk of EVERY batch (ragged almost surely) is dropped unless `return_final_batch`.
 
-    So chunk boundaries and therefore the cache's `row` ids equal the reference's on the same dataset (golden
-    fixture g11: 2500 documents, both tokenizer kinds).  Returns a `datasets.Dataset` in torch format with the single
+    So chunk boundaries and therefore the cache's `row` ids equal the reference's on the same dataset WHEN THE REFERENCE
+    MAPS WITH ONE PROCESS (golden fixture g11: 2500 documents, both tokenizer kinds, num_proc = 1).  The reference's
+    launcher passes num_proc = cpu_count() // 2 (launch/cache/cache.py:58): `Dataset.map` then cuts the dataset into
+    that many contiguous shards first and batches 2048 documents inside each, so a batch never spans a shard border
+    and one more ragged chunk is dropped per shard -- `num_proc` below reproduces that split (the same
+    `Dataset.shard(contiguous=True)` arithmetic: the first len % n shards hold one more document), still on one host
+    process.  Returns a `datasets.Dataset` in torch format with the single
     column `input_ids`, which the caller shards with `.shard(world, rank, contiguous=True)` like the reference
     (launch/cache/cache.py:66).  Only the chunk ids are kept in memory (one batch of texts at a time)."""
     from datasets import Dataset
@@ -33,8 +40,15 @@ def chunk_and_tokenize(dataset, tokenizer, max_seq_len: int, text_key: str = "te
     chunk = min(tokenizer.model_max_length, max_seq_len)
     sep = tokenizer.eos_token or "<|endoftext|>"
     rows = []
-    for start in range(0, len(dataset), batch_docs):
-        texts = dataset[start:start + batch_docs][text_key]
+    n_docs, n_sh = len(dataset), max(1, min(int(num_proc), len(dataset)))
+    div, mod = divmod(n_docs, n_sh)
+    starts = []                                        # (start, stop) of every 2048-document batch, shard by shard
+    for sh in range(n_sh):
+        lo = sh * div + min(sh, mod)
+        hi = lo + div + (1 if sh < mod else 0)
+        starts += [(b, min(b + batch_docs, hi)) for b in range(lo, hi, batch_docs)]
+    for start, stop in starts:
+        texts = dataset[start:stop][text_key]
         enc = tokenizer(sep.join([""] + list(texts)), max_length=chunk, return_attention_mask=False,
                         return_overflowing_tokens=True, truncation=True)
         ids = enc["input_ids"]
@@ -64,7 +78,9 @@ def main(cfg: CacheConfig):
     tokenizer = AutoTokenizer.from_pretrained(cfg.model, token=cfg.hf_token)
     dataset = load_dataset(cfg.dataset, split=cfg.split)
     filters = load_filter(cfg.filters_path, device=model.device) if cfg.filters_path else None
-    dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len)
+    # the reference's default: num_proc = cpu_count() // 2 (sae_auto_interp/sae/data.py:21) -- the same chunks, hence the same
+    # cache row ids, as the reference produces on this machine
+    dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=max(1, (os.cpu_count() or 2) // 2))
     shard_size = 0
     if ddp:
         dist.barrier()

@@ -50,6 +50,8 @@ def _natural_key(s: str):
 
 
 class Sae(nn.Module):
+    _warned_detached = False     # the one-time notice of Sae.encode (see its docstring)
+
     def __init__(self, d_in: int, cfg: SaeConfig, device: Union[str, torch.device] = "cpu",
                  dtype: Union[torch.dtype, None] = None, *, decoder: bool = True):
         super().__init__()
@@ -181,8 +183,19 @@ class Sae(nn.Module):
         Autograd: the call is one differentiable node (sparse backward through the selected latents) when
         gradients are enabled and `x` requires grad (the attribution hooks: the LLM's hidden states do) or
         `differentiable=True` is passed (a custom training loop that wants d/dW from a constant input);
-        plain inference on a loaded module -- whose parameters require grad by default -- saves nothing."""
+        plain inference on a loaded module -- whose parameters require grad by default -- saves nothing.  Where the
+        reference's encode would have carried gradient to its parameters and this call does not (gradients enabled, a
+        parameter requires grad, constant input, `differentiable` left unset) a one-time warning says so."""
         want_grad = torch.is_grad_enabled() and (x.requires_grad if differentiable is None else differentiable)
+        if (differentiable is None and not want_grad and torch.is_grad_enabled() and not Sae._warned_detached and
+                (self.encoder.weight.requires_grad or self.encoder.bias.requires_grad or self.b_dec.requires_grad)):
+            import warnings
+
+            Sae._warned_detached = True
+            warnings.warn("Sae.encode: gradients are enabled and the SAE's parameters require grad, but the input does not: "
+                          "this call returns DETACHED latents (the reference's encode would carry gradient to encoder.weight "
+                          "/ bias / b_dec).  Pass differentiable=True to fine-tune through encode(), or run inference under "
+                          "torch.no_grad() / on sae.requires_grad_(False) to silence this.", stacklevel=2)
         if want_grad and exact:
             raise RuntimeError("Sae.encode(exact=True) is an inference switch: differentiate pre_acts -> select_topk (the "
                                "exact path with autograd) instead")

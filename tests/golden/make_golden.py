@@ -406,6 +406,12 @@ def chunker_fixture(Sae=None, SaeConfig=None):
         got = chunk_and_tokenize(ds, tok, max_seq_len=48, num_proc=1, load_from_cache_file=False)
         out[name] = np.asarray(got["input_ids"], dtype=np.int64)
         print("chunker", name, out[name].shape)
+    # the reference's launcher maps with num_proc = cpu_count() // 2 (launch/cache/cache.py:58): Dataset.map cuts the
+    # dataset into that many contiguous shards and batches inside each (one more ragged chunk dropped per shard)
+    ds = datasets.Dataset.from_dict({"text": docs})
+    got = chunk_and_tokenize(ds, fakes.FakeSlowTokenizer(64), max_seq_len=48, num_proc=3, load_from_cache_file=False)
+    out["slow_num_proc3"] = np.asarray(got["input_ids"], dtype=np.int64)
+    print("chunker slow, num_proc=3", out["slow_num_proc3"].shape)
     np.savez_compressed(HERE / "g11_chunker.npz", **out)
 
 

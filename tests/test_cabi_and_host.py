@@ -313,5 +313,10 @@ def test_chunk_and_tokenize_matches_reference_chunker(golden_dir):
         ids = np.asarray(got["input_ids"], dtype=np.int64)
         assert ids.shape == g[name].shape, (name, ids.shape, g[name].shape)
         assert np.array_equal(ids, g[name]), name
+    # the reference's launcher maps with num_proc > 1: contiguous shards first, 2048-document batches inside each
+    got = chunk_and_tokenize(datasets.Dataset.from_dict({"text": docs}), fakes.FakeSlowTokenizer(64), max_seq_len=48, num_proc=3)
+    ids = np.asarray(got["input_ids"], dtype=np.int64)
+    assert ids.shape == g["slow_num_proc3"].shape and np.array_equal(ids, g["slow_num_proc3"])
+    assert ids.shape != g["slow"].shape or not np.array_equal(ids, g["slow"])      # (the split really changes the chunks)
     with pytest.raises(ValueError, match="Not enough data"):
         chunk_and_tokenize(datasets.Dataset.from_dict({"text": ["w1 w2"]}), fakes.FakeSlowTokenizer(64), max_seq_len=48)
