@@ -235,11 +235,13 @@ int msae_decode_bwd_acts_f32(const int32_t *idx, const float *grad_out, const fl
  * Pairs whose index lies outside [0, N) contribute nothing and are flagged in `status` (int32[1], optional).
  * d % 4 == 0.  row_sumsq (optional, f32[N]) receives |g_W_dec[n][:]|^2 per row while the row is in registers: the
  * gradient-norm pass of clip_grad_norm_ (train/sae/sae/trainer.py:390) without re-reading the 2 GiB gradient
- * (msae_sum_f32 adds the rows up in a fixed order). */
+ * (msae_sum_f32 adds the rows up in a fixed order).  row_act_sum (optional, f32[N]) receives the sum of acts over the
+ * row's pairs in ascending pair order: with acts = the latents' gradients (the sparse encoder backward, msae/ops.py) that is
+ * the encoder-bias gradient, without index_add_'s atomics. */
 size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N);
 int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts, const float *grad_out, int A,
-                             int k, int N, int d, float *g_W_dec, float *row_sumsq, int32_t *status, void *ws,
-                             size_t ws_bytes, void *stream);
+                             int k, int N, int d, float *g_W_dec, float *row_sumsq, float *row_act_sum,
+                             int32_t *status, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- feature-cache sparsify ------------------------------------------------------------------
  * From the per-token top-k (vals/idx[B*S][k], any order) produce the reference cache's COO
@@ -282,6 +284,12 @@ int msae_merge_topk_masked(const int32_t *gathered, int T, int G, int kl, int k,
  *                          weight decay, trainer.py:139-146,395) on W, M, V in place, `step` >= 1.
  *                          G is read only. */
 int msae_unit_norm_rows_f32(float *W, int N, int d, float eps, void *stream);
+/* out[d] = scale * sum_n s[n] * W[n][:] in a fixed order (rows with s[n] == 0 are not read): the b_dec gradient of the sparse
+ * encoder backward, -(s^T W_enc) with s = row_act_sum, as ONE streaming read of W_enc (the reference back-propagates a dense
+ * [T, N] gradient through nn.Linear, sae.py:172-177; a k-row gather per token is the sparse alternative).  d % 4 == 0. */
+size_t msae_weighted_row_sum_ws_bytes(int d);
+int msae_weighted_row_sum_f32(const float *W, const float *s, int N, int d, float scale, float *out, void *ws,
+                              size_t ws_bytes, void *stream);
 /* *accum += v[0] + ... + v[n - 1], summed in a fixed order (bit-reproducible): the total of row_sumsq. */
 int msae_sum_f32(const float *v, size_t n, float *accum, void *stream);
 /* msae_adam_rows_f32 with the NEXT step's passes over the same matrix folded into the one sweep:

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
                                                           const float *__restrict__ grad_out,
                                                           const int *__restrict__ offsets,
                                                           int *__restrict__ perm, int k, int N, int d,
-                                                          float *__restrict__ g_W, float *__restrict__ rowsq) {
+                                                          float *__restrict__ g_W, float *__restrict__ rowsq,
+                                                          float *__restrict__ rowsum) {
   __shared__ int s_seg[4][WGRAD_LDS_SEG];
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -300,6 +301,15 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
         ss += acc[u][0] * acc[u][0] + acc[u][1] * acc[u][1] + acc[u][2] * acc[u][2] + acc[u][3] * acc[u][3];
       }
     }
+  }
+  if (rowsum) {  // sum of the row's pair activations in ascending pair order (lane l: pairs l, l + 64, ...; then a fixed
+                 // reduction tree): with acts = the latents' gradients this IS the encoder bias gradient of feature n -- no
+                 // index_add_ with its atomics, bit-reproducible
+    float sa = 0.f;
+    for (int e = beg + lane; e < end; e += 64) sa += acts[perm[e]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sa += __shfl_xor(sa, off, 64);
+    if (lane == 0) rowsum[n] = sa;
   }
   if (rowsq) {   // the gradient-norm pass of clip_grad_norm_ (trainer.py:390) for free: the row is in registers, fixed order
 #pragma unroll
@@ -366,8 +376,8 @@ extern "C" size_t msae_decode_bwd_wdec_ws_bytes(int A, int k, int N) {
 
 extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
                                         const float *grad_out, int A, int k, int N, int d,
-                                        float *g_W_dec, float *row_sumsq, int32_t *status, void *ws, size_t ws_bytes,
-                                        void *stream) {
+                                        float *g_W_dec, float *row_sumsq, float *row_act_sum, int32_t *status, void *ws,
+                                        size_t ws_bytes, void *stream) {
   if (A < 0 || k <= 0 || N <= 0 || d <= 0 || d % 4 != 0) return MSAE_EINVAL;
   if (!ws || ws_bytes < msae_decode_bwd_wdec_ws_bytes(A, k, N)) return MSAE_EWS;
   if (!msae_aligned(grad_out, 16) || !msae_aligned(g_W_dec, 16) || !msae_aligned(ws, 256)) return MSAE_EALIGN;
@@ -388,6 +398,6 @@ extern "C" int msae_decode_bwd_wdec_f32(const int32_t *idx, const float *acts,
     hipLaunchKernelGGL(wgrad_zero_kernel, dim3(256), dim3(256), 0, s, offsets, N + 1);
   }
   hipLaunchKernelGGL(wgrad_accum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, acts, grad_out, offsets, perm,
-                     k, N, d, g_W_dec, row_sumsq);
+                     k, N, d, g_W_dec, row_sumsq, row_act_sum);
   return msae_launch_status();
 }

@@ -566,6 +566,9 @@ def collect_wgrad_sumsq():
         _WGRAD_COLLECT = prev
 
 
+_WGRAD_ROWSUM: Optional[list] = None      # set by _SparseEncode.backward around its weight-gradient call
+
+
 @torch.library.custom_op("msae::decode_bwd", mutates_args=())
 def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: Tensor,
                need_acts: bool, need_w: bool) -> Tuple[Tensor, Tensor]:
@@ -586,10 +589,13 @@ def decode_bwd(top_indices: Tensor, top_acts: Tensor, W_dec: Tensor, grad_out: T
         if need_w:
             ws = _workspace(dev, lib.msae_decode_bwd_wdec_ws_bytes(A, k, N))
             rowsq = torch.empty(N, dtype=torch.float32, device=dev) if _WGRAD_COLLECT is not None else None
+            rowsum = torch.empty(N, dtype=torch.float32, device=dev) if _WGRAD_ROWSUM is not None else None
             _hip.check(lib.msae_decode_bwd_wdec_f32(_hip.ptr(idx), _hip.ptr(acts), _hip.ptr(g), A, k, N,
-                                                    d, _hip.ptr(g_w), _hip.ptr(rowsq), _hip.ptr(flag), _hip.ptr(ws),
-                                                    ws.numel(), st),
+                                                    d, _hip.ptr(g_w), _hip.ptr(rowsq), _hip.ptr(rowsum), _hip.ptr(flag),
+                                                    _hip.ptr(ws), ws.numel(), st),
                        "msae_decode_bwd_wdec_f32")
+            if rowsum is not None:
+                _WGRAD_ROWSUM.append(rowsum)
             if rowsq is not None:
                 ent = _WGRAD_COLLECT.setdefault(W_dec.data_ptr(), [0, 0, None])
                 ent[0] += 1
@@ -791,12 +797,23 @@ class _SparseEncode(torch.autograd.Function):
         a = x.float() - b_dec
         need_x, need_W, need_be, need_bd = ctx.needs_input_grad[:4]
         g_x = g_W = g_be = g_bd = None
+        rowsum = None
         if need_W:
-            _, g_W = decode_bwd(idx_cat, g_cat, W_enc, a.contiguous(), False, True)
+            # the weight-gradient kernel also sums every feature's latent gradients (ascending pair order): the encoder-bias
+            # gradient without index_add_'s atomics, and the vector s of the b_dec gradient -(s^T W_enc) below
+            global _WGRAD_ROWSUM
+            prev, _WGRAD_ROWSUM = _WGRAD_ROWSUM, []
+            try:
+                _, g_W = decode_bwd(idx_cat, g_cat, W_enc, a.contiguous(), False, True)
+                rowsum = _WGRAD_ROWSUM[0] if _WGRAD_ROWSUM else None
+            finally:
+                _WGRAD_ROWSUM = prev
         if need_be and ctx.has_b_enc:
-            g_be = torch.zeros(W_enc.shape[0], device=g_cat.device).index_add_(
+            g_be = rowsum if rowsum is not None else torch.zeros(W_enc.shape[0], device=g_cat.device).index_add_(
                 0, idx_cat.reshape(-1), g_cat.reshape(-1))
-        if need_x or need_bd:
+        if need_bd and not need_x and rowsum is not None and W_enc.shape[1] % 4 == 0:
+            g_bd = weighted_row_sum(W_enc, rowsum, -1.0)          # ONE streaming read of W_enc (training: x is a constant)
+        elif need_x or need_bd:
             da = decode(idx_cat, g_cat, W_enc, None)
             g_x = da.to(x.dtype) if need_x else None
             g_bd = -da.sum(0) if need_bd else None
@@ -837,6 +854,22 @@ def grad_sumsq_(accum: Tensor, g: Tensor) -> Tensor:
         _hip.check(_hip.load().msae_grad_sumsq_f32(_hip.ptr(g), g.numel(), _hip.ptr(accum), _hip.stream_of(g)),
                    "msae_grad_sumsq_f32")
     return accum
+
+
+def weighted_row_sum(W: Tensor, s: Tensor, scale: float = 1.0) -> Tensor:
+    """scale * sum_n s[n] W[n, :] -> [d] f32, summed in a fixed order; rows with s[n] == 0 are not read
+    (msae_weighted_row_sum_f32)."""
+    dev = _hip.require_device(W, s)
+    lib = _hip.load()
+    Wc, sc = _f32c(W), _f32c(s)
+    N, d = Wc.shape
+    assert sc.numel() == N
+    out = torch.empty(d, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.msae_weighted_row_sum_ws_bytes(d))
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_weighted_row_sum_f32(_hip.ptr(Wc), _hip.ptr(sc), N, d, float(scale), _hip.ptr(out), _hip.ptr(ws),
+                                                 ws.numel(), _hip.stream_of(Wc)), "msae_weighted_row_sum_f32")
+    return out
 
 
 def sum_into_(accum: Tensor, v: Tensor) -> Tensor:

@@ -154,3 +154,42 @@ def test_train_step_with_and_without_the_fused_passes(dev):
         bad = diff > 2e-6 + 1e-5 * b.abs() + 0.02 * lr * steps
         assert bad.float().mean().item() < 1e-3, (name, int(bad.sum()), bad.numel())
         assert diff.max().item() <= 2.1 * lr * steps, (name, diff.max().item())
+
+
+def test_sparse_encoder_backward_bias_gradients_without_atomics(dev):
+    """The sparse encoder backward (ops._SparseEncode; reference graph: nn.Linear -> relu -> topk, sae.py:172-185): the
+    encoder-bias gradient comes out of the weight-gradient kernel (row_act_sum: the feature's latent gradients summed in pair
+    order) and the b_dec gradient is -(s^T W_enc) as one streaming read -- against torch autograd of the dense graph, and
+    bit-reproducible run to run (index_add_'s atomics were not)."""
+    from msae import ops
+
+    d, N, k, T = 512, 8192, 16, 700
+    g = torch.Generator(device=dev).manual_seed(21)
+    W = (torch.randn(N, d, generator=g, device=dev) / d ** 0.5).requires_grad_()
+    b = (torch.randn(N, generator=g, device=dev) * 0.05).requires_grad_()
+    bd = (torch.randn(d, generator=g, device=dev) * 0.1).requires_grad_()
+    x = torch.randn(T, d, generator=g, device=dev)
+    go = torch.randn(T, k, generator=g, device=dev)
+    grads = []
+    for _ in range(2):
+        (acts, idx), = ops.sparse_encode(x, W, b, bd, k)
+        (acts * go).sum().backward()
+        grads.append([p.grad.clone() for p in (W, b, bd)])
+        for p in (W, b, bd):
+            p.grad = None
+    for a, c in zip(*grads):
+        assert torch.equal(a, c), "the sparse encoder backward is not reproducible"
+    # dense restatement on the same selection
+    Wr, br, bdr = (p.detach().clone().requires_grad_() for p in (W, b, bd))
+    pre = torch.relu(torch.nn.functional.linear(x - bdr, Wr, br))
+    (pre.gather(1, idx) * go).sum().backward()
+    for got, ref, name in zip(grads[0], (Wr.grad, br.grad, bdr.grad), ("W_enc", "b_enc", "b_dec")):
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * ref.abs().max().item() + 1e-7, (name, err, ref.abs().max().item())
+    # the primitive on its own
+    s = torch.randn(N, generator=g, device=dev)
+    s[::3] = 0.0
+    out = ops.weighted_row_sum(W.detach(), s, -1.0)
+    ref = -(s.double() @ W.detach().double())
+    assert (out.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-7
+    assert torch.equal(out, ops.weighted_row_sum(W.detach(), s, -1.0))
