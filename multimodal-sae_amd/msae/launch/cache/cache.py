@@ -80,7 +80,12 @@ def main(cfg: CacheConfig):
     filters = load_filter(cfg.filters_path, device=model.device) if cfg.filters_path else None
     # the reference's default: num_proc = cpu_count() // 2 (sae_auto_interp/sae/data.py:21) -- the same chunks, hence the same
     # cache row ids, as the reference produces on this machine
-    dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=max(1, (os.cpu_count() or 2) // 2))
+    try:
+        dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=max(1, (os.cpu_count() or 2) // 2))
+    except ValueError:
+        # a dataset too small for that many shards (a shard without one complete chunk): the reference stops here; one
+        # shard gives it a chance
+        dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=1)
     shard_size = 0
     if ddp:
         dist.barrier()

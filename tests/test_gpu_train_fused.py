@@ -141,11 +141,13 @@ def test_train_step_with_and_without_the_fused_passes(dev):
                 assert ops._TRAIN_FRESH[key][0] == sae.encoder.weight._version     # operands of THIS version: no rebuild next step
                 assert ts._normed_version == sae.W_dec._version
                 assert torch.allclose(sae.W_dec.norm(dim=1), torch.ones(N, device=dev), atol=1e-5)
-        runs.append(([p.detach().clone() for p in sae.parameters()], fvu))
+        runs.append(({n: p.detach().clone() for n, p in sae.named_parameters()}, fvu))
     (pa, fa), (pb, fb) = runs
     assert max(abs(a - b) for a, b in zip(fa, fb)) <= 1e-5
     lr, steps = 1e-3, 4
-    for a, b, name in zip(pa, pb, ("W_enc", "b_enc", "W_dec", "b_dec")):
+    assert set(pa) == {"W_dec", "b_dec", "encoder.weight", "encoder.bias"}
+    for name in pa:
+        a, b = pa[name], pb[name]
         if name == "W_dec":
             a = a / (a.norm(dim=1, keepdim=True) + torch.finfo(torch.float32).eps)   # the unfused run renormalises next step
         # Adam's update lr * m / (sqrt(v) + eps) is ill-conditioned where |g| ~ eps (an element whose gradient is rounding noise
