@@ -29,7 +29,23 @@ for G in (8, 4, 2, 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): ops.decode(ii, vv, W_dec[:nl], b_dec)
     torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 10 * 1e3
-    print(f"G={G} k_loc={kl}: encode {t:.3f} ms  stages(prep,sample,tau,gemm,rescore,fallback)={np.round(st,3).tolist()}  merge {tm:.3f}  decode(T/G) {td:.3f}  verified {(s==0).float().mean().item():.4f}")
+    # the unconditionally enqueued second round (round 4: no host read of the flag count) with NO flagged token: compaction of
+    # the flags, the device-sized exact recompute (empty passes), the masked merge of the [T, k] round-2 pairs
+    t2 = float("nan")
+    if kl < k:
+        flags = torch.zeros(T, dtype=torch.int32, device=dev)
+        mv, mi = torch.zeros(T, k, device=dev), torch.zeros(T, k, dtype=torch.int64, device=dev)
+        g2 = torch.zeros(G * 2, T, k, dtype=torch.int32, device=dev)
+        def second():
+            rows, n = ops.compact_flags(flags)
+            v2 = torch.zeros(T, k, device=dev); i2 = torch.zeros(T, k, dtype=torch.int64, device=dev)
+            ops.encode_topk_rows_(x, W_enc, b_enc, b_dec, rows, n, k, v2, i2, None)
+            ops.merge_topk_gathered_masked_(g2, T, G, k, k, flags, mv, mi)
+        for _ in range(3): second()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): second()
+        torch.cuda.synchronize(); t2 = (time.perf_counter() - t0) / 10 * 1e3
+    print(f"G={G} k_loc={kl}: encode {t:.3f} ms  stages(prep,sample,tau,gemm,rescore,fallback)={np.round(st,3).tolist()}  merge {tm:.3f}  second round (empty) {t2:.3f}  decode(T/G) {td:.3f}  verified {(s==0).float().mean().item():.4f}")
     del W_enc, W_dec, prep
 
 # ---- mode="candidates": per-rank cost = shard_candidates over all T tokens + rescore_candidates over T/G tokens.

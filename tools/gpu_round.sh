@@ -30,7 +30,7 @@ python tools/pmc_traffic.py $OUT/pmc_summary.json $OUT/pmc_traffic.json > /dev/n
 echo "== rescore stats =="
 timeout 600 python tools/rescore_stats.py bench trained_like > $OUT/${R}_rescore_stats.txt 2>&1; tail -4 $OUT/${R}_rescore_stats.txt
 timeout 200 python tools/cluster_rows.py 2>&1 | grep cluster > $OUT/${R}_cluster_rows.txt; cat $OUT/${R}_cluster_rows.txt
-for T in 64 256; do MSAE_HIP_LIB=tools/bin/libmsae_rtl.so timeout 120 python tools/rescore_timeline.py $T 2>&1 | grep -v amdgpu.ids; done > $OUT/${R}_rescore_timeline_small_batches.txt
+
 echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
