@@ -193,11 +193,13 @@ def load_traffic(kernel: str):
     if f.exists():
         try:
             j = json.loads(f.read_text())
-            return j.get(kernel, {}).get("bytes_per_launch"), "profiles/pmc_traffic.json" + (
-                "@" + j["_commit"] if "_commit" in j else "") + " (rocprofv3 --pmc passes of an earlier run; L2->fabric bytes, Infinity-Cache hits included)"
+            e = j.get(kernel, {})
+            extra = {k: e[k] for k in ("effective_sclk_mhz", "mfma_busy_frac", "duration_ms_in_counter_pass") if k in e}
+            return e.get("bytes_per_launch"), "profiles/pmc_traffic.json" + (
+                "@" + j["_commit"] if "_commit" in j else "") + " (rocprofv3 --pmc passes of an earlier run; L2->fabric bytes, Infinity-Cache hits included)", extra
         except Exception:
-            return None, None
-    return None, None
+            return None, None, {}
+    return None, None, {}
 
 
 def main():
@@ -368,14 +370,16 @@ def main():
         peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
         kname = "gemm_kernel<int8,THRESH>" if i8 else "gemm_kernel<bf16,THRESH>"
         sustained = SUSTAINED_I8_TOPS if i8 else SUSTAINED_BF16_TFLOPS
-        traffic, traffic_src = load_traffic(kname) if with_traffic else (None, None)
+        traffic, traffic_src, pmc_extra = load_traffic(kname) if with_traffic else (None, None, {})
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak,
                            "sustained_peak": sustained, "sustained_frac": ach / sustained,
                            "ops": "2*T*d*W multiply-adds counted as 2 ops each (int8 MACs on the int8 path), W = %d columns of "
                                   "rank 0's launch (N_rank %d); sustained_peak = the guide's measured MFMA micro-benchmark "
-                                  "ceiling; the kernel runs at the package power limit (profiles/r03_power.txt)" % (width, rows),
+                                  "ceiling; the kernel runs at the package power limit (profiles/r03_power.txt, r04_gemm4w_power.txt)" % (width, rows),
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": float(mean[3])}
+        if pmc_extra:   # from the same committed counter passes: GRBM_GUI_ACTIVE / 8 / the kernel's duration THERE, MFMA-busy share
+            res["roofline"]["counter_pass"] = pmc_extra
         res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
         res["stage_ms"]["decode"] = dec_ms
         bytes_dec = tokens_decoded * (k * d * 4 + k * 8 + d * 4)

@@ -26,7 +26,7 @@ for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f 
 find $OUT/prof -name "*kernel_trace*" -size +2M -delete
 echo "== PMC passes =="
 timeout 1500 bash tools/gpu_pmc.sh > $OUT/pmc.log 2>&1; tail -8 $OUT/pmc.log
-python tools/pmc_traffic.py $OUT/pmc_summary.json $OUT/pmc_traffic.json > /dev/null 2>&1
+python tools/pmc_traffic.py $OUT/pmc_summary.json $OUT/pmc_traffic.json $OUT/pmc/p4/p4_kernel_trace.csv > /dev/null 2>&1
 echo "== rescore stats =="
 timeout 600 python tools/rescore_stats.py bench trained_like > $OUT/${R}_rescore_stats.txt 2>&1; tail -4 $OUT/${R}_rescore_stats.txt
 timeout 200 python tools/cluster_rows.py 2>&1 | grep cluster > $OUT/${R}_cluster_rows.txt; cat $OUT/${R}_cluster_rows.txt

@@ -21,5 +21,25 @@ for name, pats in KEYS.items():
                          "launches_averaged": v["FETCH_SIZE"]["n"],
                          "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 2 "
                                  "--warmup 1`; KiB, FETCH_SIZE doubled (gfx950 rule); L2->fabric incl. Infinity-Cache hits"}
+# effective shader clock of the dominant kernel DURING the counter pass: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the
+# kernel's mean duration in the same pass's kernel trace (argv[3] = that pass's *_kernel_trace.csv)
+if len(sys.argv) > 3:
+    import csv
+    for name, pats in KEYS.items():
+        ks = [k for k in d if any(p in k for p in pats) and "GRBM_GUI_ACTIVE" in d[k]]
+        if not ks or name not in out:
+            continue
+        durs = []
+        with open(sys.argv[3]) as fh:
+            for row in csv.DictReader(fh):
+                kn = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                if any(p in kn for p in pats):
+                    durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        if durs:
+            cyc = d[ks[0]]["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+            ms = sum(durs) / len(durs) / 1e6
+            out[name].update(effective_sclk_mhz=cyc / (ms * 1e3), grbm_cycles_per_xcd=cyc, duration_ms_in_counter_pass=ms)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d[ks[0]]:
+                out[name]["mfma_busy_frac"] = d[ks[0]]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * cyc)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
