@@ -17,7 +17,7 @@ prepared_cache = {}
 for c in range(cases):
     N = rng.choice([8192, 16384, 24576, 32768, 65536])
     d = rng.choice([256, 512, 1024, 2048])
-    T = rng.choice([1, 7, 16, 17, 33, 64, 65, 100, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1000, 2049])
+    T = rng.choice([1, 7, 16, 17, 33, 64, 65, 100, 128, 129, 160, 192, 255, 256, 257, 300, 511, 512, 513, 1000, 2049])
     k = rng.choice([1, 2, 8, 32, 64, 100, 256])
     kind = rng.choice(["gauss", "trained_like", "spiky1x20n", "lognorm", "dup"])
     coarse = rng.choice(["int8", "int8", "bf16"])
@@ -41,9 +41,10 @@ for c in range(cases):
     if "zero_feature" in kw: lat[:, kw["zero_feature"]] = 0.0
     ev, ei = ops.topk(lat, k)
     ops.set_coarse_mode(coarse)
-    v, i, st = ops.encode_topk(x, W, b, bd, prep, k, **kw)
+    exact = rng.random() < 0.05                 # msae_options::exact: every token by the in-call exact path (status 1)
+    v, i, st = ops.encode_topk(x, W, b, bd, prep, k, exact=exact, **kw)
     ops.set_coarse_mode("int8")
-    ok = bool(torch.equal(i, ei) and torch.equal(v, ev) and (st != 2).all())
+    ok = bool(torch.equal(i, ei) and torch.equal(v, ev) and (st != 2).all() and (not exact or (st == 1).all()))
     if not ok:
         bad += 1
         print(f"MISMATCH case {c}: N={N} d={d} T={T} k={k} {kind} {coarse} {kw}: idx equal {torch.equal(i, ei)} vals equal {torch.equal(v, ev)} "
