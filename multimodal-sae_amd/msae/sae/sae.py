@@ -45,6 +45,29 @@ class ForwardOutput(NamedTuple):
     multi_topk_fvu: Tensor
 
 
+class _SqErr(torch.autograd.Function):
+    """sum((pred - target)^2) -> (scalar, pred - target) with ONE elementwise kernel and one reduction forward and one
+    elementwise kernel backward, where the reference's `e = pred - x; e.pow(2).sum()` (sae.py:201,227) costs three
+    T x d sweeps forward and three backward.  `target` is a constant (the LLM's activations)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        e = pred - target
+        ctx.save_for_backward(e)
+        ctx.mark_non_differentiable(e)
+        return torch.linalg.vector_norm(e).square(), e
+
+    @staticmethod
+    def backward(ctx, g, _ge):
+        e, = ctx.saved_tensors
+        return e * (2.0 * g), None
+
+
+def _total_variance(x: Tensor) -> Tensor:
+    """(x - x.mean(0)).pow(2).sum() (sae.py:202) as one column-variance kernel + a d-element sum."""
+    return torch.var(x, dim=0, correction=0).sum() * x.shape[0]
+
+
 def _natural_key(s: str):
     return [int(p) if p.isdigit() else p for p in re.split(r"(\d+)", s)]
 
@@ -235,21 +258,33 @@ class Sae(nn.Module):
                                 dead_mask, k_aux, k_multi)
         top_acts, top_indices = sel[0]
         sae_out = self.decode(top_acts, top_indices)
-        e = sae_out - x
-        total_variance = (x - x.mean(0)).pow(2).sum()
+        # the loss terms in as few T x d sweeps as autograd allows (each elementwise torch op on [T, d] is a 45-us kernel at
+        # C2; the reference's expression is ~10 of them forward + backward): squared error and its gradient through _SqErr,
+        # the total variance as one column-variance kernel.  An input that itself requires grad keeps the plain expressions.
+        lean = x.is_cuda and x.dim() == 2 and not x.requires_grad and x.dtype == torch.float32
+        if lean:
+            sq_err, e = _SqErr.apply(sae_out, x)
+            total_variance = _total_variance(x)
+        else:
+            e = sae_out - x
+            sq_err = e.pow(2).sum()
+            total_variance = (x - x.mean(0)).pow(2).sum()
 
         if k_aux > 0:
             auxk_acts, auxk_indices = sel[1]
             e_hat = self.decode(auxk_acts, auxk_indices)
-            auxk_loss = scale * (e_hat - e).pow(2).sum() / total_variance
+            # (e is the residual the dead latents should explain: a constant target, as in the reference's graph it carries
+            # gradient to the main path too -- keep that: use the differentiable residual when it matters)
+            e_t = e if not lean else (sae_out - x)
+            auxk_loss = scale * (e_hat - e_t).pow(2).sum() / total_variance
         else:
             auxk_loss = sae_out.new_tensor(0.0)
 
-        fvu = e.pow(2).sum() / total_variance
+        fvu = sq_err / total_variance
         if k_multi > 0:
             top_acts, top_indices = sel[-1]
             sae_out = self.decode(top_acts, top_indices)
-            multi_topk_fvu = (sae_out - x).pow(2).sum() / total_variance
+            multi_topk_fvu = (_SqErr.apply(sae_out, x)[0] if lean else (sae_out - x).pow(2).sum()) / total_variance
         else:
             multi_topk_fvu = sae_out.new_tensor(0.0)
         return ForwardOutput(sae_out, top_acts, top_indices, fvu, auxk_loss, multi_topk_fvu)
