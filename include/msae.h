@@ -287,7 +287,7 @@ int msae_unit_norm_rows_f32(float *W, int N, int d, float eps, void *stream);
 /* out[d] = scale * sum_n s[n] * W[n][:] in a fixed order (rows with s[n] == 0 are not read): the b_dec gradient of the sparse
  * encoder backward, -(s^T W_enc) with s = row_act_sum, as ONE streaming read of W_enc (the reference back-propagates a dense
  * [T, N] gradient through nn.Linear, sae.py:172-177; a k-row gather per token is the sparse alternative).  d % 4 == 0. */
-size_t msae_weighted_row_sum_ws_bytes(int d);
+size_t msae_weighted_row_sum_ws_bytes(int N, int d);
 int msae_weighted_row_sum_f32(const float *W, const float *s, int N, int d, float scale, float *out, void *ws,
                               size_t ws_bytes, void *stream);
 /* *accum += v[0] + ... + v[n - 1], summed in a fixed order (bit-reproducible): the total of row_sumsq. */

@@ -165,41 +165,56 @@ __global__ __launch_bounds__(256) void wgrad_count_kernel(const int32_t *__restr
   if (acts[p] != 0.f) atomicAdd(counts + i, 1);
 }
 
-// single workgroup: offsets[n] = exclusive prefix of counts; cursor = copy; offsets[N] = total.  Thread t owns the
-// contiguous chunk [t ch, (t + 1) ch): chunk sums (independent 16-B loads), ONE block scan of the 1024 sums, then the chunk's
-// running offsets (the second read hits L1 / L2) -- 14 us at N = 131072 where a 1024-wide scan per iteration took 137.
+// single workgroup: offsets[n] = exclusive prefix of counts; cursor = copy; offsets[N] = total.  Tiles of 8192 counts: a thread
+// owns 8 CONSECUTIVE counts (two coalesced 16-B loads, its local prefix in registers), one wave scan of the thread totals, one
+// LDS hop across the 16 waves, coalesced 16-B stores: 16 iterations at N = 131072 (the 1024-wide scan of round 3 took 128
+// iterations = 137 us; a chunk-per-thread scan, tried first in round 4, 265 us: 4-byte accesses 512 B apart).
 __global__ __launch_bounds__(1024) void wgrad_scan_kernel(const int *__restrict__ counts, int N,
                                                           int *__restrict__ offsets,
                                                           int *__restrict__ cursor) {
   __shared__ int wave_tot[16];
+  __shared__ int carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ch = ((N + 1023) / 1024 + 3) & ~3;           // multiple of 4: chunks start 16-B aligned
-  const int beg = threadIdx.x * ch, end = min(N, beg + ch);
-  int sum = 0;
-  int i = beg;
-  for (; i + 4 <= end; i += 4) {
-    const i32x4 v = *reinterpret_cast<const i32x4 *>(counts + i);
-    sum += (v[0] + v[1]) + (v[2] + v[3]);
-  }
-  for (; i < end; ++i) sum += counts[i];
-  int incl = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  int pre = 0;
-  for (int w = 0; w < wave; ++w) pre += wave_tot[w];
-  int run = pre + incl - sum;                            // exclusive prefix of this chunk
-  for (i = beg; i < end; ++i) {
-    const int v = counts[i];
-    offsets[i] = run;
-    cursor[i] = run;
-    run += v;
+  for (int base = 0; base < N; base += 8192) {
+    const int i0 = base + threadIdx.x * 8;
+    int v[8];
+    if (i0 + 8 <= N) {
+      const i32x4 a = *reinterpret_cast<const i32x4 *>(counts + i0), b = *reinterpret_cast<const i32x4 *>(counts + i0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = i0 + e < N ? counts[i0 + e] : 0;
+    }
+    int tot = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int t = v[e]; v[e] = tot; tot += t; }   // v[e] = exclusive prefix inside the thread
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wave_tot[w];
+    const int excl = pre + incl - tot;
+    if (i0 + 8 <= N) {
+      const i32x4 a = {excl + v[0], excl + v[1], excl + v[2], excl + v[3]}, b = {excl + v[4], excl + v[5], excl + v[6], excl + v[7]};
+      *reinterpret_cast<i32x4 *>(offsets + i0) = a; *reinterpret_cast<i32x4 *>(offsets + i0 + 4) = b;
+      *reinterpret_cast<i32x4 *>(cursor + i0) = a; *reinterpret_cast<i32x4 *>(cursor + i0 + 4) = b;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (i0 + e < N) { offsets[i0 + e] = excl + v[e]; cursor[i0 + e] = excl + v[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = pre + incl;
+    __syncthreads();
   }
-  if (threadIdx.x == 1023) offsets[N] = pre + incl;      // the last thread's inclusive prefix is the total
+  if (threadIdx.x == 0) offsets[N] = carry;
 }
 
 __global__ __launch_bounds__(256) void wgrad_fill_kernel(const int32_t *__restrict__ idx,
@@ -275,21 +290,50 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float ss = 0.f;                                      // this lane's share of |g_W[n]|^2 (rowsq)
+  // the segment's first 64 (pair id, activation) in registers, one per lane: the pair loop below reads them with readlane
+  // (scalar operands: the row address of a pair no longer hangs on two dependent vector loads per pass, and the loads of
+  // several pairs are in flight together -- round 4: 0.93 -> ms per 2-GiB gradient, profiles/r04_train_kernel_stats.csv)
+  int my_p = 0;
+  float my_v = 0.f;
+  if (lane < L) { my_p = perm[beg + lane]; my_v = acts[my_p]; }
   for (int c0 = lane * 4; c0 < d; c0 += 256 * 4) {     // 4 column chunks in flight per pass
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int e = beg; e < end; ++e) {
-      const int p = perm[e];
-      const float v = acts[p];
-      const float *g = grad_out + (size_t)(p / k) * d;
+    const int Lr = L < 64 ? L : 64;
+    int e = 0;
+    for (; e + 2 <= Lr; e += 2) {                       // two pairs' rows in flight; the fma chain stays in ascending pair order
+      const int p0 = __builtin_amdgcn_readlane(my_p, e), p1 = __builtin_amdgcn_readlane(my_p, e + 1);
+      const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), e));
+      const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), e + 1));
+      const float *g0 = grad_out + (size_t)(p0 / k) * d, *g1 = grad_out + (size_t)(p1 / k) * d;
+      f32x4 a0[4], a1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 256;
+        a0[u] = c < d ? *reinterpret_cast<const f32x4 *>(g0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        a1[u] = c < d ? *reinterpret_cast<const f32x4 *>(g1 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u][0] = __builtin_fmaf(v0, a0[u][0], acc[u][0]); acc[u][1] = __builtin_fmaf(v0, a0[u][1], acc[u][1]);
+        acc[u][2] = __builtin_fmaf(v0, a0[u][2], acc[u][2]); acc[u][3] = __builtin_fmaf(v0, a0[u][3], acc[u][3]);
+        acc[u][0] = __builtin_fmaf(v1, a1[u][0], acc[u][0]); acc[u][1] = __builtin_fmaf(v1, a1[u][1], acc[u][1]);
+        acc[u][2] = __builtin_fmaf(v1, a1[u][2], acc[u][2]); acc[u][3] = __builtin_fmaf(v1, a1[u][3], acc[u][3]);
+      }
+    }
+    for (; e < L; ++e) {                                // the odd pair, and pairs beyond the 64 held in registers
+      int pe; float ve;
+      if (e < 64) { pe = __builtin_amdgcn_readlane(my_p, e); ve = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), e)); }
+      else { pe = perm[beg + e]; ve = acts[pe]; }
+      const float *g = grad_out + (size_t)(pe / k) * d;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + u * 256;
         if (c < d) {
           const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + c);
-          acc[u][0] = __builtin_fmaf(v, gv[0], acc[u][0]); acc[u][1] = __builtin_fmaf(v, gv[1], acc[u][1]);
-          acc[u][2] = __builtin_fmaf(v, gv[2], acc[u][2]); acc[u][3] = __builtin_fmaf(v, gv[3], acc[u][3]);
+          acc[u][0] = __builtin_fmaf(ve, gv[0], acc[u][0]); acc[u][1] = __builtin_fmaf(ve, gv[1], acc[u][1]);
+          acc[u][2] = __builtin_fmaf(ve, gv[2], acc[u][2]); acc[u][3] = __builtin_fmaf(ve, gv[3], acc[u][3]);
         }
       }
     }

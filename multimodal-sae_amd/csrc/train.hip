@@ -160,30 +160,48 @@ __global__ __launch_bounds__(1024) void sum_fixed_kernel(const float *__restrict
 
 // out[c] = scale * sum_n s[n] W[n][c]: the b_dec gradient of the sparse encoder backward, -sum_t sum_j g[t,j] W_enc[n_tj] =
 // -(s^T W_enc) with s[n] = the summed latent gradients of feature n (msae_decode_bwd_wdec_f32: row_act_sum) -- ONE streaming read
-// of W_enc instead of a k-row gather per token plus a sum over tokens.  Stage 1: workgroup b sums rows b, b + G, ... (fixed
-// order) into part[b][:]; stage 2 adds the G partial rows up in order.  Bit-reproducible.
-constexpr int WRS_GROUPS = 512;
+// of W_enc instead of a k-row gather per token plus a sum over tokens.  Stage 1: workgroup b sums its 64 consecutive rows (ascending)
+// into part[b][:]; stage 2 adds the partial rows up in a fixed order.  Bit-reproducible.
+constexpr int WRS_ROWS = 64;       // rows per workgroup of stage 1
 __global__ __launch_bounds__(256) void weighted_rows_part_kernel(const float *__restrict__ W, const float *__restrict__ sv, int N,
                                                                  int d, float *__restrict__ part) {
+  __shared__ float s_w[WRS_ROWS];
+  const int n0 = blockIdx.x * WRS_ROWS;
+  if (threadIdx.x < WRS_ROWS) s_w[threadIdx.x] = n0 + (int)threadIdx.x < N ? sv[n0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  const int rows = min(WRS_ROWS, N - n0);
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int n = blockIdx.x; n < N; n += WRS_GROUPS) {
-      const float w = sv[n];
-      if (w == 0.f) continue;                        // features that did not fire carry no gradient: their rows are not read
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(W + (size_t)n * d + c);
-      acc[0] = __builtin_fmaf(w, v[0], acc[0]); acc[1] = __builtin_fmaf(w, v[1], acc[1]);
-      acc[2] = __builtin_fmaf(w, v[2], acc[2]); acc[3] = __builtin_fmaf(w, v[3], acc[3]);
+    const float *base = W + (size_t)n0 * d + c;
+    for (int r0 = 0; r0 < rows; r0 += 8) {            // eight rows' loads in flight per thread; rows with s == 0 are not read
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool live = r0 + u < rows && s_w[r0 + u] != 0.f;           // workgroup-uniform
+        v[u] = live ? *reinterpret_cast<const f32x4 *>(base + (size_t)(r0 + u) * d) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                    // ascending row order: a fixed summation order
+        const float w = r0 + u < rows ? s_w[r0 + u] : 0.f;
+        acc[0] = __builtin_fmaf(w, v[u][0], acc[0]); acc[1] = __builtin_fmaf(w, v[u][1], acc[1]);
+        acc[2] = __builtin_fmaf(w, v[u][2], acc[2]); acc[3] = __builtin_fmaf(w, v[u][3], acc[3]);
+      }
     }
     *reinterpret_cast<f32x4 *>(part + (size_t)blockIdx.x * d + c) = acc;
   }
 }
-__global__ __launch_bounds__(256) void weighted_rows_sum_kernel(const float *__restrict__ part, int d, float scale,
+__global__ __launch_bounds__(256) void weighted_rows_sum_kernel(const float *__restrict__ part, int groups, int d, float scale,
                                                                 float *__restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d) return;
-  float acc = 0.f;
-  for (int b = 0; b < WRS_GROUPS; ++b) acc += part[(size_t)b * d + c];
-  out[c] = scale * acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four interleaved partial sums (fixed assignment), then a fixed combine
+  int b = 0;
+  for (; b + 4 <= groups; b += 4) {
+    a0 += part[(size_t)b * d + c]; a1 += part[(size_t)(b + 1) * d + c];
+    a2 += part[(size_t)(b + 2) * d + c]; a3 += part[(size_t)(b + 3) * d + c];
+  }
+  for (; b < groups; ++b) a0 += part[(size_t)b * d + c];
+  out[c] = scale * ((a0 + a1) + (a2 + a3));
 }
 
 // adam_rows_kernel with the NEXT step's passes over the same matrix folded in (d % 4 == 0; the updated row stays in registers
@@ -284,16 +302,19 @@ __global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict_
 
 }  // namespace
 
-extern "C" size_t msae_weighted_row_sum_ws_bytes(int d) { return d > 0 ? (size_t)WRS_GROUPS * d * 4 : 0; }
+extern "C" size_t msae_weighted_row_sum_ws_bytes(int N, int d) {
+  return (N > 0 && d > 0) ? (size_t)((N + WRS_ROWS - 1) / WRS_ROWS) * d * 4 : 0;
+}
 
 extern "C" int msae_weighted_row_sum_f32(const float *W, const float *s, int N, int d, float scale, float *out, void *ws,
                                          size_t ws_bytes, void *stream) {
   if (!W || !s || !out || N <= 0 || d <= 0 || (d & 3) != 0) return MSAE_EINVAL;
-  if (!ws || ws_bytes < msae_weighted_row_sum_ws_bytes(d)) return MSAE_EWS;
+  if (!ws || ws_bytes < msae_weighted_row_sum_ws_bytes(N, d)) return MSAE_EWS;
   if (!msae_aligned(W, 16) || !msae_aligned(ws, 16)) return MSAE_EALIGN;
   float *part = static_cast<float *>(ws);
-  hipLaunchKernelGGL(weighted_rows_part_kernel, dim3(WRS_GROUPS), dim3(256), 0, (hipStream_t)stream, W, s, N, d, part);
-  hipLaunchKernelGGL(weighted_rows_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, d, scale, out);
+  const int groups = (N + WRS_ROWS - 1) / WRS_ROWS;
+  hipLaunchKernelGGL(weighted_rows_part_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, W, s, N, d, part);
+  hipLaunchKernelGGL(weighted_rows_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, groups, d, scale, out);
   return msae_launch_status();
 }
 

@@ -83,7 +83,7 @@ PROTOTYPES = {
     "msae_unit_norm_rows_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     "msae_grad_sumsq_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "msae_sum_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
-    "msae_weighted_row_sum_ws_bytes": (c_size_t, [c_int]),
+    "msae_weighted_row_sum_ws_bytes": (c_size_t, [c_int, c_int]),
     "msae_weighted_row_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "msae_adam_rows_fused_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float,
                                          c_int, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p, c_int,

@@ -865,7 +865,7 @@ def weighted_row_sum(W: Tensor, s: Tensor, scale: float = 1.0) -> Tensor:
     N, d = Wc.shape
     assert sc.numel() == N
     out = torch.empty(d, dtype=torch.float32, device=dev)
-    ws = _workspace(dev, lib.msae_weighted_row_sum_ws_bytes(d))
+    ws = _workspace(dev, lib.msae_weighted_row_sum_ws_bytes(N, d))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_weighted_row_sum_f32(_hip.ptr(Wc), _hip.ptr(sc), N, d, float(scale), _hip.ptr(out), _hip.ptr(ws),
                                                  ws.numel(), _hip.stream_of(Wc)), "msae_weighted_row_sum_f32")
