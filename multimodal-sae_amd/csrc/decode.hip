@@ -266,16 +266,22 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
   const int beg = offsets[n], end = offsets[n + 1];
   const int L = end - beg;
   // deterministic summation order: the segment (filled through an atomic cursor, i.e. in any order) is sorted
-  // by pair id = by token.  <= 64 pairs: lane 0, insertion sort; <= 1024: the wave, in LDS; longer (a feature
-  // active on more than 1024 tokens of the call): the wave, in place, agent-scope fences between the steps.
-  if (L > 1 && L <= 64) {
-    if (lane == 0) {
-      for (int a = beg + 1; a < end; ++a) {
-        const int key = perm[a];
-        int b = a - 1;
-        while (b >= beg && perm[b] > key) { perm[b + 1] = perm[b]; --b; }
-        perm[b + 1] = key;
-      }
+  // by pair id = by token.  <= 64 pairs (nearly every feature): one pair id per lane, a 21-step bitonic network over the wave's
+  // registers (round 4; lane 0's insertion sort in global memory was a chain of dependent L2 round trips per pair -- most of the
+  // kernel's time); <= 1024: the wave, in LDS; longer (a feature active on more than 1024 tokens of the call): the wave, in
+  // place, agent-scope fences between the steps.
+  int my_p = 0x7FFFFFFF;                               // lane l's pair id of the (sorted) first 64
+  if (L <= 64) {
+    if (lane < L) my_p = perm[beg + lane];
+    if (L > 1) {
+#pragma unroll
+      for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+          const int other = __shfl_xor(my_p, j, 64);
+          const bool keep_min = ((lane & kk) == 0) == ((lane & j) == 0);
+          my_p = keep_min ? (my_p < other ? my_p : other) : (my_p > other ? my_p : other);
+        }
     }
   } else if (L > 64 && L <= WGRAD_LDS_SEG) {
     int *seg = s_seg[threadIdx.x >> 6];
@@ -292,10 +298,10 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
   float ss = 0.f;                                      // this lane's share of |g_W[n]|^2 (rowsq)
   // the segment's first 64 (pair id, activation) in registers, one per lane: the pair loop below reads them with readlane
   // (scalar operands: the row address of a pair no longer hangs on two dependent vector loads per pass, and the loads of
-  // several pairs are in flight together -- round 4: 0.93 -> ms per 2-GiB gradient, profiles/r04_train_kernel_stats.csv)
-  int my_p = 0;
+  // several pairs are in flight together)
   float my_v = 0.f;
-  if (lane < L) { my_p = perm[beg + lane]; my_v = acts[my_p]; }
+  if (L > 64) my_p = perm[beg + lane];                 // (sorted in memory above)
+  if (lane < L) my_v = acts[my_p];
   for (int c0 = lane * 4; c0 < d; c0 += 256 * 4) {     // 4 column chunks in flight per pass
     f32x4 acc[4];
 #pragma unroll
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(256) void wgrad_accum_kernel(const float *__restric
   if (rowsum) {  // sum of the row's pair activations in ascending pair order (lane l: pairs l, l + 64, ...; then a fixed
                  // reduction tree): with acts = the latents' gradients this IS the encoder bias gradient of feature n -- no
                  // index_add_ with its atomics, bit-reproducible
-    float sa = 0.f;
-    for (int e = beg + lane; e < end; e += 64) sa += acts[perm[e]];
+    float sa = my_v;                                     // (pair lane of the sorted first 64; 0 beyond the segment)
+    for (int e = beg + 64 + lane; e < end; e += 64) sa += acts[perm[e]];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sa += __shfl_xor(sa, off, 64);
     if (lane == 0) rowsum[n] = sa;

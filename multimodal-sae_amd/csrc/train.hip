@@ -190,18 +190,21 @@ __global__ __launch_bounds__(256) void weighted_rows_part_kernel(const float *__
     *reinterpret_cast<f32x4 *>(part + (size_t)blockIdx.x * d + c) = acc;
   }
 }
-__global__ __launch_bounds__(256) void weighted_rows_sum_kernel(const float *__restrict__ part, int groups, int d, float scale,
-                                                                float *__restrict__ out) {
+// out[y][c] = scale * sum of part rows [y per, (y + 1) per) (blockIdx.y = y): run twice -- 2048 partial rows -> 64 -> 1 -- so that
+// no thread walks more than 64 rows (one 16-block launch over 2048 rows took 0.22 ms)
+__global__ __launch_bounds__(256) void weighted_rows_sum_kernel(const float *__restrict__ part, int groups, int per, int d,
+                                                                float scale, float *__restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d) return;
+  const int b0 = blockIdx.y * per, b1 = min(groups, b0 + per);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four interleaved partial sums (fixed assignment), then a fixed combine
-  int b = 0;
-  for (; b + 4 <= groups; b += 4) {
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
     a0 += part[(size_t)b * d + c]; a1 += part[(size_t)(b + 1) * d + c];
     a2 += part[(size_t)(b + 2) * d + c]; a3 += part[(size_t)(b + 3) * d + c];
   }
-  for (; b < groups; ++b) a0 += part[(size_t)b * d + c];
-  out[c] = scale * ((a0 + a1) + (a2 + a3));
+  for (; b < b1; ++b) a0 += part[(size_t)b * d + c];
+  out[(size_t)blockIdx.y * d + c] = scale * ((a0 + a1) + (a2 + a3));
 }
 
 // adam_rows_kernel with the NEXT step's passes over the same matrix folded in (d % 4 == 0; the updated row stays in registers
@@ -302,8 +305,9 @@ __global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict_
 
 }  // namespace
 
+constexpr int WRS_MID = 64;        // partial rows after the first summation level
 extern "C" size_t msae_weighted_row_sum_ws_bytes(int N, int d) {
-  return (N > 0 && d > 0) ? (size_t)((N + WRS_ROWS - 1) / WRS_ROWS) * d * 4 : 0;
+  return (N > 0 && d > 0) ? (size_t)((N + WRS_ROWS - 1) / WRS_ROWS + WRS_MID) * d * 4 : 0;
 }
 
 extern "C" int msae_weighted_row_sum_f32(const float *W, const float *s, int N, int d, float scale, float *out, void *ws,
@@ -314,7 +318,12 @@ extern "C" int msae_weighted_row_sum_f32(const float *W, const float *s, int N, 
   float *part = static_cast<float *>(ws);
   const int groups = (N + WRS_ROWS - 1) / WRS_ROWS;
   hipLaunchKernelGGL(weighted_rows_part_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, W, s, N, d, part);
-  hipLaunchKernelGGL(weighted_rows_sum_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, groups, d, scale, out);
+  float *mid = part + (size_t)groups * d;
+  const int per = (groups + WRS_MID - 1) / WRS_MID, n_mid = (groups + per - 1) / per;
+  hipLaunchKernelGGL(weighted_rows_sum_kernel, dim3((d + 255) / 256, n_mid), dim3(256), 0, (hipStream_t)stream, part, groups, per, d,
+                     1.f, mid);
+  hipLaunchKernelGGL(weighted_rows_sum_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, mid, n_mid, n_mid, d,
+                     scale, out);
   return msae_launch_status();
 }
 
