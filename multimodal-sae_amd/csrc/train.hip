@@ -250,10 +250,13 @@ __global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict_
   {
     int it = 0;
     for (int c = threadIdx.x * 4; c < d; c += 1024, ++it) {
-      const f32x4 g = *reinterpret_cast<const f32x4 *>(G + base + c);     // L2 hit when projecting
+      // the moments are touched exactly once per step (and the gradient, unless the projection has just read it): streaming
+      // accesses, kept out of the caches' way (MSAE_ADAM_PLAIN_LOADS in a tuning build switches the hint off)
+      const f32x4 g = a.project ? *reinterpret_cast<const f32x4 *>(G + base + c)     // L2 hit when projecting
+                                : MSAE_ADAM_LOAD(reinterpret_cast<const f32x4 *>(G + base + c));
       f32x4 w = *reinterpret_cast<const f32x4 *>(W + base + c);
-      f32x4 m = *reinterpret_cast<const f32x4 *>(M + base + c);
-      f32x4 v = *reinterpret_cast<const f32x4 *>(V + base + c);
+      f32x4 m = MSAE_ADAM_LOAD(reinterpret_cast<const f32x4 *>(M + base + c));
+      f32x4 v = MSAE_ADAM_LOAD(reinterpret_cast<const f32x4 *>(V + base + c));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float ge = g[e] * clip, we = w[e], me = m[e], ve = v[e];
@@ -261,8 +264,8 @@ __global__ __launch_bounds__(256) void adam_rows_fused_kernel(float *__restrict_
         adam_update(we, ge, me, ve, a);
         w[e] = we; m[e] = me; v[e] = ve;
       }
-      *reinterpret_cast<f32x4 *>(M + base + c) = m;
-      *reinterpret_cast<f32x4 *>(V + base + c) = v;
+      MSAE_ADAM_STORE(m, reinterpret_cast<f32x4 *>(M + base + c));
+      MSAE_ADAM_STORE(v, reinterpret_cast<f32x4 *>(V + base + c));
       if (renorm) {
 #pragma unroll
         for (int q = 0; q < KEEP; ++q) if (q == it) keep[q] = w;

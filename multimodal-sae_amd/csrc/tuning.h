@@ -55,6 +55,14 @@
 #define MSAE_MF_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
+#ifdef MSAE_ADAM_PLAIN_LOADS
+#define MSAE_ADAM_LOAD(p) (*(p))
+#define MSAE_ADAM_STORE(v, p) (*(p) = (v))
+#else
+#define MSAE_ADAM_LOAD(p) __builtin_nontemporal_load(p)
+#define MSAE_ADAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // ---- ablation switches (results are INVALID when one is set; stage clocks of the others stay comparable) ---------------------
 namespace msae_tuning {
 #ifdef MSAE_ABL_NOEPI
