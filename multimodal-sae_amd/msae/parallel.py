@@ -326,9 +326,13 @@ class ShardedSae:
             got = self._encode_candidates(x, **ed)
             if got is not None:
                 return got[0]()
-        vals, idx, status = self._encode(x, self.k_loc, **ed)
+        # a handful of tokens (a steering decode step: latency, not bandwidth -- the small-batch encoder re-scores the same ~100
+        # candidates whatever k_loc is): every shard sends its full top-k, so there is no truncation to verify and no second
+        # round (two kernels and one more collective on a ~60-us step)
+        kl = self.k if x.shape[0] <= self.local_decode_max_t else self.k_loc
+        vals, idx, status = self._encode(x, kl, **ed)
         mv, mi, flagged = self._gather_merge(vals, idx)
-        if self.k_loc < self.k:
+        if kl < self.k:
             # second round, enqueued whatever `flagged` holds (identical on every rank; usually all zero): nothing is
             # read back, the exact recompute is sized on the device and the masked merge touches the flagged rows only
             self._count_second_round(flagged)
