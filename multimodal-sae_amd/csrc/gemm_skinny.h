@@ -26,7 +26,12 @@ struct SkinnyCfg {
   static constexpr int TM = BM, TN = 32, MI = BM / 32, NI = 1;
   static constexpr bool I8 = true;
   static constexpr int KC = (NW_ == 4 ? 32768 : 65536) / BM;   // bytes of k per A chunk
-  static constexpr int PITCH = KC + 16;                 // row pitch of the LDS image (16 B: rows spread over the banks)
+  // ADMA (the 256-token tile): the token rows travel L2 -> LDS by LDS-DMA (global_load_lds, as gemm_mfma.h's operands) instead of
+  // through 32 registers per lane, which buys the B stream a second k-step in flight (UN = 2: 64 KB of weights in flight per CU
+  // instead of 32).  DMA writes lane-linear, so the image is unpadded ([row][KC] with the row's sixteen 16-B chunks XOR-swizzled
+  // by row & 15: the 16 rows of a fragment read land on 16 different bank groups).
+  static constexpr bool ADMA = BM_ == 256 && NW_ == 8;
+  static constexpr int PITCH = ADMA ? KC : KC + 16;     // row pitch of the LDS image (16 B pad: rows spread over the banks)
   static constexpr int A_BUF = BM * PITCH;
   static constexpr int LDS_RING_BYTES = 2 * A_BUF;
   static constexpr int SIDE_SLOTS = 6;
@@ -34,10 +39,11 @@ struct SkinnyCfg {
   static constexpr int QCAP = 128 * NW_;                // ~0.5 % of BM x BN outputs pass the hot loop's bound
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   // k-steps (64 B of k each) per B batch (registers: 8 UN per batch; the accumulators take BM / 2 of the wave's budget)
-  static constexpr int UN = BM_ > 128 ? MSAE_SK_UN / 4 : (BM_ > 64 ? MSAE_SK_UN / 2 : MSAE_SK_UN);
+  static constexpr int UN = ADMA ? MSAE_SK_UN / 2 : (BM_ > 128 ? MSAE_SK_UN / 4 : (BM_ > 64 ? MSAE_SK_UN / 2 : MSAE_SK_UN));
   static_assert(UN >= 1 && BM % 32 == 0 && BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
   static_assert(KC % (2 * UN * 64) == 0, "a chunk is a whole number of B double-batches");
   static_assert(LDS_BYTES <= (NW_ == 4 ? 80 : 160) * 1024, "LDS budget");
+  static_assert(!ADMA || KC == 256, "the DMA path's chunk swizzle covers sixteen 16-B chunks per row");
 };
 
 template <int BM, int NW, bool DENSE>
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   // zeroed once in both buffers
   constexpr int RPQ = C::NT / CPR;                       // rows covered by one piece index q
   auto fetch_a = [&](int chunk) {
+    if constexpr (C::ADMA) return;
 #pragma unroll
     for (int q = 0; q < A_PIECES; ++q) {
       if (q * RPQ >= T) continue;                        // wave-uniform
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
     }
   };
   auto put_a = [&](int buf) {
+    if constexpr (C::ADMA) return;
 #pragma unroll
     for (int q = 0; q < A_PIECES; ++q) {
       if (q * RPQ >= T) continue;
@@ -119,12 +127,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
       *reinterpret_cast<i32x4 *>(smem + buf * C::A_BUF + row * C::PITCH + c16 * 16) = areg[q];
     }
   };
+  // ADMA: one 1-KiB piece = 4 token rows x 256 B; wave w issues pieces 8 w .. 8 w + 7 of a chunk.  Lane l delivers chunk
+  // (l & 15) ^ (row & 15) of row 4 piece + (l >> 4) to LDS position l & 15 of that row (the DMA writes lane-linear).  The rows of
+  // the padded tile (>= T) are zero in xq, so every piece is always fetched.  4 per-lane offsets (piece & 3 decides row & 15).
+  [[maybe_unused]] unsigned dma_off[4];
+  if constexpr (C::ADMA) {
 #pragma unroll
-  for (int q = 0; q < A_PIECES; ++q) {
-    if (q * RPQ < T) continue;
-    const int p = q * C::NT + tid, row = p / CPR, c16 = p % CPR;
-    *reinterpret_cast<i32x4 *>(smem + row * C::PITCH + c16 * 16) = i32x4{0, 0, 0, 0};
-    *reinterpret_cast<i32x4 *>(smem + C::A_BUF + row * C::PITCH + c16 * 16) = i32x4{0, 0, 0, 0};
+    for (int j = 0; j < 4; ++j) {
+      const unsigned row_in = lane >> 4, pos = lane & 15, r15 = ((unsigned)j << 2) | row_in;
+      dma_off[j] = row_in * (unsigned)op.ldA + ((pos ^ r15) << 4);
+    }
+  }
+  auto dma_a = [&](int chunk, int buf) {
+    if constexpr (C::ADMA) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int piece = __builtin_amdgcn_readfirstlane(wave) * 8 + q;   // wave-uniform: SGPR addresses below
+        const unsigned char *sbase = op.A + (size_t)(piece * 4) * op.ldA + (size_t)chunk * C::KC;
+        const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + buf * C::A_BUF + piece * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(dma_off[q & 3]), "s"(sbase), "s"(dst) : "memory", "m0");
+      }
+    }
+  };
+  if constexpr (!C::ADMA) {
+#pragma unroll
+    for (int q = 0; q < A_PIECES; ++q) {
+      if (q * RPQ < T) continue;
+      const int p = q * C::NT + tid, row = p / CPR, c16 = p % CPR;
+      *reinterpret_cast<i32x4 *>(smem + row * C::PITCH + c16 * 16) = i32x4{0, 0, 0, 0};
+      *reinterpret_cast<i32x4 *>(smem + C::A_BUF + row * C::PITCH + c16 * 16) = i32x4{0, 0, 0, 0};
+    }
   }
   // k is walked in a ROTATED order: workgroup b starts at chunk b mod nchunks and every wave at its own batch inside the
   // chunk (all workgroups start together and advance in step; rows are d bytes apart: without the rotation every request
@@ -137,6 +170,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   auto chunk_of = [&](int c) { const int cc = c + rot_c; return cc >= nchunks ? cc - nchunks : cc; };
   auto ks_of = [&](int c, int b) { const int bq = b + rot_b; return chunk_of(c) * KSC + (bq >= BPC ? bq - BPC : bq) * 2 * UN; };
   fetch_a(chunk_of(0));
+  dma_a(chunk_of(0), 0);
 
   // this lane's B fragment streams: feature groups 0 / 1 of the wave (rows 16 apart), 64 B of a row per k-step, from the
   // FRAGMENT-major Wq copy (encode_fused.hip: frag_off) -- [16-row block][k-step][lane][16 B]: the fragment of a k-step is one
@@ -183,12 +217,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
     }
   }
   put_a(0);
+  if constexpr (C::ADMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk 0 has landed (the compiler does not see the DMA)
   __syncthreads();
 
   // ---- main stream
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks && !(MSAE_SK_ABL & 1)) fetch_a(chunk_of(c + 1));
-    const unsigned char *abuf = smem + (c & 1) * C::A_BUF + l15 * C::PITCH + lg * 16;
+    if (c + 1 < nchunks && !(MSAE_SK_ABL & 1)) { fetch_a(chunk_of(c + 1)); dma_a(chunk_of(c + 1), (c + 1) & 1); }
+    const unsigned char *abuf = smem + (c & 1) * C::A_BUF + l15 * C::PITCH + (C::ADMA ? 0 : lg * 16);
+    // ADMA: the 16-B chunk (4 ks + lg) of row (16 tg + l15) sits at position chunk ^ l15
+    auto a_frag = [&](int tg, int ksl) -> i32x4 {
+      if constexpr (C::ADMA) return *reinterpret_cast<const i32x4 *>(abuf + tg * 16 * C::PITCH + ((((ksl << 2) | lg) ^ l15) << 4));
+      else return *reinterpret_cast<const i32x4 *>(abuf + tg * 16 * C::PITCH + ksl * 64);
+    };
 #pragma unroll 1
     for (int b = 0; b < BPC; ++b) {
       const int ks = ks_of(c, b);                       // physical k-step of ba[0]
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
       for (int u = 0; u < UN; ++u) {
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
-          if (!(MSAE_SK_ABL & 4)) mfma(tg, *reinterpret_cast<const i32x4 *>(abuf + tg * 16 * C::PITCH + (k0 + u) * 64), ba[u]);
+          if (!(MSAE_SK_ABL & 4)) mfma(tg, a_frag(tg, k0 + u), ba[u]);
           else asm volatile("" :: "v"(ba[u][0]), "v"(ba[u][1]));
         }
       }
@@ -208,13 +248,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
       for (int u = 0; u < UN; ++u) {
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
-          if (!(MSAE_SK_ABL & 4)) mfma(tg, *reinterpret_cast<const i32x4 *>(abuf + tg * 16 * C::PITCH + (k0 + UN + u) * 64), bb[u]);
+          if (!(MSAE_SK_ABL & 4)) mfma(tg, a_frag(tg, k0 + UN + u), bb[u]);
           else asm volatile("" :: "v"(bb[u][0]), "v"(bb[u][1]));
         }
       }
     }
     if (c + 1 < nchunks && !(MSAE_SK_ABL & 1)) {
       put_a((c + 1) & 1);                               // the other buffer: last read in iteration c - 1 (barrier below)
+      // ADMA: the next chunk's pieces were issued at the top of this iteration; everything issued since is B loads, of which
+      // only the last batch (2 UN loads: ba for the next iteration) may still be in flight -- vmcnt counts in order
+      if constexpr (C::ADMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * UN) : "memory");
       // a raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. drain the B batches in flight at every chunk
       // (measured: the stream ran at 3.3 TB/s with it)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -229,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   {
     constexpr int TP = C::BN + 4;                        // row pitch in ints: the 4 row groups of a store land 16 banks apart
     // the image of 128 token rows at a time (BM = 256: two halves through the same LDS)
-    constexpr int HR = C::BM < 128 ? C::BM : 128, NH = C::BM / HR;
+    constexpr int HR = C::ADMA ? 64 : (C::BM < 128 ? C::BM : 128), NH = C::BM / HR;   // (the unpadded ADMA ring holds 64 image rows)
     static_assert(HR * TP * 4 <= C::LDS_RING_BYTES, "tile image fits the A buffers");
     int *timg = reinterpret_cast<int *>(smem);
 #pragma unroll
