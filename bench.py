@@ -393,7 +393,8 @@ def main():
         got = rb[rb > 0]
         if got.numel():
             res["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())
-            res["rescore_rounds_per_token"] = float((got >> 24).float().mean().item())
+            res["rescore_rounds_per_token"] = float(((got >> 24) & 0x3F).float().mean().item())
+            res["rescore_feature_major"] = bool(((got >> 30) & 1).any().item())
         res["clock"] = dict(sampler_out)
 
     workload = ("BASELINE configs[1]: d_model=%d width=%d k=%d, %%s %s activations/step resident in HBM, %s" % (

@@ -75,9 +75,12 @@ enum {
  *   status_detail diagnostics (tools/soak_fused.py): a token recomputed inside the call reports
  *                 status = 1 | reason << 8 (reason bits below) instead of 1, so `status & 0xFF` is the code.
  *   profile       a handle from msae_profile_create (stage timing, below) or NULL.
- *   rows_rescored (ABI 3) optional DEVICE int32[T]: per token, rounds << 24 | first-round rows << 12 | rows of W_enc the
- *                 exact re-score read for it (0 for tokens the large-batch re-score did not verify / paths without it) --
- *                 the measurement behind bench.py's rows_rescored_per_token; costs one store per token.
+ *   rows_rescored (ABI 3) optional DEVICE int32[T]: per token, rounds (6 bits) << 24 | first-round rows << 12 | rows of W_enc
+ *                 the exact re-score read for it (0 for tokens the large-batch re-score did not verify / paths without it) --
+ *                 the measurement behind bench.py's rows_rescored_per_token; costs one store per token.  Bit 30: the first
+ *                 round ran FEATURE-major (batches in which a feature is a candidate of >= ~4 tokens, e.g. k = 256 at 8192
+ *                 tokens: the pairs are counting-sorted by feature, every row of W_enc comes from HBM once and the
+ *                 activation rows out of the Infinity Cache -- same chains, same bits).
  *   exact         (ABI 3) != 0: msae_encode_topk[_i64] computes EVERY token by the exact path (msae_pre_acts_f32 +
  *                 msae_topk_f32 semantics through the in-call fallback: <= 1 GiB of dense scratch whatever T; status 1
  *                 for every token).  The switch for callers that cannot accept the fused path's statistical contract:

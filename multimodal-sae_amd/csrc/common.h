@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 #define MSAE_HIP_TRY(expr)                  \

@@ -131,7 +131,8 @@ inline void prof_step(ProfState *pf) {
 
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
-  bool fast, i8, small;
+  bool fast, i8, small, fm;
+  size_t off_fmcount, off_fmtarget, off_fmkeys, off_fmpairs, off_fmpre;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
@@ -203,6 +204,14 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
     p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);   // token list [T] | count | per-pass counts
     p.off_fbdense = take((size_t)p.fb_cap * N * 4);
+    p.fm = shard_C == 0 && fm_shape_ok(T, k, N, p.r_max);    // feature-major first round of the re-score (encode_rescore.h)
+    if (p.fm) {
+      p.off_fmcount = take(((size_t)N + 64 + (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK) * 4);   // counts [N] | total | block sums
+      p.off_fmtarget = take((size_t)T * 4);
+      p.off_fmkeys = take((size_t)T * p.r_max * 8);
+      p.off_fmpairs = take((size_t)T * p.r_max * 8);
+      p.off_fmpre = take((size_t)T * p.r_max * 4);
+    }
   } else {
     p.off_dense = take((size_t)T * N * 4);
   }
@@ -527,7 +536,27 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.rows_out = co.rows_out;
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
-    const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    int lrc;
+    if (pl.fm) {
+      int *fcount = reinterpret_cast<int *>(ws + pl.off_fmcount);
+      int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
+      float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);
+      ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
+      ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max;
+      MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
+      lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
+      if (lrc) return lrc;
+      const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK;
+      hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, fcount + N + 64);
+      hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, fcount + N + 64);
+      hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, pl.r_max, fcount, pairs);
+      const long max_pairs = (long)T * pl.r_max;
+      hipLaunchKernelGGL(fm_dot_kernel<DT>, dim3((unsigned)((max_pairs + 63) / 64)), dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs,
+                         fcount + N, d, pl.r_max, fpre);
+      lrc = launch_select_rescore<false, 2>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    } else {
+      lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    }
     if (lrc) return lrc;
   }
   prof_mark(co.prof, 5, s);

@@ -25,7 +25,11 @@ struct RescoreArgs {
   // instead of cnt / cand / tau_vals / rowc / colc: record (g, t) at ext + ((size_t)g * ext_T + t) * ext_stride
   const unsigned char *ext; int ext_G, ext_C, ext_T, ext_stride, ext_valid;
   int lpr;   // lanes per row in the first round (1, 2, 4): small batches need the extra bytes in flight (rescore_shape)
+  // FEATURE-MAJOR first round (PHASE 1 / 2 of select_rescore_kernel, fm_* kernels below): per-feature pair counts [N + 1],
+  // first-round size per token (| FM_SORTED), the first-round keys [T][fm_rcap], their exact pre-activations [T][fm_rcap]
+  int *fm_count; int *fm_target; unsigned long long *fm_keys; const float *fm_pre; int fm_rcap;
 };
+constexpr int FM_SORTED = 1 << 30;   // fm_target: the token's whole list was written back in sorted order
 
 // One shard's record of a token (msae_shard_candidates): C keys (order key of the upper value u | 0x7FFFFFFF -
 // GLOBAL feature, 0 = empty), C times z sigma of that (token, feature) pair, tau = the largest u any feature of
@@ -84,7 +88,13 @@ __device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, f
 // belong to ITS piece of the row (ds_read_b128, counted waits) -- the scalar loads of the default path return out of
 // order, so each pair of them is a full lgkmcnt(0) round trip (128 per pass), which nothing hides when a token's
 // waves are alone on their SIMDs.
-template <int NW, bool EXT = false, bool LDSA = false>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
+//
+// PHASE (feature-major first round, run_fast): when a feature is a candidate of many tokens of the batch (k = 256 at 8192 tokens:
+// 347 rows per token = 22 tokens per feature), the token-major first round reads every row of W_enc ~22 times from HBM.  PHASE 1
+// stops behind the choice of the first round and hands its (token, feature) pairs to a counting sort by feature; fm_dot_kernel
+// computes the same exact chains feature-major (W_enc once, the activations out of the Infinity Cache); PHASE 2 picks the
+// values up as its first round and continues as PHASE 0 does (verification, follow-up rounds token-major: a handful of rows).
+template <int NW, bool EXT = false, bool LDSA = false, int PHASE = 0>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
 __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,15 +168,18 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   constexpr int PRE_LO = 96, PRE_HI = 128, PRE_MIN = 192, PRE_PK = 32;
   int n_sorted = n;
   bool partial = false;
+  bool presorted = false;                      // PHASE 2: PHASE 1 left the list sorted in place
+  if constexpr (PHASE == 2) presorted = (p.fm_target[t] & FM_SORTED) != 0;
   auto full_sort = [&]() {
     if constexpr (!EXT) {
       __syncthreads();
       for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
     }
+    if (presorted) { __syncthreads(); return; }
     wave_sort_desc_u64<NT>(keys, np, lane);
   };
   if constexpr (!EXT && NW == 1) {
-    if (msae_tuning::RESCORE_PRESELECT && n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
+    if (msae_tuning::RESCORE_PRESELECT && !presorted && n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
       const int nj = (n + 63) >> 6;
       unsigned long long kreg[PRE_PK];
 #pragma unroll
@@ -224,7 +237,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   // ---- size of the first round ------------------------------------------------------------------
   const int lim = n < p.r_max ? n : p.r_max;
   int target = lim;
-  {
+  if constexpr (PHASE == 2) {
+    target = p.fm_target[t] & (FM_SORTED - 1);
+  } else {
     const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
     const int mt = n < mt_max ? n : mt_max;
     float my_cc = -__builtin_inff(), my_zs = 0.f;
@@ -267,6 +282,18 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
   const bool guarded = !EXT && rc[3] != 0.f;     // the token's shape is outside the noise model (quant_x_kernel): exact path
   if (guarded) target = 0;                       // (no row is read for it here)
+  if constexpr (PHASE == 1) {
+    if (partial && target > n_sorted) need_full();          // wave-uniform
+    for (int c = lane; c < target; c += NT) {
+      const unsigned long long key = keys[c];
+      p.fm_keys[(size_t)t * p.fm_rcap + c] = key;
+      atomicAdd(p.fm_count + rank_key_index(key), 1);
+    }
+    if (!partial)
+      for (int i = lane; i < n; i += NT) const_cast<unsigned long long *>(p.cand)[(size_t)t * p.cap + i] = keys[i];
+    if (lane == 0) p.fm_target[t] = target | (partial ? 0 : FM_SORTED);
+    return;
+  }
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
   bool ok = false, viol = false;
   int rounds = 0;
@@ -353,12 +380,30 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
     // p.lpr lanes per row and as many waves per token.
     if (partial && target > n_sorted) need_full();          // wave-uniform
-    const bool few = rounds > 1 && target - done <= NT / 4;
-    int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
-    while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
-    if (lpr == 4) run_pass(std::integral_constant<int, 4>());
-    else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
-    else run_pass(std::integral_constant<int, 1>());
+    bool from_fm = false;
+    if constexpr (PHASE == 2) {
+      if (rounds == 1) {                                     // the first round's values: fm_dot_kernel computed them
+        from_fm = true;
+        for (int c = lane; c < target; c += NT) {
+          const unsigned long long key = keys[c];
+          const int f = rank_key_index(key);
+          const float upper = f32_from_order_key((unsigned)(key >> 32));
+          const float pre = p.fm_pre[(size_t)t * p.fm_rcap + c];
+          res[has_set + c] = rank_key(pre > 0.f ? pre : 0.f, f);
+          const float zs2 = band_sq(rc, p.colc[f], p.zz12, i8);
+          const float diff = pre - (upper - __builtin_sqrtf(zs2));
+          if (diff * diff * p.z2 > zc2 * zs2 * 1.0001f + 1e-30f) my_viol = 1;
+        }
+      }
+    }
+    if (!from_fm) {
+      const bool few = rounds > 1 && target - done <= NT / 4;
+      int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
+      while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
+      if (lpr == 4) run_pass(std::integral_constant<int, 4>());
+      else if (lpr == 2) run_pass(std::integral_constant<int, 2>());
+      else run_pass(std::integral_constant<int, 1>());
+    }
     done = target;
     viol = viol || (__syncthreads_or(my_viol) != 0);
     MSAE_RTL(2 + 2 * rounds);
@@ -393,13 +438,133 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     const int reason = 2 | (cnt > p.cap ? 4 : 0) | (!(tau > 0.f) ? 8 : 0) |
                        (done + has_set < p.k ? 16 : 0) | (guarded ? 128 : (viol ? 64 : 32));
     if (p.status) p.status[t] = ok ? 0 : reason;
-    // msae_options::rows_rescored: rounds << 24 | first-round rows << 12 | rows of W_enc this token read (0: not verified here)
-    if (p.rows_out) p.rows_out[t] = ok ? (rounds << 24) | (first_target << 12) | done : 0;
+    // msae_options::rows_rescored: [1 << 30: first round feature-major] | rounds << 24 | first-round rows << 12 | rows of W_enc
+    // this token read (0: not verified here)
+    if (p.rows_out) p.rows_out[t] = ok ? (PHASE == 2 ? 1 << 30 : 0) | (rounds << 24) | (first_target << 12) | done : 0;
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
       if (slot < p.fb_cap) p.flagged[slot] = t;
     }
   }
+}
+
+// ---- feature-major first round -------------------------------------------------------------------
+// counts[0 .. N) -> exclusive starts in place, counts[N] = the number of pairs: block sums (1024 counts each), then every block
+// adds up the sums before it and scans its own 1024 counts (4 per thread).
+constexpr int FM_SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(256) void fm_blocksum_kernel(const int *__restrict__ counts, int N, int *__restrict__ bsum) {
+  __shared__ int red[4];
+  const int i0 = blockIdx.x * FM_SCAN_BLOCK + threadIdx.x * 4;
+  int s = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s += (i0 + e < N) ? counts[i0 + e] : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, int N, const int *__restrict__ bsum) {
+  __shared__ int part[256];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  int pre = 0;
+  for (int j = tid; j < b; j += 256) pre += bsum[j];
+  part[tid] = pre;
+  __syncthreads();
+  if (tid < 64) {
+    int v = part[tid] + part[tid + 64] + part[tid + 128] + part[tid + 192];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (tid == 0) s_base = v;
+  }
+  __syncthreads();
+  const int i0 = b * FM_SCAN_BLOCK + tid * 4;
+  int c[4], sum = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c[e] = (i0 + e < N) ? counts[i0 + e] : 0; sum += c[e]; }
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_base + part[tid] - sum;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { if (i0 + e < N) counts[i0 + e] = run; run += c[e]; }
+  if (b == (int)gridDim.x - 1 && tid == 255) counts[N] = s_base + part[255];
+}
+// pair (t, c) -> its place among its feature's pairs (any order inside a feature: the pairs are independent).
+// pairs[pos] = (feature, t * rcap + c); starts[f] ends up as the END of feature f.
+__global__ __launch_bounds__(256) void fm_scatter_kernel(const int *__restrict__ fm_target, const unsigned long long *__restrict__ fm_keys,
+                                                         int rcap, int *__restrict__ starts, int2 *__restrict__ pairs) {
+  const int t = blockIdx.x, target = fm_target[t] & (FM_SORTED - 1);
+  for (int c = threadIdx.x; c < target; c += 256) {
+    const int f = rank_key_index(fm_keys[(size_t)t * rcap + c]);
+    pairs[atomicAdd(starts + f, 1)] = make_int2(f, t * rcap + c);
+  }
+}
+// One lane per pair, the pairs in feature order: the lane walks its feature's row of W_enc and its token's row of x
+// itself (a = float(x) - b_dec, sae.py:174: the same f32 value prep writes to a32), one ascending-k fma chain as
+// select_rescore_kernel's.  Consecutive lanes mostly share the W_enc row (the texture path merges equal addresses and the
+// row comes from HBM once); the activation rows (T x d in the caller's type: 67 MB of bf16 at 8192 x 4096) come out of the
+// Infinity Cache.  profiles/r04_fm_rescore_probe.txt: 3.9 ms for the 2.84 M pairs of k = 256 against 7.2 token-major.
+template <int DT>
+__global__ __launch_bounds__(64) void fm_dot_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
+                                                    const float *__restrict__ W_enc, const float *__restrict__ b_enc,
+                                                    const int2 *__restrict__ pairs, const int *__restrict__ n_pairs_p, int d, int rcap,
+                                                    float *__restrict__ fm_pre) {
+  const int n_pairs = *n_pairs_p;
+  if ((int)blockIdx.x * 64 >= n_pairs) return;
+  const int lane = threadIdx.x, pair = blockIdx.x * 64 + lane;
+  const int2 fo = pairs[pair < n_pairs ? pair : n_pairs - 1];
+  const float *__restrict__ w = W_enc + (size_t)fo.x * d;
+  constexpr bool X32 = DT == MSAE_F32;
+  constexpr int U = X32 ? 8 : 16, B = 4 * U;           // 16-B pieces of the W row / floats per batch; two batches in flight
+  constexpr int XU = X32 ? U : U / 2;                   // 16-B pieces of the x row per batch
+  const unsigned char *__restrict__ xr = static_cast<const unsigned char *>(x) + (size_t)(fo.y / rcap) * d * (X32 ? 4 : 2);
+  f32x4 wa[U], wb[U];
+  u32x4 xa[XU], xb[XU];
+  float acc = 0.f;
+  auto fetch = [&](f32x4 (&dw)[U], u32x4 (&dx)[XU], int kk) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) dw[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
+#pragma unroll
+    for (int u = 0; u < XU; ++u) dx[u] = *reinterpret_cast<const u32x4 *>(xr + (size_t)kk * (X32 ? 4 : 2) + 16 * u);
+  };
+  auto consume = [&](auto bd_tag, const f32x4 (&sw)[U], const u32x4 (&sx)[XU], int kk) {
+    constexpr bool HAS_BD = decltype(bd_tag)::value;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xf;
+        if constexpr (X32) xf = __uint_as_float(sx[u][e]);
+        else {
+          const unsigned pk = sx[u >> 1][(u & 1) * 2 + (e >> 1)];
+          if constexpr (DT == MSAE_BF16) xf = __uint_as_float((e & 1) ? (pk & 0xFFFF0000u) : (pk << 16));
+          else xf = f16_bits_to_f32((unsigned short)((e & 1) ? (pk >> 16) : (pk & 0xFFFFu)));
+        }
+        float a = xf;
+        if constexpr (HAS_BD) a = xf - b_dec[kk + 4 * u + e];           // wave-uniform address: scalar loads
+        acc = __builtin_fmaf(a, sw[u][e], acc);
+      }
+    }
+  };
+  auto walk = [&](auto bd_tag) {
+    fetch(wa, xa, 0);
+    for (int kk = 0; kk < d; kk += 2 * B) {              // d % B == 0 (fast_shape_ok)
+      const bool has_b = kk + B < d;
+      if (has_b) fetch(wb, xb, kk + B);
+      consume(bd_tag, wa, xa, kk);
+      if (kk + 2 * B < d) fetch(wa, xa, kk + 2 * B);
+      if (has_b) consume(bd_tag, wb, xb, kk + B);
+    }
+  };
+  if (b_dec) walk(std::true_type()); else walk(std::false_type());
+  if (pair < n_pairs) fm_pre[fo.y] = acc + (b_enc ? b_enc[fo.x] : 0.f);
 }
 
 // Feature-sharded group, sender side: the C best candidates of THIS shard per token by upper value, as the
@@ -502,25 +667,40 @@ inline void rescore_shape(int T, int k, int &nw, int &lpr) {
     nw = lpr;
   }
 }
-template <bool EXT>
+template <bool EXT, int PHASE = 0>
 inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, const float *a32, const float *W_enc,
                                  hipStream_t s) {
   int nw;
   rescore_shape(T, k, nw, ra.lpr);
-  const bool ldsa = ra.lpr > 1 && smem + (size_t)ra.d * 4 <= 96 * 1024;      // small batch: activations in LDS
+  const bool ldsa = PHASE == 0 && ra.lpr > 1 && smem + (size_t)ra.d * 4 <= 96 * 1024;      // small batch: activations in LDS
   if (ldsa) smem += (size_t)ra.d * 4;
-#define MSAE_RS_LAUNCH(NWV, LDSAV)                                                                                   \
-  do {                                                                                                               \
-    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT, LDSAV>,                           \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                        \
-    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
+#define MSAE_RS_LAUNCH(NWV, LDSAV, PH)                                                                                   \
+  do {                                                                                                                   \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT, LDSAV, PH>,                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                            \
+    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV, PH>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
   } while (0)
-  if (ldsa) { if (nw == 2) MSAE_RS_LAUNCH(2, true); else MSAE_RS_LAUNCH(4, true); }
-  else if (nw == 1) MSAE_RS_LAUNCH(1, false);
-  else if (nw == 2) MSAE_RS_LAUNCH(2, false);
-  else MSAE_RS_LAUNCH(4, false);
+  if constexpr (PHASE != 0) {                 // feature-major first round: large batches only (fm_shape_ok: a lane per row)
+    if (nw == 1) MSAE_RS_LAUNCH(1, false, PHASE); else MSAE_RS_LAUNCH(4, false, PHASE);
+  } else {
+    if (ldsa) { if (nw == 2) MSAE_RS_LAUNCH(2, true, 0); else MSAE_RS_LAUNCH(4, true, 0); }
+    else if (nw == 1) MSAE_RS_LAUNCH(1, false, 0);
+    else if (nw == 2) MSAE_RS_LAUNCH(2, false, 0);
+    else MSAE_RS_LAUNCH(4, false, 0);
+  }
 #undef MSAE_RS_LAUNCH
   return 0;
+}
+
+// The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch: ~1.36 k rows per token
+// over N features.  Measured crossover (profiles/r04_fm_rescore.txt): from ~4 tokens per feature.  MSAE_FM=0 / 1 forces it.
+inline bool fm_shape_ok(int T, int k, int N, int r_max) {
+  int nw, lpr;
+  rescore_shape(T, k, nw, lpr);
+  if (lpr != 1 || (long)T * r_max >= (1L << 31)) return false;
+  static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
+  if (force >= 0) return force != 0;
+  return 1.36 * (double)T * k >= 4.0 * N;
 }
 
 }  // namespace

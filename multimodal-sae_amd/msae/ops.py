@@ -176,8 +176,8 @@ def profiling(profile: StageProfile):
 @contextlib.contextmanager
 def rescore_rows(buf: Tensor):
     """Fused encodes of <= buf.numel() tokens issued inside the block write their per-token re-score statistics
-    (msae_options::rows_rescored: rounds << 24 | first-round rows << 12 | rows of W_enc read; 0 = not verified by the
-    large-batch re-score) into `buf` (device int32)."""
+    (msae_options::rows_rescored: [bit 30: first round feature-major] | rounds << 24 | first-round rows << 12 | rows of W_enc
+    read; 0 = not verified by the large-batch re-score) into `buf` (device int32)."""
     assert buf.is_cuda and buf.dtype == torch.int32 and buf.is_contiguous()
     prev, _defaults.rows_rescored = _defaults.rows_rescored, buf
     try:

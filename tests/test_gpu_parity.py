@@ -371,6 +371,46 @@ def test_weight_stream_kernel_batches(dev, T, d):
         assert torch.equal(i, ei) and torch.equal(v, ev), (T, kw)
 
 
+@pytest.mark.parametrize("T,d,N,k,dtype", [(1536, 512, 8192, 32, torch.bfloat16), (1200, 1024, 8192, 128, torch.float16),
+                                           (2048, 256, 16384, 64, torch.float32), (1000, 512, 8192, 256, torch.bfloat16)])
+def test_feature_major_first_round_equals_exact_path(dev, coarse, T, d, N, k, dtype):
+    """Batches in which a feature is a candidate of several tokens re-score their first round FEATURE-major (counting sort of the
+    (token, feature) pairs, fm_dot_kernel reading the caller's x in its own type): the route is taken (bit 30 of
+    msae_options::rows_rescored), and its results are the exact path's bits -- plain, with hook edits, with tokens that go to
+    the exact path in the same batch."""
+    from msae import ops
+
+    W_enc, b_enc, b_dec = _rand_sae(dev, d, N, 41)
+    x = _rand_x(dev, T, d, 42).float().to(dtype)
+    x[5] = 0
+    x[9] = (x[9].float() * 1e-30).to(dtype)
+    prepared = ops.prepare_encoder(W_enc)
+    pre = ops.pre_acts(x, W_enc, b_enc, b_dec)
+    hot = int(pre[0].argmax())
+    rows = torch.zeros(T, dtype=torch.int32, device=dev)
+    for kw in (dict(), dict(set_feature=77, set_value=10.0, zero_feature=hot)):
+        lat = pre.clone()
+        if kw:
+            lat[:, 77] = 10.0
+            lat[:, hot] = 0.0
+        ev, ei = ops.topk(lat, k)
+        rows.zero_()
+        with ops.rescore_rows(rows):
+            v, i, status = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k, **kw)
+        st = status.cpu().numpy()
+        assert (st != 2).all()
+        assert (st == 0).mean() > 0.9, f"fast path verified only {(st == 0).mean():.2%}"
+        took = ((rows >> 30) & 1).bool()
+        assert took[status == 0].all(), "the feature-major route was not taken"
+        assert torch.equal(i, ei), f"{kw}: indices differ on {(i != ei).any(-1).sum().item()} tokens"
+        assert torch.equal(v, ev)
+    ref_v, ref_i = oracle.encode_topk(x[:8].float().cpu().numpy(), W_enc.cpu().numpy(), b_enc.cpu().numpy(),
+                                      b_dec.cpu().numpy(), k)
+    v, i, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)
+    assert_bit_equal(i[:8].cpu().numpy().astype(np.int32), ref_i, "feature-major idx vs oracle")
+    assert_bit_equal(v[:8].cpu().numpy(), ref_v, "feature-major vals vs oracle")
+
+
 def test_fused_encode_degenerate_tokens_take_exact_path(dev, coarse):
     """Tokens with (almost) no positive pre-activation cannot pass the guard band: they must come
     back from the in-call exact fallback (status 1) with the canonical zero-filled top-k."""

@@ -21,7 +21,7 @@ for cluster in (160, 230):
     with ops.rescore_rows(st):
         v, i, _ = ops.encode_topk(x, W.contiguous(), b, bd, ops.prepare_encoder(W.contiguous()), k)
     ok = st > 255                      # verified tokens: rounds << 24 | first round << 12 | rows
-    done, rounds = (st[ok] & 0xFFF), (st[ok] >> 24)
+    done, rounds = (st[ok] & 0xFFF), ((st[ok] >> 24) & 0x3F)
     print(f"cluster {cluster}: {int(ok.sum())}/{T} verified on the fused path; rows re-scored min/median/max "
           f"{int(done.min())}/{int(done.median())}/{int(done.max())}; rounds max {int(rounds.max())}; "
           f"tokens past 128 rows: {int((done > 128).sum())}")

@@ -26,7 +26,7 @@ for kind in kinds:
         torch.cuda.synchronize()
         s, st = buf.cpu(), st.cpu()
         ok = s >= (1 << 24)
-        rounds, first, rows = s[ok] >> 24, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
+        rounds, first, rows = (s[ok] >> 24) & 0x3F, (s[ok] >> 12) & 0xFFF, s[ok] & 0xFFF
         print(f"k={k} {kind}/{mode}: verified {int(ok.sum())}/{T}  rounds hist {torch.bincount(rounds).tolist()}  "
               f"mean rows {rows.float().mean():.1f} (first round {first.float().mean():.1f})  "
               f"rows p50/p99/max {int(rows.float().quantile(0.5))}/{int(rows.float().quantile(0.99))}/{int(rows.max())}  "
