@@ -209,7 +209,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_fmcount = take(((size_t)N + 64 + (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK) * 4);   // counts [N] | total | block sums
       p.off_fmtarget = take((size_t)T * 4);
       p.off_fmkeys = take((size_t)T * p.r_max * 8);
-      p.off_fmpairs = take((size_t)T * p.r_max * 8);
+      p.off_fmpairs = take(((size_t)T * p.r_max + (size_t)N * 16) * 8);   // slots: the pairs + every feature's padding to whole groups
       p.off_fmpre = take((size_t)T * p.r_max * 4);
     }
   } else {
@@ -546,13 +546,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
       lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
       if (lrc) return lrc;
-      const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK;
-      hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, fcount + N + 64);
-      hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, fcount + N + 64);
+      const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK, G = fm_group_lanes(T, k, N);
+      hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64);
+      hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64, pairs);
       hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, pl.r_max, fcount, pairs);
-      const long max_pairs = (long)T * pl.r_max;
-      hipLaunchKernelGGL(fm_dot_kernel<DT>, dim3((unsigned)((max_pairs + 63) / 64)), dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs,
-                         fcount + N, d, pl.r_max, fpre);
+      const long max_slots = (long)T * pl.r_max + (long)N * (G - 1);
+      const dim3 dgrid((unsigned)((max_slots + 63) / 64));
+      if (G == 16) hipLaunchKernelGGL((fm_dot_kernel<DT, 16>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
+      else hipLaunchKernelGGL((fm_dot_kernel<DT, 4>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
       lrc = launch_select_rescore<false, 2>(ra, T, k, smem, (const float *)a32, W_enc, s);
     } else {
       lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);

@@ -449,22 +449,26 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
 }
 
 // ---- feature-major first round -------------------------------------------------------------------
-// counts[0 .. N) -> exclusive starts in place, counts[N] = the number of pairs: block sums (1024 counts each), then every block
-// adds up the sums before it and scans its own 1024 counts (4 per thread).
+// The pairs of a feature occupy whole GROUPS of G lanes (G = 4 or 16: fm_group_lanes) of fm_dot_kernel's waves, so a feature's
+// count is rounded up to a multiple of G; the pad slots carry the feature and no token.
+// counts[0 .. N) -> padded exclusive starts in place, counts[N] = the number of slots: block sums (1024 counts each), then
+// every block adds up the sums before it and scans its own 1024 counts (4 per thread) and writes its features' pad slots.
 constexpr int FM_SCAN_BLOCK = 1024;
-__global__ __launch_bounds__(256) void fm_blocksum_kernel(const int *__restrict__ counts, int N, int *__restrict__ bsum) {
+__device__ __forceinline__ int fm_pad(int c, int G) { return (c + G - 1) & ~(G - 1); }
+__global__ __launch_bounds__(256) void fm_blocksum_kernel(const int *__restrict__ counts, int N, int G, int *__restrict__ bsum) {
   __shared__ int red[4];
   const int i0 = blockIdx.x * FM_SCAN_BLOCK + threadIdx.x * 4;
   int s = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) s += (i0 + e < N) ? counts[i0 + e] : 0;
+  for (int e = 0; e < 4; ++e) s += (i0 + e < N) ? fm_pad(counts[i0 + e], G) : 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, int N, const int *__restrict__ bsum) {
+__global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, int N, int G, const int *__restrict__ bsum,
+                                                      int2 *__restrict__ slots) {
   __shared__ int part[256];
   __shared__ int s_base;
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, 
   const int i0 = b * FM_SCAN_BLOCK + tid * 4;
   int c[4], sum = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { c[e] = (i0 + e < N) ? counts[i0 + e] : 0; sum += c[e]; }
+  for (int e = 0; e < 4; ++e) { c[e] = (i0 + e < N) ? counts[i0 + e] : 0; sum += fm_pad(c[e], G); }
   part[tid] = sum;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
@@ -493,79 +497,118 @@ __global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, 
   }
   int run = s_base + part[tid] - sum;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { if (i0 + e < N) counts[i0 + e] = run; run += c[e]; }
+  for (int e = 0; e < 4; ++e) {
+    if (i0 + e < N) {
+      counts[i0 + e] = run;
+      const int padded = fm_pad(c[e], G);
+      for (int q = c[e]; q < padded; ++q) slots[run + q] = make_int2(i0 + e, -1);
+      run += padded;
+    }
+  }
   if (b == (int)gridDim.x - 1 && tid == 255) counts[N] = s_base + part[255];
 }
-// pair (t, c) -> its place among its feature's pairs (any order inside a feature: the pairs are independent).
-// pairs[pos] = (feature, t * rcap + c); starts[f] ends up as the END of feature f.
+// pair (t, c) -> its place among its feature's slots (any order inside a feature: the pairs are independent).
+// slots[pos] = (feature, t * rcap + c); starts[f] ends up behind the feature's last pair.
 __global__ __launch_bounds__(256) void fm_scatter_kernel(const int *__restrict__ fm_target, const unsigned long long *__restrict__ fm_keys,
-                                                         int rcap, int *__restrict__ starts, int2 *__restrict__ pairs) {
+                                                         int rcap, int *__restrict__ starts, int2 *__restrict__ slots) {
   const int t = blockIdx.x, target = fm_target[t] & (FM_SORTED - 1);
   for (int c = threadIdx.x; c < target; c += 256) {
     const int f = rank_key_index(fm_keys[(size_t)t * rcap + c]);
-    pairs[atomicAdd(starts + f, 1)] = make_int2(f, t * rcap + c);
+    slots[atomicAdd(starts + f, 1)] = make_int2(f, t * rcap + c);
   }
 }
-// One lane per pair, the pairs in feature order: the lane walks its feature's row of W_enc and its token's row of x
-// itself (a = float(x) - b_dec, sae.py:174: the same f32 value prep writes to a32), one ascending-k fma chain as
-// select_rescore_kernel's.  Consecutive lanes mostly share the W_enc row (the texture path merges equal addresses and the
-// row comes from HBM once); the activation rows (T x d in the caller's type: 67 MB of bf16 at 8192 x 4096) come out of the
-// Infinity Cache.  profiles/r04_fm_rescore_probe.txt: 3.9 ms for the 2.84 M pairs of k = 256 against 7.2 token-major.
-template <int DT>
-__global__ __launch_bounds__(64) void fm_dot_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
-                                                    const float *__restrict__ W_enc, const float *__restrict__ b_enc,
-                                                    const int2 *__restrict__ pairs, const int *__restrict__ n_pairs_p, int d, int rcap,
-                                                    float *__restrict__ fm_pre) {
-  const int n_pairs = *n_pairs_p;
-  if ((int)blockIdx.x * 64 >= n_pairs) return;
-  const int lane = threadIdx.x, pair = blockIdx.x * 64 + lane;
-  const int2 fo = pairs[pair < n_pairs ? pair : n_pairs - 1];
-  const float *__restrict__ w = W_enc + (size_t)fo.x * d;
-  constexpr bool X32 = DT == MSAE_F32;
-  constexpr int U = X32 ? 8 : 16, B = 4 * U;           // 16-B pieces of the W row / floats per batch; two batches in flight
-  constexpr int XU = X32 ? U : U / 2;                   // 16-B pieces of the x row per batch
-  const unsigned char *__restrict__ xr = static_cast<const unsigned char *>(x) + (size_t)(fo.y / rcap) * d * (X32 ? 4 : 2);
-  f32x4 wa[U], wb[U];
-  u32x4 xa[XU], xb[XU];
-  float acc = 0.f;
-  auto fetch = [&](f32x4 (&dw)[U], u32x4 (&dx)[XU], int kk) {
+// acc = fma(a, w of lane SH of this lane's group, acc): ONE v_fmac_f32 (fused) with the DPP source modifier on w.  Written as
+// asm because the compiler does not fold a v_mov_dpp into the fma: it emits the 64 moves of a batch up front (+128 VGPRs).
+// (The registers read through DPP are written by loads, not by VALU instructions; the s_nop covers a copy the register
+// allocator might put in front of a chain.)
+template <int G, int SH>
+__device__ __forceinline__ void fma_share(float &acc, float a, float w) {
+  if constexpr (G == 16) {
+    if constexpr (SH == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(a));
+    else asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(a), "n"(SH));
+  } else {
+    if constexpr (SH == 0) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(a));
+    else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(a), "n"(SH));
+  }
+}
+// piece P of a batch: the 4 G consecutive elements the group's G lanes hold (4 each), in ascending k
+template <int DT, bool HAS_BD, int G, int P, int SH = 0>
+struct FmChain {
+  template <class WR, class XR>
+  static __device__ __forceinline__ void run(float &acc, const WR &sw, const XR &sx, const float *__restrict__ bd) {
+    if constexpr (SH < G) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) dw[u] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * u);
-#pragma unroll
-    for (int u = 0; u < XU; ++u) dx[u] = *reinterpret_cast<const u32x4 *>(xr + (size_t)kk * (X32 ? 4 : 2) + 16 * u);
-  };
-  auto consume = [&](auto bd_tag, const f32x4 (&sw)[U], const u32x4 (&sx)[XU], int kk) {
-    constexpr bool HAS_BD = decltype(bd_tag)::value;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int c = 0; c < 4; ++c) {
+        const int e = (P * G + SH) * 4 + c;                // element of the batch
         float xf;
-        if constexpr (X32) xf = __uint_as_float(sx[u][e]);
+        if constexpr (DT == MSAE_F32) xf = __uint_as_float(sx[e >> 2][e & 3]);
         else {
-          const unsigned pk = sx[u >> 1][(u & 1) * 2 + (e >> 1)];
+          const unsigned pk = sx[e >> 3][(e >> 1) & 3];
           if constexpr (DT == MSAE_BF16) xf = __uint_as_float((e & 1) ? (pk & 0xFFFF0000u) : (pk << 16));
           else xf = f16_bits_to_f32((unsigned short)((e & 1) ? (pk >> 16) : (pk & 0xFFFFu)));
         }
         float a = xf;
-        if constexpr (HAS_BD) a = xf - b_dec[kk + 4 * u + e];           // wave-uniform address: scalar loads
-        acc = __builtin_fmaf(a, sw[u][e], acc);
+        if constexpr (HAS_BD) a = xf - bd[e];               // wave-uniform address: scalar loads
+        fma_share<G, SH>(acc, a, sw[P][c]);
       }
+      FmChain<DT, HAS_BD, G, P, SH + 1>::run(acc, sw, sx, bd);
+    }
+  }
+};
+// One lane per slot, the slots in feature order, G lanes per group: every lane walks its token's row of x itself (the
+// caller's x in its own type: a = float(x) - b_dec, sae.py:174, the same f32 value prep writes to a32), the G lanes of a group
+// load 16 G contiguous bytes of their feature's row of W_enc per instruction and take each other's elements through DPP
+// inside ONE ascending-k fma chain per lane (select_rescore_kernel's chain, bit for bit).  W_enc comes from HBM once per
+// feature; the activation rows (T x d: 67 MB of bf16 at 8192 x 4096) come out of the Infinity Cache, which is the bound:
+// 23 GB at 8.9 TB/s for the 2.84 M pairs of k = 256 (profiles/r04_fm_rescore_probe.txt: 3.1 ms; a lane walking both rows
+// itself 3.9 -- the texture path then carries 24 KB per pair instead of 9; token-major 7.2).
+template <int DT, int G>
+__global__ __launch_bounds__(64) void fm_dot_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
+                                                    const float *__restrict__ W_enc, const float *__restrict__ b_enc,
+                                                    const int2 *__restrict__ slots, const int *__restrict__ n_slots_p, int d, int rcap,
+                                                    float *__restrict__ fm_pre) {
+  const int n_slots = *n_slots_p;                        // a multiple of G
+  if ((int)blockIdx.x * 64 >= n_slots) return;
+  const int lane = threadIdx.x, slot = blockIdx.x * 64 + lane;
+  // slots behind the last one: lanes of whole groups (n_slots % G == 0); they walk the last feature's row, without a token
+  const int2 fo = slot < n_slots ? slots[slot] : make_int2(slots[n_slots - 1].x, -1);
+  const bool valid = fo.y >= 0;
+  constexpr bool X32 = DT == MSAE_F32;
+  constexpr int KB = 64, WP = KB / (4 * G), XP = X32 ? KB / 4 : KB / 8;   // floats of k per batch; 16-B pieces of W / x per lane
+  const float *__restrict__ w = W_enc + (size_t)fo.x * d + 4 * (lane % G);
+  const unsigned char *__restrict__ xr = static_cast<const unsigned char *>(x) + (size_t)(valid ? fo.y / rcap : 0) * d * (X32 ? 4 : 2);
+  f32x4 wa[WP], wb[WP];
+  u32x4 xa[XP], xb[XP];
+  float acc = 0.f;
+  auto fetch = [&](f32x4 (&dw)[WP], u32x4 (&dx)[XP], int kk) {
+#pragma unroll
+    for (int p = 0; p < WP; ++p) dw[p] = *reinterpret_cast<const f32x4 *>(w + kk + 4 * G * p);
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < XP; ++u) dx[u] = *reinterpret_cast<const u32x4 *>(xr + (size_t)kk * (X32 ? 4 : 2) + 16 * u);
     }
   };
   auto walk = [&](auto bd_tag) {
+    constexpr bool HAS_BD = decltype(bd_tag)::value;
+    auto consume = [&](const f32x4 (&sw)[WP], const u32x4 (&sx)[XP], int kk) {
+      const float *__restrict__ bd = HAS_BD ? b_dec + kk : nullptr;
+      FmChain<DT, HAS_BD, G, 0>::run(acc, sw, sx, bd);
+      if constexpr (WP >= 2) FmChain<DT, HAS_BD, G, 1>::run(acc, sw, sx, bd);
+      if constexpr (WP >= 4) { FmChain<DT, HAS_BD, G, 2>::run(acc, sw, sx, bd); FmChain<DT, HAS_BD, G, 3>::run(acc, sw, sx, bd); }
+    };
     fetch(wa, xa, 0);
-    for (int kk = 0; kk < d; kk += 2 * B) {              // d % B == 0 (fast_shape_ok)
-      const bool has_b = kk + B < d;
-      if (has_b) fetch(wb, xb, kk + B);
-      consume(bd_tag, wa, xa, kk);
-      if (kk + 2 * B < d) fetch(wa, xa, kk + 2 * B);
-      if (has_b) consume(bd_tag, wb, xb, kk + B);
+    for (int kk = 0; kk < d; kk += 2 * KB) {             // d % KB == 0 (fast_shape_ok)
+      const bool has_b = kk + KB < d;
+      if (has_b) fetch(wb, xb, kk + KB);
+      consume(wa, xa, kk);
+      if (kk + 2 * KB < d) fetch(wa, xa, kk + 2 * KB);
+      if (has_b) consume(wb, xb, kk + KB);
     }
   };
   if (b_dec) walk(std::true_type()); else walk(std::false_type());
-  if (pair < n_pairs) fm_pre[fo.y] = acc + (b_enc ? b_enc[fo.x] : 0.f);
+  if (valid) fm_pre[fo.y] = acc + (b_enc ? b_enc[fo.x] : 0.f);
 }
+static_assert(64 / (4 * 16) == 1 && 64 / (4 * 4) == 4, "fm_dot_kernel's consume covers WP = 1, 2 and 4");
 
 // Feature-sharded group, sender side: the C best candidates of THIS shard per token by upper value, as the
 // record shard_record_bytes() describes (global feature ids).  One wave per token.
@@ -694,10 +737,12 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
 
 // The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch: ~1.36 k rows per token
 // over N features.  Measured crossover (profiles/r04_fm_rescore.txt): from ~4 tokens per feature.  MSAE_FM=0 / 1 forces it.
+// lanes per feature group of fm_dot_kernel: 16 when a feature has >= ~12 pairs (k = 256 at 8192 tokens: 22), else 4
+inline int fm_group_lanes(int T, int k, int N) { return 1.36 * (double)T * k >= 12.0 * N ? 16 : 4; }
 inline bool fm_shape_ok(int T, int k, int N, int r_max) {
   int nw, lpr;
   rescore_shape(T, k, nw, lpr);
-  if (lpr != 1 || (long)T * r_max >= (1L << 31)) return false;
+  if (lpr != 1 || (long)T * r_max + (long)N * 16 >= (1L << 31)) return false;
   static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
   if (force >= 0) return force != 0;
   return 1.36 * (double)T * k >= 4.0 * N;
