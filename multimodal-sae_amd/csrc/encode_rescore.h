@@ -29,7 +29,9 @@ struct RescoreArgs {
   // first-round size per token (| FM_SORTED), the first-round keys [T][fm_rcap], their exact pre-activations [T][fm_rcap]
   int *fm_count; int *fm_target; unsigned long long *fm_keys; const float *fm_pre; int fm_rcap;
 };
-constexpr int FM_SORTED = 1 << 30;   // fm_target: the token's whole list was written back in sorted order
+// fm_target[t] = first-round size (12 bits) | sorted prefix saved in fm_keys (8 bits, PHASE 1's preselect) << 12 | FM_SORTED
+constexpr int FM_SORTED = 1 << 30;   // the token's whole list was written back to cand in sorted order
+constexpr int FM_TARGET_MASK = 0xFFF, FM_PREFIX_SHIFT = 12, FM_PREFIX_MASK = 0xFF;
 
 // One shard's record of a token (msae_shard_candidates): C keys (order key of the upper value u | 0x7FFFFFFF -
 // GLOBAL feature, 0 = empty), C times z sigma of that (token, feature) pair, tau = the largest u any feature of
@@ -50,6 +52,41 @@ __device__ __forceinline__ void wave_sort_desc_u64(unsigned long long *s, int n,
       }
     }
   __syncthreads();
+}
+
+// The same order for <= 64 R keys by ONE wave in registers: key i = r * 64 + lane sits in v[r]; partners 64 or more apart are
+// the lane's own registers, closer ones another lane's (two 32-bit shuffles).  No LDS traffic, no barriers: a 64-key sort is
+// 21 compare-exchange steps of ~10 instructions (the LDS version: 21 barriers, ~10 k cycles for a wave that is alone).
+template <int R>
+__device__ __forceinline__ void wave_sort_desc_u64_regs(unsigned long long (&v)[R], int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64 * R; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 64) {
+        constexpr int dummy = 0; (void)dummy;
+        const int rs = stride >> 6;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & rs) == 0) {
+            const bool desc = (((r * 64 + lane) & size) == 0);
+            const unsigned long long a = v[r], b = v[r | rs];
+            if ((a < b) == desc) { v[r] = b; v[r | rs] = a; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = r * 64 + lane;
+          const unsigned lo = __shfl_xor((unsigned)v[r], stride, 64), hi = __shfl_xor((unsigned)(v[r] >> 32), stride, 64);
+          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+          // the lower index of a pair keeps the larger key where the block sorts descending
+          const bool lower = (lane & stride) == 0, desc = ((i & size) == 0);
+          const bool take_max = lower == desc;
+          v[r] = take_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+        }
+      }
+    }
 }
 
 // number of keys (sorted descending, value in the upper 32 bits as an order key) whose value is >= v
@@ -178,8 +215,17 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     if (presorted) { __syncthreads(); return; }
     wave_sort_desc_u64<NT>(keys, np, lane);
   };
+  if constexpr (PHASE == 2 && NW == 1) {      // PHASE 1's preselected + sorted prefix, as it left it
+    const int saved = (p.fm_target[t] >> FM_PREFIX_SHIFT) & FM_PREFIX_MASK;
+    if (!presorted && saved > 0) {
+      for (int i = lane; i < PRE_HI; i += NT) keys[i] = i < saved ? p.fm_keys[(size_t)t * p.fm_rcap + i] : 0ull;
+      __syncthreads();
+      partial = true;
+      n_sorted = saved;
+    }
+  }
   if constexpr (!EXT && NW == 1) {
-    if (msae_tuning::RESCORE_PRESELECT && !presorted && n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
+    if (msae_tuning::RESCORE_PRESELECT && !presorted && !partial && n > PRE_MIN && n <= 64 * PRE_PK && p.k + 4 <= 64) {          // wave-uniform
       const int nj = (n + 63) >> 6;
       unsigned long long kreg[PRE_PK];
 #pragma unroll
@@ -217,7 +263,14 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
           }
         }
         for (int i = c_sel + lane; i < PRE_HI; i += NT) keys[i] = 0ull;
-        wave_sort_desc_u64<NT>(keys, PRE_HI, lane);
+        {   // the PRE_HI = 128 slots: two keys per lane, sorted in registers
+          static_assert(PRE_HI == 2 * NT, "two key slots per lane");
+          __syncthreads();
+          unsigned long long v2[2] = {keys[lane], keys[64 + lane]};
+          wave_sort_desc_u64_regs<2>(v2, lane);
+          keys[lane] = v2[0]; keys[64 + lane] = v2[1];
+          __syncthreads();
+        }
         partial = true;
         n_sorted = c_sel;
       }
@@ -238,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const int lim = n < p.r_max ? n : p.r_max;
   int target = lim;
   if constexpr (PHASE == 2) {
-    target = p.fm_target[t] & (FM_SORTED - 1);
+    target = p.fm_target[t] & FM_TARGET_MASK;
   } else {
     const int mt_max = p.k <= 64 ? 64 : NT;       // the same statistic whatever the number of waves per token
     const int mt = n < mt_max ? n : mt_max;
@@ -284,14 +337,16 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   if (guarded) target = 0;                       // (no row is read for it here)
   if constexpr (PHASE == 1) {
     if (partial && target > n_sorted) need_full();          // wave-uniform
-    for (int c = lane; c < target; c += NT) {
+    // the first round's keys (the counting sort reads them), and behind them the rest of a preselected prefix for PHASE 2
+    const int save = partial && n_sorted <= p.fm_rcap && n_sorted <= FM_PREFIX_MASK ? n_sorted : 0;
+    for (int c = lane; c < (target > save ? target : save); c += NT) {
       const unsigned long long key = keys[c];
       p.fm_keys[(size_t)t * p.fm_rcap + c] = key;
-      atomicAdd(p.fm_count + rank_key_index(key), 1);
+      if (c < target) atomicAdd(p.fm_count + rank_key_index(key), 1);
     }
     if (!partial)
       for (int i = lane; i < n; i += NT) const_cast<unsigned long long *>(p.cand)[(size_t)t * p.cap + i] = keys[i];
-    if (lane == 0) p.fm_target[t] = target | (partial ? 0 : FM_SORTED);
+    if (lane == 0) p.fm_target[t] = target | (save << FM_PREFIX_SHIFT) | (partial ? 0 : FM_SORTED);
     return;
   }
   int done = 0;                                  // candidates re-scored so far (wave-uniform)
@@ -409,7 +464,18 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     MSAE_RTL(2 + 2 * rounds);
     {   // res[] is zero (= empty, the smallest key) behind the slots written so far: sort the filled prefix only
       const int filled = next_pow2(done + has_set > 2 ? done + has_set : 2);
-      wave_sort_desc_u64<NT>(res, filled < nrp ? filled : nrp, lane);
+      bool in_regs = false;
+      if constexpr (NW == 1) {
+        if (filled <= 64 && nrp >= 64) {                     // wave-uniform: one key per lane, sorted in registers
+          in_regs = true;
+          __syncthreads();
+          unsigned long long v1[1] = {res[lane]};
+          wave_sort_desc_u64_regs<1>(v1, lane);
+          res[lane] = v1[0];
+          __syncthreads();
+        }
+      }
+      if (!in_regs) wave_sort_desc_u64<NT>(res, filled < nrp ? filled : nrp, lane);
     }
     MSAE_RTL(3 + 2 * rounds);
     const bool have_k = done + has_set >= p.k;
@@ -511,7 +577,7 @@ __global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, 
 // slots[pos] = (feature, t * rcap + c); starts[f] ends up behind the feature's last pair.
 __global__ __launch_bounds__(256) void fm_scatter_kernel(const int *__restrict__ fm_target, const unsigned long long *__restrict__ fm_keys,
                                                          int rcap, int *__restrict__ starts, int2 *__restrict__ slots) {
-  const int t = blockIdx.x, target = fm_target[t] & (FM_SORTED - 1);
+  const int t = blockIdx.x, target = fm_target[t] & FM_TARGET_MASK;
   for (int c = threadIdx.x; c < target; c += 256) {
     const int f = rank_key_index(fm_keys[(size_t)t * rcap + c]);
     slots[atomicAdd(starts + f, 1)] = make_int2(f, t * rcap + c);
@@ -735,17 +801,19 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
   return 0;
 }
 
-// The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch: ~1.36 k rows per token
-// over N features.  Measured crossover (profiles/r04_fm_rescore.txt): from ~4 tokens per feature.  MSAE_FM=0 / 1 forces it.
+// The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch -- ~1.36 k rows per token
+// over N features -- and because the activation rows it reads per pair instead come out of the Infinity Cache in the caller's
+// 16-bit type.  Measured at 8192 x 4096 x 131072 (profiles/r04_fm_rescore.txt): k = 256 (22 tokens per feature) 7.96 -> 4.56 ms,
+// k = 32 (2.7) 1.05 -> 0.85; from ~2 tokens per feature the counting sort and the second kernel are paid for.  MSAE_FM=0 / 1 forces it.
 // lanes per feature group of fm_dot_kernel: 16 when a feature has >= ~12 pairs (k = 256 at 8192 tokens: 22), else 4
 inline int fm_group_lanes(int T, int k, int N) { return 1.36 * (double)T * k >= 12.0 * N ? 16 : 4; }
 inline bool fm_shape_ok(int T, int k, int N, int r_max) {
   int nw, lpr;
   rescore_shape(T, k, nw, lpr);
-  if (lpr != 1 || (long)T * r_max + (long)N * 16 >= (1L << 31)) return false;
+  if (lpr != 1 || r_max > 0xFFF || (long)T * r_max + (long)N * 16 >= (1L << 31)) return false;   // (fm_target's 12 bits)
   static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
   if (force >= 0) return force != 0;
-  return 1.36 * (double)T * k >= 4.0 * N;
+  return 1.36 * (double)T * k >= 2.0 * N;
 }
 
 }  // namespace
