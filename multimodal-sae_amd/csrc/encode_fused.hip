@@ -537,7 +537,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
     int lrc;
-    if (pl.fm) {
+    if (pl.fm && msae_aligned(x, 16)) {   // (fm_dot_kernel reads x in 16-B pieces; the entry points ask 8 B of a 16-bit x)
       int *fcount = reinterpret_cast<int *>(ws + pl.off_fmcount);
       int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
       float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);

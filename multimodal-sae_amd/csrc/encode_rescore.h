@@ -152,10 +152,12 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   float tau;
   MSAE_RTL(0);
   const float *__restrict__ a = a32 + (size_t)t * p.d;  // noalias kernel arg + uniform address: s_load
-  if constexpr (LDSA) {                                   // published by the barriers of the list sort below
+  auto stage_a = [&]() {
     for (int i = 4 * (int)threadIdx.x; i < p.d; i += 4 * 64 * NW)
       *reinterpret_cast<f32x4 *>(a_lds + i) = *reinterpret_cast<const f32x4 *>(a + i);
-  }
+  };
+  // (PHASE 2 stages them when a token gets a follow-up round: its first round read no row here)
+  if constexpr (LDSA && PHASE == 0) stage_a();            // published by the barriers of the list sort below
   f32x4 rc = {0.f, 0.f, 0.f, 0.f};
   const bool i8 = p.i8 != 0;
   int np;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       target = n1 < lim ? n1 : lim;
     }
   }
-  if constexpr (LDSA) {   // small batch: one pass reads 64 NW / lpr rows whatever the target -- fill it (fewer second rounds)
+  if constexpr (LDSA && PHASE == 0) {   // small batch: one pass reads 64 NW / lpr rows whatever the target -- fill it (fewer second rounds)
     const int rpp = p.lpr > 0 ? NT / p.lpr : NT;
     const int fill = rpp < lim ? rpp : lim;
     if (target < fill) target = fill;
@@ -452,6 +454,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       }
     }
     if (!from_fm) {
+      // PHASE 2: a follow-up round's wave is alone on its SIMD -- the scalar loads of the activations would be one exposed round
+      // trip per pair of them (~130 k cycles per pass, the kernel's tail); LDSA reads them from LDS
+      if constexpr (LDSA && PHASE == 2) { if (rounds == 2) { stage_a(); __syncthreads(); } }
       const bool few = rounds > 1 && target - done <= NT / 4;
       int lpr = few ? 4 : (MSAE_RESCORE_LPR == 4 ? 4 : p.lpr);
       while (lpr > 1 && p.d % (4 * MSAE_RESCORE_U * lpr) != 0) lpr >>= 1;      // a batch is 64 lpr floats of a row
@@ -790,7 +795,10 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
     hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV, PH>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
   } while (0)
   if constexpr (PHASE != 0) {                 // feature-major first round: large batches only (fm_shape_ok: a lane per row)
-    if (nw == 1) MSAE_RS_LAUNCH(1, false, PHASE); else MSAE_RS_LAUNCH(4, false, PHASE);
+    const bool lds2 = PHASE == 2 && nw == 1 && smem + (size_t)ra.d * 4 <= 64 * 1024;   // follow-up rounds: activations in LDS
+    if (lds2) { smem += (size_t)ra.d * 4; MSAE_RS_LAUNCH(1, true, PHASE); }
+    else if (nw == 1) MSAE_RS_LAUNCH(1, false, PHASE);
+    else MSAE_RS_LAUNCH(4, false, PHASE);
   } else {
     if (ldsa) { if (nw == 2) MSAE_RS_LAUNCH(2, true, 0); else MSAE_RS_LAUNCH(4, true, 0); }
     else if (nw == 1) MSAE_RS_LAUNCH(1, false, 0);

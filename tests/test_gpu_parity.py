@@ -404,6 +404,18 @@ def test_feature_major_first_round_equals_exact_path(dev, coarse, T, d, N, k, dt
         assert took[status == 0].all(), "the feature-major route was not taken"
         assert torch.equal(i, ei), f"{kw}: indices differ on {(i != ei).any(-1).sum().item()} tokens"
         assert torch.equal(v, ev)
+    if dtype != torch.float32:
+        # a 16-bit x that is only 8-byte aligned (all the entry points ask for): token-major first round, same bits
+        buf = torch.empty(T * d + 4, dtype=dtype, device=dev)
+        xm = buf[4:].view(T, d)
+        xm.copy_(x)
+        assert xm.data_ptr() % 16 == 8
+        rows.zero_()
+        with ops.rescore_rows(rows):
+            v, i, status = ops.encode_topk(xm, W_enc, b_enc, b_dec, prepared, k)
+        assert not ((rows >> 30) & 1).any()
+        ev, ei = ops.topk(pre, k)
+        assert torch.equal(i, ei) and torch.equal(v, ev)
     ref_v, ref_i = oracle.encode_topk(x[:8].float().cpu().numpy(), W_enc.cpu().numpy(), b_enc.cpu().numpy(),
                                       b_dec.cpu().numpy(), k)
     v, i, _ = ops.encode_topk(x, W_enc, b_enc, b_dec, prepared, k)

@@ -35,6 +35,12 @@ echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_1M_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
+echo "== feature-major re-score: A/B, probe, k = 256 soak, fuzz with the route forced on / off =="
+timeout 400 bash tools/gpu_fm_ab.sh > $OUT/${R}_fm_rescore.txt 2>&1; cat $OUT/${R}_fm_rescore.txt | cut -c1-220
+KS=256 timeout 250 bash tools/gpu_fm.sh > /dev/null 2>&1; cp $OUT/fm/kernel_stats_k256.csv $OUT/${R}_k256_kernel_stats.csv 2>/dev/null
+[ -x tools/bin/fm_rescore_probe ] && timeout 200 tools/bin/fm_rescore_probe > $OUT/${R}_fm_rescore_probe.txt 2>&1 < /dev/null
+timeout 600 python tools/soak_fused.py --tokens 262144 --N 131072 --d 4096 --k 256 --out $OUT/${R}_soak_k256_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak k256 exit $?"
+(MSAE_FM=1 timeout 400 python tools/fuzz_fused.py 1500 11; MSAE_FM=0 timeout 400 python tools/fuzz_fused.py 1500 11; timeout 400 python tools/fuzz_fused.py 1500 12) 2>&1 | grep -i "cases" > $OUT/${R}_fuzz.txt; cat $OUT/${R}_fuzz.txt
 echo "== shapes / latency / shard emulation / training =="
 timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat $OUT/${R}_other_shapes.txt | grep "T="
 timeout 300 python tools/latency_small_T.py > $OUT/${R}_latency_small_T.txt 2>&1; grep "T=" $OUT/${R}_latency_small_T.txt

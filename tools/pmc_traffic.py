@@ -10,7 +10,11 @@ src, dst = sys.argv[1], sys.argv[2]
 d = json.load(open(src))
 KEYS = {"gemm_kernel<int8,THRESH>": ("gemm_kernel<GemmCfg<256, 256, 2, 2, 4, true, 0>, false>",),
         "gemm_kernel<bf16,THRESH>": ("gemm_kernel<GemmCfg<256, 256, 2, 2, 4, false, 0>, false>",),
-        "select_rescore_kernel": ("select_rescore_kernel<1>", "select_rescore_kernel<1, false"), "decode_fwd_v4_kernel": ("decode_fwd_v4_kernel",)}
+        # the re-score of the bench batch since round 4: PHASE 1 | counting sort | fm_dot_kernel (the row reads) | PHASE 2
+        "fm_dot_kernel": ("fm_dot_kernel",), "select_rescore_kernel<PHASE 1>": ("select_rescore_kernel<1, false, false, 1>",),
+        "select_rescore_kernel<PHASE 2>": ("select_rescore_kernel<1, false, true, 2>",),
+        "select_rescore_kernel": ("select_rescore_kernel<1>", "select_rescore_kernel<1, false, false, 0>"),
+        "decode_fwd_v4_kernel": ("decode_fwd_v4_kernel",)}
 out = {}
 for name, pats in KEYS.items():
     for k, v in d.items():
