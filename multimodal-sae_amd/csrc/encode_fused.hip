@@ -204,7 +204,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     p.fb_chunks = (T + p.fb_cap - 1) / p.fb_cap;
     p.off_flag = take(((size_t)T + 64 + p.fb_chunks) * 4);   // token list [T] | count | per-pass counts
     p.off_fbdense = take((size_t)p.fb_cap * N * 4);
-    p.fm = shard_C == 0 && fm_shape_ok(T, k, N, p.r_max);    // feature-major first round of the re-score (encode_rescore.h)
+    p.fm = shard_C == 0 && fm_shape_ok(T, k, N, d, p.r_max);    // feature-major first round of the re-score (encode_rescore.h)
     if (p.fm) {
       p.off_fmcount = take(((size_t)N + 64 + (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK) * 4);   // counts [N] | total | block sums
       p.off_fmtarget = take((size_t)T * 4);
@@ -537,7 +537,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const int nrp = next_pow2(pl.r_max + 1);
     const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
     int lrc;
-    if (pl.fm && msae_aligned(x, 16)) {   // (fm_dot_kernel reads x in 16-B pieces; the entry points ask 8 B of a 16-bit x)
+    // (fm_dot_kernel reads x in 16-B pieces; the entry points ask 8 B of a 16-bit x)
+    if (pl.fm && msae_aligned(x, 16) && fm_pays(T, k, N, d, DT == MSAE_F32 ? 4 : 2)) {
       int *fcount = reinterpret_cast<int *>(ws + pl.off_fmcount);
       int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
       float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);

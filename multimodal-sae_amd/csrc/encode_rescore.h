@@ -809,19 +809,29 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
   return 0;
 }
 
-// The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch -- ~1.36 k rows per token
-// over N features -- and because the activation rows it reads per pair instead come out of the Infinity Cache in the caller's
-// 16-bit type.  Measured at 8192 x 4096 x 131072 (profiles/r04_fm_rescore.txt): k = 256 (22 tokens per feature) 7.96 -> 4.56 ms,
-// k = 32 (2.7) 1.05 -> 0.85; from ~2 tokens per feature the counting sort and the second kernel are paid for.  MSAE_FM=0 / 1 forces it.
+// The feature-major first round pays when a row of W_enc is a candidate of several tokens of the batch -- m = ~1.36 k T / N tokens
+// per feature -- and because the activation rows it reads per pair instead come out of the Infinity Cache in the caller's own
+// type.  Cost model per (token, feature) pair, from profiles/r04_fm_rescore_probe.txt: token-major 4 d bytes of HBM at 6.2 TB/s;
+// feature-major (esize + 4 / m) d bytes over the fabric at 8 TB/s plus ~0.5 ns of counting sort, second kernel and a second
+// select kernel per pair.  Measured at 8192 x 4096 x 131072, bf16 x (profiles/r04_fm_rescore.txt): k = 256 (m = 22) 7.94 -> 4.55
+// ms, k = 32 (m = 2.7) 1.03 -> 0.82; small d (768: the pairs are cheap either way) and f32 activations at moderate m stay
+// token-major.  MSAE_FM=0 / 1 forces the route (where the shape allows it).
+inline bool fm_pays(int T, int k, int N, int d, int esize) {
+  static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
+  if (force >= 0) return force != 0;
+  const double m = 1.36 * (double)T * k / N;
+  if (m < 1.0) return false;
+  const double gain_ps = d * (4.0 / 6.2 - (esize + 4.0 / m) / 8.0);   // per pair
+  return gain_ps >= 500.0;
+}
 // lanes per feature group of fm_dot_kernel: 16 when a feature has >= ~12 pairs (k = 256 at 8192 tokens: 22), else 4
 inline int fm_group_lanes(int T, int k, int N) { return 1.36 * (double)T * k >= 12.0 * N ? 16 : 4; }
-inline bool fm_shape_ok(int T, int k, int N, int r_max) {
+// the plan's side (no activation type there: the workspace is sized for the 16-bit case, run_fast asks fm_pays() again)
+inline bool fm_shape_ok(int T, int k, int N, int d, int r_max) {
   int nw, lpr;
   rescore_shape(T, k, nw, lpr);
   if (lpr != 1 || r_max > 0xFFF || (long)T * r_max + (long)N * 16 >= (1L << 31)) return false;   // (fm_target's 12 bits)
-  static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
-  if (force >= 0) return force != 0;
-  return 1.36 * (double)T * k >= 2.0 * N;
+  return fm_pays(T, k, N, d, 2);
 }
 
 }  // namespace

@@ -371,8 +371,9 @@ def test_weight_stream_kernel_batches(dev, T, d):
         assert torch.equal(i, ei) and torch.equal(v, ev), (T, kw)
 
 
-@pytest.mark.parametrize("T,d,N,k,dtype", [(1536, 512, 8192, 32, torch.bfloat16), (1200, 1024, 8192, 128, torch.float16),
-                                           (2048, 256, 16384, 64, torch.float32), (1000, 512, 8192, 256, torch.bfloat16)])
+# (shapes the route's cost model accepts -- fm_pays(): rows long enough, and for f32 activations many tokens per feature)
+@pytest.mark.parametrize("T,d,N,k,dtype", [(1536, 2048, 8192, 32, torch.bfloat16), (1200, 2048, 8192, 128, torch.float16),
+                                           (2048, 4096, 8192, 128, torch.float32), (1000, 2048, 8192, 256, torch.bfloat16)])
 def test_feature_major_first_round_equals_exact_path(dev, coarse, T, d, N, k, dtype):
     """Batches in which a feature is a candidate of several tokens re-score their first round FEATURE-major (counting sort of the
     (token, feature) pairs, fm_dot_kernel reading the caller's x in its own type): the route is taken (bit 30 of
