@@ -63,6 +63,10 @@ class Cache:
         self._bitmaps: Dict[str, Tensor] = {}
         self.device_budget_bytes = device_budget_bytes
         self._pending, self._pending_bytes = [], 0
+        # groups of batches on their way to the host: (copy-done event, device buffers kept alive, pinned staging, layout)
+        self._inflight = []
+        self._copy_stream = None
+        self._staging = []                                # free pinned byte buffers, reused from group to group
 
     def _bitmap(self, module_path: str, num_latents: int, device) -> Optional[Tensor]:
         if self.filters is None:
@@ -86,16 +90,62 @@ class Cache:
         self._pending.append((module_path, loc, act, nnz))
         self._pending_bytes += loc.numel() * 8 + act.numel() * 4
         if self._pending_bytes >= self.device_budget_bytes:
-            self.flush_pending()
+            # this group starts its way to the host; the one before it (a whole budget's worth of batches ago) is finished
+            self._start_transfer()
+            self._drain(keep=1)
+
+    def _pinned(self, nbytes: int) -> Tensor:
+        for i, b in enumerate(self._staging):
+            if b.numel() >= nbytes:
+                return self._staging.pop(i)
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+
+    def _start_transfer(self):
+        """The pending batches' (worst-case sized) record buffers and counts go to PINNED host memory on a side stream, behind
+        an event of the compute stream: the host does not wait and keeps enqueueing encodes (a `.cpu()` per batch is a pageable,
+        blocking copy -- 470 MB per 64 batches of 8192 tokens stalled the loop for 9 % of its time)."""
+        group, self._pending, self._pending_bytes = self._pending, [], 0
+        dev = group[0][1].device
+        if self._copy_stream is None or self._copy_stream.device != dev:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        layout, off = [], 0
+        for (_, loc, act, _) in group:
+            lb, ab = loc.numel() * 8, act.numel() * 4
+            layout.append((off, lb, off + lb, ab))
+            off += (lb + ab + 15) // 16 * 16
+        counts_off = off
+        host = self._pinned(off + 4 * len(group))
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            for (_, loc, act, nnz), (lo, lb, ao, ab) in zip(group, layout):
+                host[lo:lo + lb].view(torch.int64).view(loc.shape).copy_(loc, non_blocking=True)
+                host[ao:ao + ab].view(torch.float32).view(act.shape).copy_(act, non_blocking=True)
+            host[counts_off:counts_off + 4 * len(group)].view(torch.int32).copy_(
+                torch.stack([p[3] for p in group]).to(torch.int32), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        self._inflight.append((done, group, host, layout, counts_off))
+
+    def _drain(self, keep: int = 0):
+        """Finish all but the `keep` most recent transfers: wait for the copy, slice the records out of the staging buffer
+        (into ordinary host tensors, batch order) and give the staging buffer back."""
+        while len(self._inflight) > keep:
+            done, group, host, layout, counts_off = self._inflight.pop(0)
+            done.synchronize()
+            counts = host[counts_off:counts_off + 4 * len(group)].view(torch.int32).tolist()
+            for (module_path, loc, act, _), (lo, lb, ao, ab), n in zip(group, layout, counts):
+                loc_h = host[lo:lo + lb].view(torch.int64).view(loc.shape)[:n].clone()
+                act_h = host[ao:ao + ab].view(torch.float32).view(act.shape)[:n].clone()
+                self._append(module_path, loc_h, act_h)
+            self._staging.append(host)
 
     def flush_pending(self):
-        """Move the batches collected on the device to host memory (ONE host synchronisation)."""
-        if not self._pending:
-            return
-        counts = torch.stack([p[3] for p in self._pending]).cpu().tolist()
-        for (module_path, loc, act, _), n in zip(self._pending, counts):
-            self._append(module_path, loc[:n].cpu(), act[:n].cpu())
-        self._pending, self._pending_bytes = [], 0
+        """Move every batch collected on the device to host memory (ONE host synchronisation)."""
+        if self._pending:
+            self._start_transfer()
+        self._drain(0)
 
     def _append(self, module_path: str, loc: Tensor, act: Tensor):
         if self.spill_dir is None:

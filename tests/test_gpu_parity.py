@@ -494,6 +494,33 @@ class _TinyLM(torch.nn.Module):
         return (self.model.layers["24"](self.embed(input_ids)),)
 
 
+def test_cache_flushes_through_pinned_staging_keep_order_and_contents(dev):
+    """Cache.add_topk's records leave the device in groups (`device_budget_bytes`), asynchronously, through pinned staging
+    buffers on a side stream: whatever the group size, `save()` yields the batches' records in batch order, equal to the
+    per-batch synchronous sparsify."""
+    from msae import ops
+    from msae.features.cache import Cache
+
+    N, k, B, S = 4096, 8, 4, 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    caches = [Cache(0, batch_size=B, device_budget_bytes=b) for b in (1, 1 << 16, 1 << 40)]
+    want_loc, want_act = [], []
+    for b in range(9):
+        acts = torch.rand(B, S, k, generator=g, device=dev)
+        acts[torch.rand(B, S, k, generator=g, device=dev) < 0.3] = 0.0        # dropped by the 1e-5 threshold
+        idx = torch.randint(0, N, (B, S, k), generator=g, device=dev)
+        for c in caches:
+            c.add_topk(acts, idx, N, b, "m")
+        loc, act = ops.sparsify(acts, idx, N, row_base=b * B, thresh=1e-5, sync=True)
+        want_loc.append(loc.cpu()); want_act.append(act.cpu())
+    want_loc, want_act = torch.cat(want_loc), torch.cat(want_act)
+    for c in caches:
+        c.save()
+        assert torch.equal(c.feature_locations["m"], want_loc)
+        assert torch.equal(c.feature_activations["m"], want_act)
+        assert not c._inflight and not c._pending
+
+
 def test_feature_cache_end_to_end_files(dev, golden_dir, tmp_path):
     """FeatureCache.run -> save_splits -> concate_safetensors reproduces the files the reference
     wrote for the same activations (fixture g4: names, locations, activations)."""
