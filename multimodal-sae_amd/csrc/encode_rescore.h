@@ -89,6 +89,47 @@ __device__ __forceinline__ void wave_sort_desc_u64_regs(unsigned long long (&v)[
     }
 }
 
+// ... and for 64 NW R keys by a WORKGROUP of NW waves: key i = tid * R + r sits in v[r] of thread tid.  Partners closer than R
+// are the thread's own registers, up to 32 R apart another lane's (shuffles), farther another wave's: those few steps
+// (3 of 66 for 2048 keys) go through `xch` (LDS, 64 NW R keys) behind barriers.  All threads call.
+template <int NW, int R>
+__device__ __forceinline__ void wg_sort_desc_u64_regs(unsigned long long (&v)[R], int tid, unsigned long long *xch) {
+  constexpr int M = 64 * NW * R;
+#pragma unroll
+  for (int size = 2; size <= M; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride < R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & stride) == 0) {
+            const bool desc = (((tid * R + r) & size) == 0);
+            const unsigned long long a = v[r], b = v[r | stride];
+            if ((a < b) == desc) { v[r] = b; v[r | stride] = a; }
+          }
+        }
+      } else {
+        const int pt = stride / R;                         // partner thread = tid ^ pt
+        const bool lower = (tid & pt) == 0;
+        if (pt >= 64) {
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < R; ++r) xch[tid * R + r] = v[r];
+          __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          unsigned long long o;
+          if (pt >= 64) o = xch[(tid ^ pt) * R + r];
+          else o = ((unsigned long long)__shfl_xor((unsigned)(v[r] >> 32), pt, 64) << 32) | __shfl_xor((unsigned)v[r], pt, 64);
+          const bool desc = (((tid * R + r) & size) == 0);
+          const bool take_max = lower == desc;
+          v[r] = take_max ? (v[r] > o ? v[r] : o) : (v[r] < o ? v[r] : o);
+        }
+      }
+    }
+}
+
 // number of keys (sorted descending, value in the upper 32 bits as an order key) whose value is >= v
 __device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, float v) {
   const unsigned tk = f32_order_key(v);
@@ -215,6 +256,20 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
     }
     if (presorted) { __syncthreads(); return; }
+    if constexpr (NW == 4 && !EXT) {
+      if (np <= 2048 && p.cap >= 2048) {                   // wave-uniform: 8 keys per thread, sorted in registers (keys[] = the exchange buffer: 2048 slots)
+        __syncthreads();
+        unsigned long long v8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] = lane * 8 + r < np ? keys[lane * 8 + r] : 0ull;
+        wg_sort_desc_u64_regs<4, 8>(v8, lane, keys);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) keys[lane * 8 + r] = v8[r];
+        __syncthreads();
+        return;
+      }
+    }
     wave_sort_desc_u64<NT>(keys, np, lane);
   };
   if constexpr (PHASE == 2 && NW == 1) {      // PHASE 1's preselected + sorted prefix, as it left it
@@ -477,6 +532,20 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
           unsigned long long v1[1] = {res[lane]};
           wave_sort_desc_u64_regs<1>(v1, lane);
           res[lane] = v1[0];
+          __syncthreads();
+        }
+      }
+      if constexpr (NW == 4) {
+        if (filled <= 1024 && nrp >= 1024) {                // wave-uniform: 4 keys per thread (k = 256: ~350 results)
+          in_regs = true;
+          __syncthreads();
+          unsigned long long v4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v4[r] = res[lane * 4 + r];
+          wg_sort_desc_u64_regs<4, 4>(v4, lane, res);
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[lane * 4 + r] = v4[r];
           __syncthreads();
         }
       }
