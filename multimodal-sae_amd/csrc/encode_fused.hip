@@ -543,7 +543,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
       float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);
       ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
-      ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max;
+      ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max; ra.fm_cand = cand;
       MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
       lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
       if (lrc) return lrc;

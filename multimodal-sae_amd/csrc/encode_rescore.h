@@ -28,6 +28,7 @@ struct RescoreArgs {
   // FEATURE-MAJOR first round (PHASE 1 / 2 of select_rescore_kernel, fm_* kernels below): per-feature pair counts [N + 1],
   // first-round size per token (| FM_SORTED), the first-round keys [T][fm_rcap], their exact pre-activations [T][fm_rcap]
   int *fm_count; int *fm_target; unsigned long long *fm_keys; const float *fm_pre; int fm_rcap;
+  unsigned long long *fm_cand;        // = cand, writable: PHASE 1 leaves a fully sorted list there for PHASE 2
 };
 // fm_target[t] = first-round size (12 bits) | sorted prefix saved in fm_keys (8 bits, PHASE 1's preselect) << 12 | FM_SORTED
 constexpr int FM_SORTED = 1 << 30;   // the token's whole list was written back to cand in sorted order
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       if (c < target) atomicAdd(p.fm_count + rank_key_index(key), 1);
     }
     if (!partial)
-      for (int i = lane; i < n; i += NT) const_cast<unsigned long long *>(p.cand)[(size_t)t * p.cap + i] = keys[i];
+      for (int i = lane; i < n; i += NT) p.fm_cand[(size_t)t * p.cap + i] = keys[i];
     if (lane == 0) p.fm_target[t] = target | (save << FM_PREFIX_SHIFT) | (partial ? 0 : FM_SORTED);
     return;
   }
