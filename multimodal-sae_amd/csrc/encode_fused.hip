@@ -544,13 +544,14 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);
       ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
       ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max; ra.fm_cand = cand;
+      ra.fm_rank = reinterpret_cast<int *>(fpre);
       MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
       lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
       if (lrc) return lrc;
       const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK, G = fm_group_lanes(T, k, N);
       hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64);
       hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64, pairs);
-      hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, pl.r_max, fcount, pairs);
+      hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, ra.fm_rank, pl.r_max, fcount, pairs);
       const long max_slots = (long)T * pl.r_max + (long)N * (G - 1);
       const dim3 dgrid((unsigned)((max_slots + 63) / 64));
       if (G == 16) hipLaunchKernelGGL((fm_dot_kernel<DT, 16>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);

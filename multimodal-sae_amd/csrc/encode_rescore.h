@@ -29,6 +29,7 @@ struct RescoreArgs {
   // first-round size per token (| FM_SORTED), the first-round keys [T][fm_rcap], their exact pre-activations [T][fm_rcap]
   int *fm_count; int *fm_target; unsigned long long *fm_keys; const float *fm_pre; int fm_rcap;
   unsigned long long *fm_cand;        // = cand, writable: PHASE 1 leaves a fully sorted list there for PHASE 2
+  int *fm_rank;                       // = fm_pre's storage: a pair's rank inside its feature, between PHASE 1 and the scatter
 };
 // fm_target[t] = first-round size (12 bits) | sorted prefix saved in fm_keys (8 bits, PHASE 1's preselect) << 12 | FM_SORTED
 constexpr int FM_SORTED = 1 << 30;   // the token's whole list was written back to cand in sorted order
@@ -400,7 +401,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     for (int c = lane; c < (target > save ? target : save); c += NT) {
       const unsigned long long key = keys[c];
       p.fm_keys[(size_t)t * p.fm_rcap + c] = key;
-      if (c < target) atomicAdd(p.fm_count + rank_key_index(key), 1);
+      // the count's old value is this pair's rank among its feature's pairs: the scatter needs no second atomic (the rank
+      // waits in the pair's slot of fm_pre, which fm_dot_kernel fills later)
+      if (c < target) p.fm_rank[(size_t)t * p.fm_rcap + c] = atomicAdd(p.fm_count + rank_key_index(key), 1);
     }
     if (!partial)
       for (int i = lane; i < n; i += NT) p.fm_cand[(size_t)t * p.cap + i] = keys[i];
@@ -648,14 +651,15 @@ __global__ __launch_bounds__(256) void fm_scan_kernel(int *__restrict__ counts, 
   }
   if (b == (int)gridDim.x - 1 && tid == 255) counts[N] = s_base + part[255];
 }
-// pair (t, c) -> its place among its feature's slots (any order inside a feature: the pairs are independent).
-// slots[pos] = (feature, t * rcap + c); starts[f] ends up behind the feature's last pair.
+// pair (t, c) -> its place among its feature's slots: the feature's start + the rank PHASE 1's counting atomic returned (any
+// order inside a feature: the pairs are independent).  slots[pos] = (feature, t * rcap + c).
 __global__ __launch_bounds__(256) void fm_scatter_kernel(const int *__restrict__ fm_target, const unsigned long long *__restrict__ fm_keys,
-                                                         int rcap, int *__restrict__ starts, int2 *__restrict__ slots) {
+                                                         const int *__restrict__ fm_rank, int rcap, const int *__restrict__ starts,
+                                                         int2 *__restrict__ slots) {
   const int t = blockIdx.x, target = fm_target[t] & FM_TARGET_MASK;
   for (int c = threadIdx.x; c < target; c += 256) {
     const int f = rank_key_index(fm_keys[(size_t)t * rcap + c]);
-    slots[atomicAdd(starts + f, 1)] = make_int2(f, t * rcap + c);
+    slots[starts[f] + fm_rank[(size_t)t * rcap + c]] = make_int2(f, t * rcap + c);
   }
 }
 // acc = fma(a, w of lane SH of this lane's group, acc): ONE v_fmac_f32 (fused) with the DPP source modifier on w.  Written as
