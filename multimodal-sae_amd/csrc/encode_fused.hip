@@ -132,7 +132,7 @@ inline void prof_step(ProfState *pf) {
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
   bool fast, i8, small, fm;
-  size_t off_fmcount, off_fmtarget, off_fmkeys, off_fmpairs, off_fmpre;
+  size_t off_fmcount, off_fmtarget, off_fmkeys, off_fmpairs, off_fmpre, off_fmdefer;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
@@ -211,6 +211,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_fmkeys = take((size_t)T * p.r_max * 8);
       p.off_fmpairs = take(((size_t)T * p.r_max + (size_t)N * 16) * 8);   // slots: the pairs + every feature's padding to whole groups
       p.off_fmpre = take((size_t)T * p.r_max * 4);
+      p.off_fmdefer = take((size_t)T * 2 * 4);              // tokens the LEAN launch of PHASE 1 / 2 left to the full-size one
     }
   } else {
     p.off_dense = take((size_t)T * N * 4);
@@ -545,6 +546,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
       ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max; ra.fm_cand = cand;
       ra.fm_rank = reinterpret_cast<int *>(fpre);
+      ra.fm_defer = reinterpret_cast<int *>(ws + pl.off_fmdefer);
+      MSAE_HIP_TRY(hipMemsetAsync(ra.fm_defer, 0, (size_t)T * 2 * 4, s));
       MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
       lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
       if (lrc) return lrc;

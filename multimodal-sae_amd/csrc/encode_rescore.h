@@ -30,6 +30,9 @@ struct RescoreArgs {
   int *fm_count; int *fm_target; unsigned long long *fm_keys; const float *fm_pre; int fm_rcap;
   unsigned long long *fm_cand;        // = cand, writable: PHASE 1 leaves a fully sorted list there for PHASE 2
   int *fm_rank;                       // = fm_pre's storage: a pair's rank inside its feature, between PHASE 1 and the scatter
+  // LEAN / full pairs of PHASE kernels: fm_defer[(PHASE - 1) * T + t] != 0 <=> the LEAN launch left token t to the full one;
+  // fm_all != 0: this (full) launch takes every token (no LEAN launch ran for the phase)
+  int *fm_defer; int fm_all;
 };
 // fm_target[t] = first-round size (12 bits) | sorted prefix saved in fm_keys (8 bits, PHASE 1's preselect) << 12 | FM_SORTED
 constexpr int FM_SORTED = 1 << 30;   // the token's whole list was written back to cand in sorted order
@@ -174,13 +177,21 @@ __device__ __forceinline__ int count_ge(const unsigned long long *keys, int n, f
 // stops behind the choice of the first round and hands its (token, feature) pairs to a counting sort by feature; fm_dot_kernel
 // computes the same exact chains feature-major (W_enc once, the activations out of the Infinity Cache); PHASE 2 picks the
 // values up as its first round and continues as PHASE 0 does (verification, follow-up rounds token-major: a handful of rows).
-template <int NW, bool EXT = false, bool LDSA = false, int PHASE = 0>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
+// LEAN (PHASE 1 / 2): the PHASE kernels are chains of dependent steps of one lone workgroup per token, i.e. latency; how many
+// tokens a CU works on at a time is set by the LDS a workgroup claims, and that is sized for the worst token (the whole list:
+// 16-32 KB) although nearly every token is done with a sorted prefix of 128-512 keys.  A LEAN launch claims the prefix only
+// (6 KB at k = 32: 28 tokens per CU instead of 4-7) and LEAVES a token to the full-size launch behind it -- before any side
+// effect -- the moment it would need the whole list (a full sort, a candidate behind the prefix) or a follow-up round.
+template <int NW, bool EXT = false, bool LDSA = false, int PHASE = 0, bool LEAN = false>   // NW waves per token: 1 for k <= 64, 4 for larger k (longer lists)
 __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, const float *__restrict__ a32,
                                                             const float *__restrict__ W_enc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
   const int nrp = next_pow2(p.r_max + 1);
-  unsigned long long *res = keys + p.cap;
+  static_assert(!LEAN || (PHASE != 0 && !EXT && !LDSA), "LEAN: the PHASE kernels of the single-GPU path");
+  constexpr int LEAN_KEYS = NW == 1 ? 256 : 512;      // key slots of a LEAN launch
+  const int kcap = LEAN ? LEAN_KEYS : p.cap;
+  unsigned long long *res = keys + kcap;
   [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
   [[maybe_unused]] int *ef = reinterpret_cast<int *>(ezs + p.cap);        // EXT only: [cap] global feature by position
   [[maybe_unused]] float *a_lds = EXT ? reinterpret_cast<float *>(ef + p.cap) : ezs;   // LDSA only: [d]
@@ -191,6 +202,17 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   const int lane = threadIdx.x;   // thread index within the token's workgroup
   const int t = blockIdx.x;
   if constexpr (EXT) { if (t >= p.ext_valid) return; }
+  if constexpr (PHASE != 0 && !LEAN) { if (!p.fm_all && p.fm_defer[(size_t)(PHASE - 1) * p.T + t] == 0) return; }   // the LEAN launch did it
+  [[maybe_unused]] bool deferred = false;             // LEAN: this token needs the full-size launch (wave-uniform)
+#define MSAE_LEAN_BAIL()                                                                   \
+  do {                                                                                     \
+    if constexpr (LEAN) {                                                                  \
+      if (deferred) {                                                                      \
+        if (lane == 0) p.fm_defer[(size_t)(PHASE - 1) * p.T + t] = 1;                      \
+        return;                                                                            \
+      }                                                                                    \
+    }                                                                                      \
+  } while (0)
   int cnt, n;
   float tau;
   MSAE_RTL(0);
@@ -252,7 +274,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   bool partial = false;
   bool presorted = false;                      // PHASE 2: PHASE 1 left the list sorted in place
   if constexpr (PHASE == 2) presorted = (p.fm_target[t] & FM_SORTED) != 0;
+  bool have_keys = false;                      // keys[0, n_sorted) already hold a sorted prefix of the list
   auto full_sort = [&]() {
+    if constexpr (LEAN) { if (np > LEAN_KEYS) { deferred = true; return; } }
     if constexpr (!EXT) {
       __syncthreads();
       for (int i = lane; i < np; i += NT) keys[i] = (i < n) ? p.cand[(size_t)t * p.cap + i] : 0ull;
@@ -281,6 +305,16 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
       __syncthreads();
       partial = true;
       n_sorted = saved;
+      have_keys = true;
+    }
+  }
+  if constexpr (PHASE == 2 && LEAN) {          // ... or the first LEAN_KEYS of the list PHASE 1 sorted in place
+    if (presorted && n > LEAN_KEYS) {
+      for (int i = lane; i < LEAN_KEYS; i += NT) keys[i] = p.cand[(size_t)t * p.cap + i];
+      __syncthreads();
+      partial = true;
+      n_sorted = LEAN_KEYS;
+      have_keys = true;
     }
   }
   if constexpr (!EXT && NW == 1) {
@@ -332,14 +366,19 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
         }
         partial = true;
         n_sorted = c_sel;
+        have_keys = true;
       }
     }
   }
-  if (!partial) full_sort();
-  auto need_full = [&]() { full_sort(); partial = false; n_sorted = n; };
+  if (!have_keys) full_sort();
+  MSAE_LEAN_BAIL();
+  auto need_full = [&]() {
+    if constexpr (LEAN) { deferred = true; return; }
+    full_sort(); partial = false; n_sorted = n;
+  };
   auto count_needed = [&](float v) {         // candidates with u >= v (over the whole list)
     int c = count_ge(keys, n_sorted, v);
-    if (partial && c >= n_sorted) { need_full(); c = count_ge(keys, n, v); }
+    if (partial && c >= n_sorted) { need_full(); if (!deferred) c = count_ge(keys, n, v); }
     return c;
   };
   MSAE_RTL(2);
@@ -380,6 +419,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     if (kk >= 1 && kk <= mt && p.z2 > 0.f) {
       const float thr1 = s_pick[0] - GUARD_ZETA * s_pick[1] * __builtin_amdgcn_rsqf(p.z2);
       int n1 = count_needed(thr1);
+      MSAE_LEAN_BAIL();
       if (n1 < p.k + 4) n1 = p.k + 4;
       target = n1 < lim ? n1 : lim;
     }
@@ -396,6 +436,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   if (guarded) target = 0;                       // (no row is read for it here)
   if constexpr (PHASE == 1) {
     if (partial && target > n_sorted) need_full();          // wave-uniform
+    MSAE_LEAN_BAIL();
     // the first round's keys (the counting sort reads them), and behind them the rest of a preselected prefix for PHASE 2
     const int save = partial && n_sorted <= p.fm_rcap && n_sorted <= FM_PREFIX_MASK ? n_sorted : 0;
     for (int c = lane; c < (target > save ? target : save); c += NT) {
@@ -496,6 +537,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     // The first round of a SMALL batch (too few tokens to fill the chip with a lane per row) does the same with
     // p.lpr lanes per row and as many waves per token.
     if (partial && target > n_sorted) need_full();          // wave-uniform
+    MSAE_LEAN_BAIL();
     bool from_fm = false;
     if constexpr (PHASE == 2) {
       if (rounds == 1) {                                     // the first round's values: fm_dot_kernel computed them
@@ -559,8 +601,10 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     const bool have_k = done + has_set >= p.k;
     const float v_k = f32_from_order_key((unsigned)(res[p.k - 1] >> 32));
     const int needed = have_k ? count_needed(v_k) : n;          // candidates with u >= v_k
+    MSAE_LEAN_BAIL();
     ok = (cnt <= p.cap) && (tau > 0.f) && have_k && !viol && needed <= done && v_k > tau * 1.000001f && !guarded;
     if (ok || viol || guarded || done >= lim || !(tau > 0.f) || cnt > p.cap) break;
+    if constexpr (LEAN) { deferred = true; MSAE_LEAN_BAIL(); }   // a follow-up round: the full-size launch (rows token-major, activations in LDS)
     target = needed > done ? needed : done + 1;
     if (target > lim) target = lim;
     __syncthreads();
@@ -591,6 +635,8 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     }
   }
 }
+
+#undef MSAE_LEAN_BAIL
 
 // ---- feature-major first round -------------------------------------------------------------------
 // The pairs of a feature occupy whole GROUPS of G lanes (G = 4 or 16: fm_group_lanes) of fm_dot_kernel's waves, so a feature's
@@ -868,7 +914,22 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                            \
     hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, LDSAV, PH>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc);  \
   } while (0)
+#define MSAE_RS_LAUNCH_L(NWV, PH)                                                                                       \
+  do {                                                                                                                   \
+    MSAE_HIP_TRY(hipFuncSetAttribute((const void *)select_rescore_kernel<NWV, EXT, false, PH, true>,                     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                            \
+    hipLaunchKernelGGL((select_rescore_kernel<NWV, EXT, false, PH, true>), dim3(T), dim3(64 * NWV), smem, s, ra, a32, W_enc); \
+  } while (0)
   if constexpr (PHASE != 0) {                 // feature-major first round: large batches only (fm_shape_ok: a lane per row)
+    // a LEAN launch (prefix-sized LDS) in front of the full-size one, which then takes the tokens the LEAN one left to it
+    const size_t full = smem, lean = full - (size_t)ra.cap * 8 + (size_t)(nw == 1 ? 256 : 512) * 8;
+    const bool has_lean = ra.fm_defer != nullptr && (nw == 1 || PHASE == 2) && lean < full;
+    ra.fm_all = has_lean ? 0 : 1;
+    if (has_lean) {
+      smem = lean;
+      if (nw == 1) MSAE_RS_LAUNCH_L(1, PHASE); else MSAE_RS_LAUNCH_L(4, PHASE);
+      smem = full;
+    }
     const bool lds2 = PHASE == 2 && nw == 1 && smem + (size_t)ra.d * 4 <= 64 * 1024;   // follow-up rounds: activations in LDS
     if (lds2) { smem += (size_t)ra.d * 4; MSAE_RS_LAUNCH(1, true, PHASE); }
     else if (nw == 1) MSAE_RS_LAUNCH(1, false, PHASE);
@@ -880,6 +941,7 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
     else MSAE_RS_LAUNCH(4, false, 0);
   }
 #undef MSAE_RS_LAUNCH
+#undef MSAE_RS_LAUNCH_L
   return 0;
 }
 
