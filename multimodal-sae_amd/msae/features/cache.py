@@ -66,7 +66,6 @@ class Cache:
         # groups of batches on their way to the host: (copy-done event, device buffers kept alive, pinned staging, layout)
         self._inflight = []
         self._copy_stream = None
-        self._staging = []                                # free pinned byte buffers, reused from group to group
 
     def _bitmap(self, module_path: str, num_latents: int, device) -> Optional[Tensor]:
         if self.filters is None:
@@ -94,10 +93,15 @@ class Cache:
             self._start_transfer()
             self._drain(keep=1)
 
+    # free pinned byte buffers, reused from group to group and from Cache to Cache (pinning a few hundred MB takes tens of
+    # milliseconds: a pool per instance paid it again for every run)
+    _staging: list = []
+
     def _pinned(self, nbytes: int) -> Tensor:
-        for i, b in enumerate(self._staging):
+        pool = Cache._staging
+        for i, b in enumerate(pool):
             if b.numel() >= nbytes:
-                return self._staging.pop(i)
+                return pool.pop(i)
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
 
     def _start_transfer(self):
@@ -139,7 +143,7 @@ class Cache:
                 loc_h = host[lo:lo + lb].view(torch.int64).view(loc.shape)[:n].clone()
                 act_h = host[ao:ao + ab].view(torch.float32).view(act.shape)[:n].clone()
                 self._append(module_path, loc_h, act_h)
-            self._staging.append(host)
+            Cache._staging.append(host)
 
     def flush_pending(self):
         """Move every batch collected on the device to host memory (ONE host synchronisation)."""
