@@ -189,7 +189,9 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
   const int nrp = next_pow2(p.r_max + 1);
   static_assert(!LEAN || (PHASE != 0 && !EXT && !LDSA), "LEAN: the PHASE kernels of the single-GPU path");
-  constexpr int LEAN_KEYS = NW == 1 ? 256 : 512;      // key slots of a LEAN launch
+  // key slots of a LEAN launch (the 4-wave PHASE 1 sorts whole lists of up to 2048 keys in registers and needs the slots as
+  // its exchange buffer only; PHASE 1 has no results: no res[] behind the keys)
+  constexpr int LEAN_KEYS = NW == 1 ? 256 : (PHASE == 1 ? 2048 : 512);
   const int kcap = LEAN ? LEAN_KEYS : p.cap;
   unsigned long long *res = keys + kcap;
   [[maybe_unused]] float *ezs = reinterpret_cast<float *>(res + nrp);     // EXT only: [cap] z sigma by list position
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     rc = p.rowc[t];
     np = next_pow2(n > 2 ? n : 2);
   }
-  for (int i = lane; i < nrp; i += NT) res[i] = 0ull;
+  if constexpr (PHASE != 1) { for (int i = lane; i < nrp; i += NT) res[i] = 0ull; }
   MSAE_RTL(1);
   // keys[0, n_sorted) hold the n_sorted largest keys in descending order (upper value desc, index asc on ties).
   // PARTIAL: of a list of ~650 candidates a token uses the first 40-60, so one wave first SELECTS its PRE_LO..PRE_HI
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     }
     if (presorted) { __syncthreads(); return; }
     if constexpr (NW == 4 && !EXT) {
-      if (np <= 2048 && p.cap >= 2048) {                   // wave-uniform: 8 keys per thread, sorted in registers (keys[] = the exchange buffer: 2048 slots)
+      if (np <= 2048 && kcap >= 2048) {                    // wave-uniform: 8 keys per thread, sorted in registers (keys[] = the exchange buffer: 2048 slots)
         __syncthreads();
         unsigned long long v8[8];
 #pragma unroll
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   };
   MSAE_RTL(2);
   const int has_set = p.set_feature >= 0 ? 1 : 0;
-  if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature);
+  if constexpr (PHASE != 1) { if (lane == 0 && has_set) res[0] = rank_key(p.set_value, p.set_feature); }
 
   // ---- size of the first round ------------------------------------------------------------------
   const int lim = n < p.r_max ? n : p.r_max;
@@ -901,6 +903,8 @@ inline void rescore_shape(int T, int k, int &nw, int &lpr) {
     nw = lpr;
   }
 }
+// bytes of the results array behind the keys in select_rescore_kernel's dynamic LDS (smem = (cap + nrp) * 8 + 64)
+inline size_t full_minus_keys(size_t smem, int cap) { return smem - 64 - (size_t)cap * 8; }
 template <bool EXT, int PHASE = 0>
 inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, const float *a32, const float *W_enc,
                                  hipStream_t s) {
@@ -922,8 +926,9 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
   } while (0)
   if constexpr (PHASE != 0) {                 // feature-major first round: large batches only (fm_shape_ok: a lane per row)
     // a LEAN launch (prefix-sized LDS) in front of the full-size one, which then takes the tokens the LEAN one left to it
-    const size_t full = smem, lean = full - (size_t)ra.cap * 8 + (size_t)(nw == 1 ? 256 : 512) * 8;
-    const bool has_lean = ra.fm_defer != nullptr && (nw == 1 || PHASE == 2) && lean < full;
+    const size_t nres = PHASE == 1 ? 0 : full_minus_keys(smem, ra.cap);           // PHASE 1 has no results
+    const size_t full = smem, lean = (size_t)(nw == 1 ? 256 : (PHASE == 1 ? 2048 : 512)) * 8 + nres + 64;
+    const bool has_lean = ra.fm_defer != nullptr && lean < full && (nw == 1 || PHASE == 2 || ra.cap >= 2048);
     ra.fm_all = has_lean ? 0 : 1;
     if (has_lean) {
       smem = lean;
