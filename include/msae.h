@@ -159,7 +159,9 @@ int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *prepared, i
  * threshold <= 0, 16 fewer than k candidates, 32 too many rows inside the band, 64 a re-scored pair
  * was more than 6 sigma from its coarse value: the error model does not describe this token, 128 the token's
  * shape is outside the model by a deterministic test -- the dims its int8 scale rounds to zero carry more than 4
- * bands of energy). */
+ * bands of energy).
+ * Alignment: x 16 bytes for f32, 8 bytes for the 16-bit types; large batches of a 16-BYTE-aligned x additionally take the
+ * feature-major route of the exact re-score (rows_rescored bit 30; same results, less time) -- torch allocations are. */
 size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts);
 int msae_encode_topk(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                      const float *b_dec, const void *prepared, int T, int d, int N, int k,
