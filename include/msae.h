@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MSAE_ABI_VERSION 3
+#define MSAE_ABI_VERSION 4
 
 /* element type of the activation tensor x handed over by the LLM hook (sae.py:174 up-casts) */
 enum { MSAE_F32 = 0, MSAE_BF16 = 1, MSAE_F16 = 2 };
@@ -92,17 +92,40 @@ enum {
  *                 returns status 0 with that feature missing (tests/test_gpu_hostile.py::test_row_aligned_with_a_
  *                 token_s_rounding_residual pins exactly this; the bf16 pass, whose residuals are relative roundings of
  *                 other bits, and exact = 1 return the right answer).  Trained weights cannot know a future token's
- *                 residual; weights under an adversary's control can.  Slower by ~20x on large batches. */
+ *                 residual; weights under an adversary's control can.  Slower by ~20x on large batches.
+ *                 (That paragraph describes dither = MSAE_DITHER_OFF, the behaviour of ABI <= 3.  With the dither -- the
+ *                 default since ABI 4 -- the same row is found: see `dither`.)
+ *   dither        (ABI 4; the word ABI 3 called `reserved`) MSAE_DITHER_DEFAULT (0: environment MSAE_DITHER=0|1, else ON),
+ *                 MSAE_DITHER_ON, MSAE_DITHER_OFF.  ON: the int8 operands are rounded STOCHASTICALLY -- q = floor(v / step + r),
+ *                 r uniform in [0, 1) from a counter hash of (seed, token or row, dim) -- instead of to nearest: the
+ *                 activations with a fresh seed in every encode call, the weights with a fresh seed in every prepare /
+ *                 refresh.  The rounding residuals are then the LIBRARY's randomness, not a property of the data: for EVERY
+ *                 input (chosen without knowledge of the seeds) the error of a coarse value is a sum of independent,
+ *                 zero-mean terms bounded by one step each, so by Hoeffding's inequality it exceeds z sigma' with
+ *                 probability <= exp(-z^2 / 2), sigma'^2 = sw_n^2 |a_t|^2 / 4 + sx_t^2 (|W_n[in]|^2 + m_t^2 |W_n[out]|^2) / 4
+ *                 (the variance PROXY of a bounded term, 3x the variance of round-to-nearest on fine data; the band the
+ *                 kernels use).  A member of the true top-k is therefore missed with probability <= k exp(-z^2 / 2) per token
+ *                 -- 7.3e-10 at z = 7, k = 32; 4e-13 at guard_z = 8 -- whatever the weights and activations are, including
+ *                 rows built from a token's round-to-nearest residual (the pinned test now asserts the RIGHT answer).
+ *                 Outputs of verified tokens do not depend on the seeds (they are the exact path's bits); which tokens fall
+ *                 back may.  Costs ~sqrt(3) of band width: measured rows re-scored per token and step time in DESIGN.md
+ *                 section 5.  Applies to the int8 pass (all batch sizes); the bf16 pass keeps its statistical model.
+ *   dither_seed   (ABI 4) 0: the library draws a seed per call (process-random base + atomic counter through a 64-bit
+ *                 mixer -- the one piece of process state the library keeps); != 0: the seed of THIS call (reproducible
+ *                 candidate sets: tests, A/B runs). */
 enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1 };
+enum { MSAE_DITHER_DEFAULT = 0, MSAE_DITHER_ON = 1, MSAE_DITHER_OFF = 2 };
 typedef struct msae_options {
-  uint32_t size;          /* sizeof(msae_options) of the caller's header (ABI 2's 24-byte struct is accepted: exact = 0) */
+  uint32_t size;          /* sizeof(msae_options) of the caller's header (ABI 2's 24-byte and ABI 3's 40-byte structs are
+                             accepted: exact = 0 / dither_seed = 0) */
   int32_t coarse_mode;    /* MSAE_COARSE_* */
   float guard_z;          /* 0 = default */
   int32_t status_detail;  /* 0 / 1 */
   void *profile;          /* msae_profile_create handle or NULL */
   int32_t exact;          /* 0 / 1 */
-  int32_t reserved;       /* 0 */
+  int32_t dither;         /* MSAE_DITHER_* (ABI 3: reserved, 0) */
   int32_t *rows_rescored; /* device int32[T] or NULL */
+  uint64_t dither_seed;   /* 0 = drawn by the library */
 } msae_options;
 /* Fills *opts with the defaults (coarse_mode MSAE_COARSE_DEFAULT, guard_z 0, no detail, no profile). */
 void msae_options_init(msae_options *opts);
@@ -133,6 +156,10 @@ int msae_topk_f32(const float *latents, int T, int N, int k, float *vals, int32_
  * msae_encoder_prepared_bytes(N, d) bytes and stay valid while the encoder is used. */
 size_t msae_encoder_prepared_bytes(int N, int d);
 int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream);
+/* The same with options (ABI 4): `dither` / `dither_seed` choose how the int8 operands are rounded (msae_options above;
+ * msae_encoder_prepare = NULL options = the defaults: dithered with a drawn seed).  Two prepares with the same non-zero seed
+ * build identical operands. */
+int msae_encoder_prepare_opts(const float *W_enc, int N, int d, void *prepared, const msae_options *opts, void *stream);
 /* Same buffer after a weight update (one training step): rebuilds only the operands that the coarse
  * mode of `opts` reads -- the other mode's operands go stale, so call msae_encoder_prepare again before
  * encoding in the other mode. */

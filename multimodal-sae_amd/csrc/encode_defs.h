@@ -1,8 +1,10 @@
 // encode_defs.h -- constants, the prepared-encoder layout, per-call options and the error-band arithmetic shared by the kernels
 // of the fused encoder (encode_prep.h, encode_rescore.h, encode_small.h) and its host dispatch (encode_fused.hip).
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
+#include <random>
 
 #include "common.h"
 #include "tuning.h"
@@ -93,17 +95,47 @@ struct CallOpts {
   ProfState *prof;   // stage timing handle or null
   int exact;         // every token by the exact path (msae_options::exact)
   int32_t *rows_out; // per-token re-score statistics (msae_options::rows_rescored) or null
+  // Stochastic rounding of the int8 operands (msae_options::dither): seed != 0 <=> on.  The seed of THIS call: the caller's, or
+  // drawn here (draw_seed) -- activations are rounded with it in an encode, the weights in a prepare / refresh.
+  unsigned long long seed;
 };
+// 64-bit finaliser of splitmix64 (also the device-side hash of the dither, encode_prep.h)
+__host__ __device__ inline unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// A fresh non-zero seed: process-random base (std::random_device at first use) + an atomic counter, mixed.  The only
+// mutable process state of the library -- it is a random number generator.
+inline unsigned long long draw_seed() {
+  static const unsigned long long base = [] {
+    std::random_device rd;
+    return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ 0x6D736165ull;
+  }();
+  static std::atomic<unsigned long long> counter{0};
+  const unsigned long long v = mix64(base + 0x9E3779B97F4A7C15ull * (counter.fetch_add(1, std::memory_order_relaxed) + 1ull));
+  return v ? v : 1ull;
+}
 inline bool resolve_opts(const msae_options *o, CallOpts &c) {
-  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr; c.exact = 0; c.rows_out = nullptr;
+  c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr; c.exact = 0; c.rows_out = nullptr; c.seed = 0ull;
+  int dither = 0;
   if (o) {
     // `size` is the caller's sizeof: a caller compiled against ABI 2's header (no `exact`) is served with exact = 0
     if (o->size < offsetof(msae_options, exact)) return false;
     c.mode = o->coarse_mode; c.z = o->guard_z; c.detail = o->status_detail ? 1 : 0;
     c.prof = static_cast<ProfState *>(o->profile);
     if (o->size >= offsetof(msae_options, exact) + sizeof(int32_t)) c.exact = o->exact ? 1 : 0;
+    if (o->size >= offsetof(msae_options, dither) + sizeof(int32_t)) dither = o->dither;
     if (o->size >= offsetof(msae_options, rows_rescored) + sizeof(void *)) c.rows_out = o->rows_rescored;
+    if (o->size >= offsetof(msae_options, dither_seed) + sizeof(uint64_t)) c.seed = o->dither_seed;
   }
+  if (dither < 0 || dither > 2) return false;
+  if (dither == 0) {
+    const char *e = getenv("MSAE_DITHER");
+    dither = (e && e[0] == '0') ? 2 : 1;
+  }
+  if (dither == 2) c.seed = 0ull;
+  else if (c.seed == 0ull) c.seed = draw_seed();
   if (c.mode < 0) {
     const char *e = getenv("MSAE_COARSE");
     c.mode = (e && e[0] == 'b') ? 0 : 1;
@@ -129,6 +161,11 @@ constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this 
 // 0.25 with the zeroed part to leave its band) are not trusted to the statistical model: they are flagged (reason 128)
 // and recomputed by the exact path inside the call.  The test does not move with msae_options::guard_z.
 constexpr float GUARD_E0_SX = 4.f * 7.f * 0.288675f;   // 4 bands of z = 7: 8.08
+// x-side variance of one rounding in the band, in steps^2: 1/12 (round to nearest, the statistical model) or, under the dither,
+// Hoeffding's variance proxy of a zero-mean term bounded by one step, 1/4 -- times 1.001, which covers the 2^-25 granularity of
+// the hash's uniform (a bias of <= 2^-25 step per dim) and the float rounding of v / step at the clamp.  The W side carries the
+// same factor inside Q_n (row_stats_quant_row).
+__host__ __device__ inline float x_round_var(bool dither) { return dither ? 0.25f * 1.001f : 1.f / 12.f; }
 constexpr float GUARD_ZETA = MSAE_GUARD_ZETA;   // first round reaches zeta sigma below the k-th coarse value
 constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
 
@@ -136,13 +173,28 @@ constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative
 struct IdxOut { int32_t *i32; int64_t *i64; };
 
 // z^2 sigma^2 of one (token, feature) pair; rc = (sx, m, P, -), cc = (sw, Q, Si, So).  Same expression as the
-// GEMM epilogue (gemm_mfma.h).
+// GEMM epilogue (gemm_mfma.h).  zz12 = z^2 x the x-side variance of one rounding (x_round_var: 1/12, or 1/4 under the dither);
+// the W side's is inside P_t Q_n (P = z^2 |a|^2 / 12, Q = sw^2 or 3 sw^2).
 __device__ __forceinline__ float band_sq(const f32x4 rc, const f32x4 cc, float zz12, bool i8) {
   if (!i8) return rc[2] * cc[1];
   const float rz = rc[0] * rc[0] * zz12;
   return __builtin_fmaf(rc[2], cc[1], __builtin_fmaf(rz * rc[1] * rc[1], cc[3], rz * cc[2]));
 }
 
+// Dither of the activations (quant_x_kernel, prep_small_kernel): one 32-bit hash per element, keyed per token.
+//   key  = low word of mix64(seed + golden * (t + 1))      (once per thread and token)
+//   r(c) = (lowbias32(key ^ c * 0x9E3779B9) >> 8 + 0.5) * 2^-24   in (0, 1)
+// Independence is needed across the dims of ONE token only (the Hoeffding sum of a (token, feature) pair runs over c).
+__device__ __forceinline__ unsigned dither_key(unsigned long long seed, unsigned t) {
+  return (unsigned)mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1u));
+}
+__device__ __forceinline__ float dither01(unsigned key, unsigned c) {
+  unsigned h = key ^ (c * 0x9E3779B9u);
+  h ^= h >> 16; h *= 0x7FEB352Du;
+  h ^= h >> 15; h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return ((float)(h >> 8) + 0.5f) * (1.f / 16777216.f);
+}
 // ---- per-row statistics + int8 operands ---------------------------------------------------------------
 // Tile-major int8 operand of the candidate GEMM (GemmOperands::packed): byte offset of the 16-B chunk at column c
 // (c % 16 == 0) of row r, with the LDS image's chunk permutation applied (gemm_swz).  d % 128 == 0.

@@ -268,7 +268,8 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
               const unsigned char *prepared, int T, int d, int N, int k, int set_feature, float set_value,
               int zero_feature, float *vals, IdxOut idx, int32_t *status, unsigned char *ws, const FusedPlan &pl,
               const CallOpts &co, hipStream_t s) {
-  const float z = co.z, zz12 = z * z / 12.f;
+  // zz12: z^2 x the W-side variance of one rounding inside P_t (the dither's factor 3 is in Q_n); zzx: ... of the x side
+  const float z = co.z, zz12 = z * z / 12.f, zzx = z * z * x_round_var(co.seed != 0ull);
   float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
   signed char *xhi = reinterpret_cast<signed char *>(ws + pl.off_xhi);
   signed char *xlo = reinterpret_cast<signed char *>(ws + pl.off_xlo);
@@ -290,14 +291,14 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   const unsigned *valid = reinterpret_cast<const unsigned *>(prepared + offsetof(Prepared, valid));
   const unsigned need = (T > dot4_max_small() && d <= 4096) ? (PREP_I8 | PREP_FRAG) : PREP_I8;
   hipLaunchKernelGGL(prep_small_kernel<DT>, dim3(T), dim3(256), 0, s, x, b_dec, d, a32, xhi, xlo, rowc, zz12, viol, 2 * T,
-                     flagged, T + 64 + pl.fb_chunks, valid, need, T);
+                     flagged, T + 64 + pl.fb_chunks, valid, need, T, co.seed);
   prof_mark(co.prof, 1, s);
   prof_mark(co.prof, 2, s);
   prof_mark(co.prof, 3, s);
   const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
 #define MSAE_GEMV(DSEG, TT)                                                                                        \
   hipLaunchKernelGGL((gemv_small_kernel<DSEG, TT>), dim3(SMALL_GRID), dim3(256), 0, s, wq, wstat, b_enc, N, T, xhi, xlo, \
-                     rowc, zz12, skip_a, skip_b, surv, bound)
+                     rowc, zzx, skip_a, skip_b, surv, bound)
   const int dseg = d / 1024;
   int n_surv = SMALL_SURV, n_bound = SMALL_GRID;
   const int dot4_max = dot4_max_small();
@@ -315,7 +316,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
     MSAE_HIP_TRY(hipFuncSetAttribute((const void *)gemv_mfma_kernel<DSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                      (int)smem_m));                                                                \
     hipLaunchKernelGGL(gemv_mfma_kernel<DSEG>, dim3(grid_m), dim3(512), smem_m, s, wqf, wqsf, wstat, b_enc, N, T, xhi, xlo, rowc, \
-                       zz12, skip_a, skip_b, surv, bound);                                                         \
+                       zzx, skip_a, skip_b, surv, bound);                                                          \
   } while (0)
     switch (dseg) { case 1: MSAE_GEMV_M(1); break; case 2: MSAE_GEMV_M(2); break; case 4: MSAE_GEMV_M(4); break;
                     default: return MSAE_ENOTIMPL; }
@@ -335,7 +336,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   prof_mark(co.prof, 4, s);
 #define MSAE_RESCORE(DSEG)                                                                                         \
   hipLaunchKernelGGL(rescore_small_kernel<DSEG>, dim3(SMALL_RMAX, T), dim3(64), 0, s, a32, W_enc, b_enc, k, cand, tau, wstat, \
-                     rowc, zz12, z * z, set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
+                     rowc, zzx, z * z, set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
   switch (dseg) { case 1: MSAE_RESCORE(1); break; case 2: MSAE_RESCORE(2); break; case 4: MSAE_RESCORE(4); break;
                   case 8: MSAE_RESCORE(8); break; default: return MSAE_ENOTIMPL; }
 #undef MSAE_RESCORE
@@ -378,7 +379,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
   GemmOperands op_main{}, op_samp{};
-  const float z = co.z, zz12 = z * z / 12.f;
+  const float z = co.z, zz12 = z * z / 12.f, zzx = z * z * x_round_var(pl.i8 && co.seed != 0ull);   // (see run_small)
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   f32x4 *cc_perm = nullptr;        // ... of the main pass in its own column order when it leaves the sample rows out
@@ -416,10 +417,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
     if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
       hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
-                         valid, need);
+                         valid, need, co.seed);
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
-                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need);
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, co.seed);
     skip_sample = MAIN_SKIPS_SAMPLE && w_packed;   // the tile-major main operand holds the non-sample rows only
     cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
@@ -455,7 +456,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     GemmEpilogue ep{};
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
     ep.dense = sample; ep.ld_dense = pl.S;
-    ep.rowc = rowc; ep.colc = colc_s; ep.refs = refs; ep.zz12 = zz12;
+    ep.rowc = rowc; ep.colc = colc_s; ep.refs = refs; ep.zz12 = zzx;
     const int grc = skinny == 64    ? gemm_skinny_launch<64, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 128 ? gemm_skinny_launch<128, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 256 ? gemm_skinny_launch<256, true>(op_samp, T, d, pl.S, ep, s)
@@ -493,7 +494,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.cnt = pcnt; ep.cand = pcand; ep.cap = pl.cap; ep.segs = pl.segs;
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
-    ep.rowc = rowc; ep.colc = skip_sample ? cc_perm : colc; ep.refs = refs; ep.zz12 = zz12;
+    ep.rowc = rowc; ep.colc = skip_sample ? cc_perm : colc; ep.refs = refs; ep.zz12 = zzx;
     if constexpr (msae_tuning::GEMM_TIMELINE != 0) {
       if (!g_timeline) (void)hipMalloc(&g_timeline, 64 * 8 * 8);
       (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
@@ -513,7 +514,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     PackArgs pa{};
     pa.cnt = cnt; pa.cand = cand; pa.cap = pl.cap;
     pa.tau_vals = tauv; pa.tau_ld = pl.r; pa.tau_col = pl.r - 1;
-    pa.rowc = rowc; pa.colc = colc; pa.zz12 = zz12; pa.i8 = pl.i8 ? 1 : 0;
+    pa.rowc = rowc; pa.colc = colc; pa.zz12 = zzx; pa.i8 = pl.i8 ? 1 : 0;
     pa.C = shard->C; pa.row_offset = shard->row_offset; pa.stride = shard_record_bytes(shard->C);
     pa.recs = shard->recs;
     if (pl.cap <= 64 * 32) hipLaunchKernelGGL(pack_candidates_kernel<32>, dim3(T), dim3(64), 0, s, pa);
@@ -530,7 +531,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.tau_vals = tauv; ra.tau_ld = pl.r; ra.tau_col = pl.r - 1;
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
-    ra.rowc = rowc; ra.colc = colc; ra.zz12 = zz12; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
+    ra.rowc = rowc; ra.colc = colc; ra.zz12 = zzx; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
@@ -599,8 +600,9 @@ extern "C" void msae_options_init(msae_options *opts) {
   opts->status_detail = 0;
   opts->profile = nullptr;
   opts->exact = 0;
-  opts->reserved = 0;
+  opts->dither = MSAE_DITHER_DEFAULT;
   opts->rows_rescored = nullptr;
+  opts->dither_seed = 0;
 }
 
 extern "C" int msae_profile_create(int max_steps, void **handle) {
@@ -654,7 +656,7 @@ extern "C" size_t msae_encoder_prepared_bytes(int N, int d) {
 namespace {
 // modes: bit 0 = bf16 operands, bit 1 = int8 operands, bit 2 = without the fragment-major copies (the weight-stream kernels of
 // batches of <= 128 tokens read them; the caller refreshes for a large batch)
-int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hipStream_t s) {
+int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, unsigned long long seed, hipStream_t s) {
   if (N <= 0 || d <= 0 || !prepared) return MSAE_EINVAL;
   if (!msae_aligned(prepared, 256)) return MSAE_EALIGN;
   Prepared p = make_prepared(N, d);
@@ -669,7 +671,8 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
                          reinterpret_cast<unsigned short *>(base + p.off_wb),
                          reinterpret_cast<unsigned short *>(base + p.off_ws));
     const bool i8 = i8_shape_ok(N, d);
-    const RowQuantOut ro = row_quant_out(base, p, modes, i8);
+    RowQuantOut ro = row_quant_out(base, p, modes, i8);
+    ro.seed = seed;
     if ((modes & 2) && i8)   // row statistics (both passes' error bands) + int8 operands
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
     else
@@ -679,8 +682,14 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, hi
 }
 }  // namespace
 
+extern "C" int msae_encoder_prepare_opts(const float *W_enc, int N, int d, void *prepared, const msae_options *opts,
+                                         void *stream) {
+  CallOpts co;
+  if (!resolve_opts(opts, co)) return MSAE_EINVAL;
+  return prepare_impl(W_enc, N, d, prepared, 3, co.seed, (hipStream_t)stream);
+}
 extern "C" int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream) {
-  return prepare_impl(W_enc, N, d, prepared, 3, (hipStream_t)stream);
+  return msae_encoder_prepare_opts(W_enc, N, d, prepared, nullptr, stream);
 }
 
 // After a weight update (training): rebuild only the operands the coarse mode in force reads.
@@ -689,7 +698,7 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   CallOpts co;
   if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
-  return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, (hipStream_t)stream);
+  return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, co.seed, (hipStream_t)stream);
 }
 
 // ... for an encode of T_next tokens that follows: a batch of more than 256 tokens does not read the fragment-major copies (0.5 GB
@@ -699,7 +708,7 @@ extern "C" int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *
   CallOpts co;
   if (!resolve_opts(opts, co) || T_next <= 0) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
-  return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0), (hipStream_t)stream);
+  return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0), co.seed, (hipStream_t)stream);
 }
 
 extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const msae_options *opts) {

@@ -59,9 +59,7 @@ __global__ __launch_bounds__(256) void prep_x_kernel(const void *__restrict__ x,
 // floor(s + r(n, c)), r uniform in [0, 1) -- unbiased for any activation direction, residual variance
 // <= 1/4 step^2 instead of 1/12: Q_i8 = 3 sw^2 for them.
 __device__ __forceinline__ float hash01(unsigned long long z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
+  z = mix64(z);
   return (float)(unsigned)(z >> 40) * (1.f / 16777216.f);
 }
 // The work of one 256-thread workgroup on row n (also the tail of the fused optimiser pass of csrc/train.hip, which calls it
@@ -70,6 +68,9 @@ struct RowQuantOut {
   f32x4 *wstat, *wstat_s, *colbf, *colbf_s;
   signed char *wq, *wqs, *wqp, *wqsp, *wqf, *wqsf;
   int layout;
+  // msae_options::dither of the prepare / refresh: != 0 rounds EVERY row stochastically with this seed (Q_i8 = 3 sw^2 x 1.001:
+  // the residual of every weight is the library's randomness); 0: round to nearest, sub-step rows with the fixed hash (ABI 3)
+  unsigned long long seed;
 };
 template <bool QUANT>
 __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W, int n, int d, const RowQuantOut &o,
@@ -102,11 +103,12 @@ __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W,
   s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   s4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
   const float scale = m > 0.f ? m / 127.f : 0.f;          // an all-zero row: coarse value = bias exactly, no band
-  const bool dither = s2 < scale * scale * (float)d;       // rms below one step
+  const bool dither = o.seed != 0ull || s2 < scale * scale * (float)d;       // every row / rms below one step
+  const unsigned long long hseed = o.seed != 0ull ? mix64(o.seed) : 0ull;
   const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
   if (threadIdx.x == 0) {
     const float q_bf = __builtin_sqrtf(s4);
-    const f32x4 st = {scale, scale * scale * (dither ? 3.f : 1.f), s2, q_bf};
+    const f32x4 st = {scale, scale * scale * (dither ? 12.f * x_round_var(true) : 1.f), s2, q_bf};
     const f32x4 cb = {1.f, q_bf, 0.f, 0.f};
     wstat[n] = st;
     colbf[n] = cb;
@@ -123,7 +125,7 @@ __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float sv = v[e] * inv;
-          int iv = dither ? (int)floorf(sv + hash01((unsigned long long)n * (unsigned)d + (unsigned)(c + 4 * q + e)))
+          int iv = dither ? (int)floorf(sv + hash01(hseed + (unsigned long long)n * (unsigned)d + (unsigned)(c + 4 * q + e)))
                           : (int)rintf(sv);
           iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
           w |= ((unsigned)iv & 0xFFu) << (8 * e);
@@ -264,9 +266,16 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
                                                       signed char *__restrict__ xq,
                                                       signed char *__restrict__ xqo,
                                                       f32x4 *__restrict__ rowc, float zz12, int tile_major,
-                                                      const unsigned *__restrict__ valid, unsigned need) {
+                                                      const unsigned *__restrict__ valid, unsigned need,
+                                                      unsigned long long seed) {
   __shared__ float red[3][4];
   const int t = blockIdx.x;
+  // msae_options::dither: q = floor(v / step + r(t, c)) instead of rint -- the residual of every dim is zero-mean whatever the
+  // token is (dims below one step round to 0 or +-1 at random).  The E0 guard below stays as it is: a token it flags has a
+  // scale so coarse that its band separates nothing -- straight to the exact path instead of through a re-score that would
+  // flag it anyway (reason 32 / 4); e0 counts the dims that round-to-nearest would zero, whichever rounding runs.
+  const bool dith = seed != 0ull;
+  const unsigned dkey = dith ? dither_key(seed, (unsigned)t) : 0u;
   auto xq_at = [&](int c) { return xq + (tile_major ? packed_off((size_t)t, c, d, tile_major) : (size_t)t * d + c); };
   if (t >= T) {
     for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(xq_at(c)) = i32x4{0, 0, 0, 0};
@@ -344,9 +353,10 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool outl = ((flags >> (8 * e)) & 0xFFu) != 0;
-        int iv = outl ? 0 : (int)rintf(v[e] * inv);
+        const float sv = v[e] * inv;
+        int iv = outl ? 0 : (dith ? (int)floorf(sv + dither01(dkey, (unsigned)(c + 4 * q + e))) : (int)rintf(sv));
         iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
-        e0 += (!outl && iv == 0) ? v[e] * v[e] : 0.f;
+        e0 += (!outl && fabsf(sv) <= 0.5f) ? v[e] * v[e] : 0.f;
         w |= ((unsigned)iv & 0xFFu) << (8 * e);
       }
       packed[q] = (int)w;
@@ -371,7 +381,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
       if constexpr (!FROM_X) av = row32[dim];
       else av = load_x1<SRC>(x, (size_t)t * d + dim) - (b_dec ? b_dec[dim] : 0.f);
     }
-    int iv = dim >= 0 ? (int)rintf(av * inv_o) : 0;
+    // (the outlier dims' own stream of the hash: indices d .. d + MAX_OUT)
+    int iv = dim >= 0 ? (dith ? (int)floorf(av * inv_o + dither01(dkey, (unsigned)(d + threadIdx.x))) : (int)rintf(av * inv_o)) : 0;
     iv = iv > 127 ? 127 : (iv < -127 ? -127 : iv);
     xqo[(size_t)t * MAX_OUT + threadIdx.x] = (signed char)iv;
   }

@@ -958,7 +958,8 @@ inline int launch_select_rescore(RescoreArgs &ra, int T, int k, size_t smem, con
 // ms, k = 32 (m = 2.7) 1.03 -> 0.82; small d (768: the pairs are cheap either way) and f32 activations at moderate m stay
 // token-major.  MSAE_FM=0 / 1 forces the route (where the shape allows it).
 inline bool fm_pays(int T, int k, int N, int d, int esize) {
-  static const int force = [] { const char *e = getenv("MSAE_FM"); return e ? atoi(e) : -1; }();
+  const char *e = getenv("MSAE_FM");          // (read at every call: a test forces the route on and off in one process)
+  const int force = e ? atoi(e) : -1;
   if (force >= 0) return force != 0;
   const double m = 1.36 * (double)T * k / N;
   if (m < 1.0) return false;

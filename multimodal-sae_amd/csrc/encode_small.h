@@ -47,9 +47,12 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict_
                                                          signed char *__restrict__ xlo, f32x4 *__restrict__ rowc,
                                                          float zz12, int *__restrict__ zero_a, int n_a,
                                                          int *__restrict__ zero_b, int n_b,
-                                                         const unsigned *__restrict__ valid, unsigned need, int T) {
+                                                         const unsigned *__restrict__ valid, unsigned need, int T,
+                                                         unsigned long long seed) {
   __shared__ float red[2][4];
   const int t = blockIdx.x;
+  const bool dith = seed != 0ull;                      // msae_options::dither (quant_x_kernel)
+  const unsigned dkey = dith ? dither_key(seed, (unsigned)t) : 0u;
   if (t == 0) {   // per-call counters (model-check flags [T], finished-wave counters [T], flag list + counts) start at zero
     // stale operands (Prepared::valid): the model-check flag of every token starts RAISED -- all of them go to the exact path
     const int stale = (*valid & need) != need ? 1 : 0;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict_
     unsigned wh = 0, wl = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      int q = (int)rintf(v[e] * inv);
+      int q = dith ? (int)floorf(v[e] * inv + dither01(dkey, (unsigned)(c + e))) : (int)rintf(v[e] * inv);
       q = q > 16319 ? 16319 : (q < -16319 ? -16319 : q);
       const int hi = (q + 64) >> 7, lo = q - hi * 128;
       wh |= ((unsigned)hi & 0xFFu) << (8 * e);

@@ -408,6 +408,7 @@ extern "C" int msae_adam_rows_fused_f32(float *W, const float *G, float *M, floa
       MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
       unsigned char *base = static_cast<unsigned char *>(prepared);
       ft.rq = row_quant_out(base, p, modes, i8);
+      ft.rq.seed = co.seed;                                        // msae_options::dither: this refresh's own seed
       ft.wb = reinterpret_cast<unsigned short *>(base + p.off_wb);
       ft.ws = reinterpret_cast<unsigned short *>(base + p.off_ws);
       refresh = i8 ? 1 : 2;

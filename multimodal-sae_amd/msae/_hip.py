@@ -18,14 +18,14 @@ LIB_PATH = _LIB_DIR / "libmsae_hip.so"
 c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                ctypes.c_size_t, ctypes.c_int64)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MsaeOptions(ctypes.Structure):
     """struct msae_options of include/msae.h: the per-call options of the fused encoder."""
     _fields_ = [("size", ctypes.c_uint32), ("coarse_mode", ctypes.c_int32), ("guard_z", ctypes.c_float),
                 ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p), ("exact", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("rows_rescored", ctypes.c_void_p)]
+                ("dither", ctypes.c_int32), ("rows_rescored", ctypes.c_void_p), ("dither_seed", ctypes.c_uint64)]
 
 
 c_opts_p = ctypes.POINTER(MsaeOptions)
@@ -43,6 +43,7 @@ PROTOTYPES = {
                               c_void_p]),
     "msae_encoder_prepared_bytes": (c_size_t, [c_int, c_int]),
     "msae_encoder_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "msae_encoder_prepare_opts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
     "msae_encoder_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
     "msae_encoder_refresh_for": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_opts_p, c_void_p]),
     "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_opts_p]),

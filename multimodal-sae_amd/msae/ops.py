@@ -91,11 +91,14 @@ class StageProfile:
 
 class Options:
     COARSE = {"default": -1, "bf16": 0, "int8": 1}
+    DITHER = {"default": 0, "on": 1, "off": 2}
 
     def __init__(self, coarse: str = "default", guard_z: float = 0.0, status_detail: bool = False,
-                 profile: Optional[StageProfile] = None, exact: bool = False):
+                 profile: Optional[StageProfile] = None, exact: bool = False, dither: str = "default",
+                 dither_seed: int = 0):
         self.coarse, self.guard_z, self.status_detail, self.profile = coarse, guard_z, status_detail, profile
         self.exact = exact
+        self.dither, self.dither_seed = dither, int(dither_seed)   # msae_options::dither / dither_seed (0: drawn per call)
         self.rows_rescored: Optional[Tensor] = None     # device int32 [T] (msae_options::rows_rescored) or None
 
     def struct(self) -> "_hip.MsaeOptions":
@@ -106,6 +109,8 @@ class Options:
         o.status_detail = int(bool(self.status_detail))
         o.profile = self.profile.handle if self.profile is not None else None
         o.exact = int(bool(self.exact))
+        o.dither = self.DITHER[self.dither]
+        o.dither_seed = self.dither_seed & 0xFFFFFFFFFFFFFFFF
         o.rows_rescored = self.rows_rescored.data_ptr() if self.rows_rescored is not None else None
         return o
 
@@ -134,19 +139,26 @@ _OPTS_CACHE: dict = {}
 _WS_BYTES_CACHE: dict = {}
 
 
-def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False, exact: bool = False) -> _OptsRef:
+_DITHER_NAME = {0: "default", 1: "on", 2: "off"}
+
+
+def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False, exact: bool = False,
+          dither: int = 0, dither_seed: int = 0) -> _OptsRef:
     """Options of one call: explicit arguments win, the process defaults fill the rest."""
     coarse = _defaults.coarse if coarse_mode < 0 else ("int8" if coarse_mode == 1 else "bf16")
     z = guard_z if guard_z > 0.0 else _defaults.guard_z
     detail = bool(status_detail or _defaults.status_detail)
     exact = bool(exact or _defaults.exact)
+    dith = _DITHER_NAME[dither] if dither else _defaults.dither
+    seed = dither_seed if dither_seed else _defaults.dither_seed
     prof, rows = _defaults.profile, _defaults.rows_rescored
-    key = (coarse, z, detail, id(prof) if prof is not None else 0, exact, rows.data_ptr() if rows is not None else 0)
+    key = (coarse, z, detail, id(prof) if prof is not None else 0, exact, rows.data_ptr() if rows is not None else 0,
+           dith, seed)
     ref = _OPTS_CACHE.get(key)
     if ref is None or ref.profile is not prof:
         if len(_OPTS_CACHE) > 64:
             _OPTS_CACHE.clear()
-        o = Options(coarse, z, detail, prof, exact)
+        o = Options(coarse, z, detail, prof, exact, dith, seed)
         o.rows_rescored = rows
         ref = _OPTS_CACHE[key] = _OptsRef(o)
     return ref
@@ -154,7 +166,8 @@ def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = Fal
 
 def _encode_ws_bytes(lib, T: int, d: int, N: int, k: int, opts: _OptsRef) -> int:
     """msae_encode_topk_ws_bytes, memoised (a pure function of the shape and the coarse mode)."""
-    key = (T, d, N, k, opts.struct.coarse_mode, os.environ.get("MSAE_COARSE") if opts.struct.coarse_mode < 0 else None)
+    key = (T, d, N, k, opts.struct.coarse_mode, os.environ.get("MSAE_COARSE") if opts.struct.coarse_mode < 0 else None,
+           os.environ.get("MSAE_FM"))
     n = _WS_BYTES_CACHE.get(key)
     if n is None:
         if len(_WS_BYTES_CACHE) > 4096:
@@ -348,6 +361,16 @@ def set_exact(on: bool) -> None:
     _defaults.exact = bool(on)
 
 
+def set_dither(mode: str = "default", seed: int = 0) -> None:
+    """Default of msae_options::dither / dither_seed for this process's ops: "on" rounds the int8 operands stochastically
+    (activations per encode call, weights per prepare / refresh) so that the fused encoder's miss bound holds for EVERY input
+    (include/msae.h); "off" is round-to-nearest with the statistical noise model; "default" = environment MSAE_DITHER, else on.
+    seed != 0 pins the hash seed of every call (reproducible candidate sets); 0 lets the library draw one per call."""
+    if mode not in Options.DITHER:
+        raise ValueError(f"dither mode {mode!r}: expected one of {sorted(Options.DITHER)}")
+    _defaults.dither, _defaults.dither_seed = mode, int(seed)
+
+
 def set_status_detail(on: bool) -> None:
     """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
     _defaults.status_detail = bool(on)
@@ -374,8 +397,8 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
             _hip.check(lib.msae_encoder_refresh(_hip.ptr(W), N, d, _hip.ptr(out), _opts().ref(), _hip.stream_of(W)),
                        "msae_encoder_refresh")
         else:
-            _hip.check(lib.msae_encoder_prepare(_hip.ptr(W), N, d, _hip.ptr(out), _hip.stream_of(W)),
-                       "msae_encoder_prepare")
+            _hip.check(lib.msae_encoder_prepare_opts(_hip.ptr(W), N, d, _hip.ptr(out), _opts().ref(), _hip.stream_of(W)),
+                       "msae_encoder_prepare_opts")
     return out
 
 
@@ -427,11 +450,12 @@ def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
 def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Optional[Tensor],
                 prepared: Optional[Tensor], k: int, set_feature: int = -1, set_value: float = 0.0,
                 zero_feature: int = -1, coarse_mode: int = -1, guard_z: float = 0.0,
-                status_detail: bool = False, exact: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+                status_detail: bool = False, exact: bool = False, dither: int = 0,
+                dither_seed: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...]).
     coarse_mode (-1 default / 0 bf16 / 1 int8), guard_z (0 = default), status_detail and exact (every token by the
-    exact path: include/msae.h, msae_options::exact) are this call's msae_options; what is left at its default comes
-    from the process defaults (set_coarse_mode & co.)."""
+    exact path: include/msae.h, msae_options::exact), dither (0 default / 1 on / 2 off) and dither_seed (0 = drawn by the
+    library) are this call's msae_options; what is left at its default comes from the process defaults (set_coarse_mode & co.)."""
     dev = _hip.require_device(x, W_enc, b_enc, b_dec, prepared)
     lib = _hip.load()
     xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
@@ -444,7 +468,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     status = torch.empty(xa.shape[:-1], dtype=torch.int32, device=dev)
     if T == 0:
         return vals, idx, status
-    opts = _opts(coarse_mode, guard_z, status_detail, exact)
+    opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed)
     ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
@@ -457,7 +481,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
 
 @encode_topk.register_fake
 def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1, coarse_mode=-1,
-      guard_z=0.0, status_detail=False, exact=False):
+      guard_z=0.0, status_detail=False, exact=False, dither=0, dither_seed=0):
     return (x.new_empty(*x.shape[:-1], k, dtype=torch.float32),
             x.new_empty(*x.shape[:-1], k, dtype=torch.int64),
             x.new_empty(x.shape[:-1], dtype=torch.int32))

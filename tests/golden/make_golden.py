@@ -125,6 +125,34 @@ def encode_decode_fixture(Sae, SaeConfig, name, d, N, ks, T, wseed, xseed):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def encode_decode_large_fixture(Sae, SaeConfig, name, d, N, ks, T, wseed, xseed):
+    """g13 (round-4 verdict, item 2): the reference's encode / decode at batch sizes that reach the kernels bench.py
+    times -- T > 256 tokens (the large-batch int8 candidate GEMM, the feature-major re-score) and 17 <= T <= 256 slices of the
+    same batch (the weight-stream GEMM) -- stored compactly: top-k values + indices + the (k, k+1) gap for every token,
+    the reconstruction as per-token sums (f64 of the f32 rows) plus 16 whole rows."""
+    out = {"d": d, "N": N, "T": T, "wseed": wseed, "xseed": xseed, "ks": np.array(ks)}
+    x = torch.from_numpy(synth.activations(T, d, xseed)).to(torch.bfloat16)
+    sae = _make_ref_sae(Sae, SaeConfig, d, N, ks[0], wseed)
+    rows = np.arange(0, T, max(1, T // 16))[:16]
+    out["recon_rows_at"] = rows
+    with torch.no_grad():
+        pre = sae.pre_acts(x)  # sae.py:172
+        out["pre_slice"] = pre[:8, :256].numpy()
+        for k in ks:
+            sae.cfg.k = k
+            top = sae.select_topk(pre)  # sae.py:179
+            v, i = _canon(top.top_acts, top.top_indices)
+            out[f"k{k}_acts"], out[f"k{k}_idx"] = v, i
+            kk = pre.topk(k + 1, sorted=True).values
+            out[f"k{k}_gap"] = (kk[:, k - 1] - kk[:, k]).numpy()
+            recon = sae.decode(top.top_acts, top.top_indices)  # sae.py:187
+            out[f"k{k}_recon_sum"] = recon.double().sum(-1).numpy()
+            out[f"k{k}_recon_abs"] = recon.double().abs().sum(-1).numpy()
+            out[f"k{k}_recon_rows"] = recon[torch.from_numpy(rows)].numpy()
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def decode_seam_fixture(eager_decode):
     """train/sae/tests/test_decode.py:6-20 restated with fixed inputs (CPU)."""
     g = torch.Generator().manual_seed(0)
@@ -425,11 +453,17 @@ def main():
     Sae, SaeConfig, eager_decode, cache_mod = _import_reference()
     if args.only:
         for name in args.only.split(","):
+            if name == "g13":
+                encode_decode_large_fixture(Sae, SaeConfig, "g13_d4096_n16384_t1024", 4096, 16384, [32, 256], 1024, 12, 13)
+                if args.full:
+                    encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 14, 15)
+                continue
             fn = globals()[name]
             fn(Sae, SaeConfig, cache_mod) if name in ("cache_fixture", "image_cache_fixture") else fn(Sae, SaeConfig)
         return
     encode_decode_fixture(Sae, SaeConfig, "g1_c1_d768_n4096", 768, 4096, [32], 64, 1, 0)
     encode_decode_fixture(Sae, SaeConfig, "g2_d4096_n16384", 4096, 16384, [32, 256], 16, 2, 3)
+    encode_decode_large_fixture(Sae, SaeConfig, "g13_d4096_n16384_t1024", 4096, 16384, [32, 256], 1024, 12, 13)
     decode_seam_fixture(eager_decode)
     cache_fixture(Sae, SaeConfig, cache_mod)
     hook_fixture(Sae, SaeConfig)
@@ -441,6 +475,7 @@ def main():
     chunker_fixture()
     if args.full:
         encode_decode_fixture(Sae, SaeConfig, "g2_c2_d4096_n131072", 4096, 131072, [32, 256], 16, 3, 4)
+        encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 14, 15)
 
 
 if __name__ == "__main__":

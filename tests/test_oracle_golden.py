@@ -59,6 +59,46 @@ def test_encode_topk_decode_matches_reference(golden_dir, name):
         assert np.array_equal(i2, idx) and np.array_equal(v2, vals)
 
 
+def check_large_fixture(g, k, vals, idx, recon):
+    """g13's compact encode / decode record vs one implementation's (canonical) top-k and reconstruction; shared with the
+    GPU test (tests/test_gpu_parity.py).  Same rules as above."""
+    ref_v, ref_i, gap = g[f"k{k}_acts"], g[f"k{k}_idx"], g[f"k{k}_gap"]
+    assert _close(vals, ref_v)
+    safe = gap > EPS_GAP
+    assert safe.mean() > 0.9
+    pos_v, pos_r = vals > 0, ref_v > 0
+    for t in np.nonzero(safe)[0]:
+        assert set(idx[t][pos_v[t]]) == set(ref_i[t][pos_r[t]]), t
+    sep = np.all(np.abs(np.diff(ref_v, axis=1)) > EPS_GAP, axis=1) & safe
+    assert np.array_equal(idx[sep], ref_i[sep])
+    pos_ok = np.ones_like(ref_i, dtype=bool)
+    pos_ok[:, 1:] &= np.abs(np.diff(ref_v, axis=1)) > EPS_GAP
+    pos_ok[:, :-1] &= np.abs(np.diff(ref_v, axis=1)) > EPS_GAP
+    pos_ok &= safe[:, None]
+    assert np.array_equal(idx[pos_ok], ref_i[pos_ok])
+    rows = g["recon_rows_at"]
+    ref_rows = g[f"k{k}_recon_rows"]
+    scale = np.abs(ref_rows).max()
+    ok = safe[rows]
+    assert np.all(np.abs(recon[rows][ok] - ref_rows[ok]) <= RTOL * scale)
+    # every token's reconstruction through its sum (f64 of the f32 row): |sum error| <= RTOL * sum |recon|
+    s = recon.astype(np.float64).sum(-1)
+    assert np.all(np.abs(s[safe] - g[f"k{k}_recon_sum"][safe]) <= RTOL * g[f"k{k}_recon_abs"][safe])
+    return int(safe.sum())
+
+
+@pytest.mark.parametrize("name", ["g13_d4096_n16384_t1024", "g13_c2_d4096_n131072_t320"])
+def test_large_batch_fixture_matches_reference(golden_dir, name):
+    """g13: the reference's encode / decode at T = 1024 (N = 16384) and at the FULL C2 shape with T = 320 -- the batch sizes
+    whose HIP kernels bench.py times; the GPU counterpart is test_benchmarked_kernels_match_reference_fixture."""
+    g, (W_enc, b_enc, W_dec, b_dec), x = _load(golden_dir, name)
+    for k in g["ks"]:
+        k = int(k)
+        vals, idx = oracle.encode_topk(x, W_enc, b_enc, b_dec, k)
+        recon = oracle.decode(idx, vals, W_dec, b_dec)
+        check_large_fixture(g, k, vals, idx, recon)
+
+
 def test_decode_seam_reference_test(golden_dir):
     """train/sae/tests/test_decode.py:6-20: sparse decode == eager decode."""
     g = np.load(golden_dir / "g3_decode_seam.npz")
