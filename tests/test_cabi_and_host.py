@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libmsae_hip.so does not export {name}"
     assert set(declared) == set(_hip.PROTOTYPES), set(declared) ^ set(_hip.PROTOTYPES)
-    assert lib.msae_abi_version() == 3
+    assert lib.msae_abi_version() == 4
     assert lib.msae_target_arch() == b"gfx950"
     assert b"workspace" in lib.msae_error_string(-3)
     # pure host-side size queries (no GPU needed)
@@ -49,9 +49,14 @@ def test_library_exports_every_declared_symbol():
     bad.guard_z, bad.size = 0.0, 4     # a caller compiled against a shorter struct than this library knows
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(bad)) == 0
     # ... while ABI 2's struct (24 bytes, no `exact`) is still served (exact = 0: the same plan)
-    assert o8.exact == 0 and ctypes.sizeof(_hip.MsaeOptions) == 40
+    assert o8.exact == 0 and o8.dither == 0 and o8.dither_seed == 0 and ctypes.sizeof(_hip.MsaeOptions) == 48
     o8.size = 24
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == w8
+    # ... and ABI 3's (40 bytes: `reserved` where `dither` now is, no dither_seed)
+    o8.size = 40
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == w8
+    o8.size, o8.dither = 48, 7         # an unknown dither mode is an argument error
+    assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == 0
 
 
 def test_compute_on_cpu_tensors_raises_instead_of_falling_back():
