@@ -150,7 +150,11 @@ inline bool resolve_opts(const msae_options *o, CallOpts &c) {
 }
 
 unsigned long long *g_timeline = nullptr;   // tuning builds only (msae_tuning::GEMM_TIMELINE)
-constexpr float GUARD_Z_CHECK = 6.f;      // a re-scored pair further than this many sigma from its coarse value flags the token
+// Model check: a re-scored pair further than this many sigma (of the band's sigma) from its coarse value flags the token.
+// Round to nearest: 6 sigma of the noise model (2e-9 per pair under it) -- the data-side assumption is being tested.  Dither:
+// the band's sigma is Hoeffding's proxy, sqrt(3/2) x the actual rms on fine data, and nothing about the data is assumed any more
+// (the check is only the net under operands edited behind the API): 5 proxy sigma = 6.1 actual, the same false-alarm rate.
+__host__ __device__ inline float guard_z_check2(bool dither) { return dither ? 25.f : 36.f; }
 // Deterministic per-token guard of the int8 pass.  The x-side residual is modelled as independent rounding
 // noise of variance sx^2 / 12 per dim.  The dims that round to ZERO are the exception: their residual is the
 // activation itself, i.e. structured -- a feature whose weights correlate with that part of the token (cosine c) is off by

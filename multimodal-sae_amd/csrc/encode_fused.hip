@@ -336,7 +336,7 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   prof_mark(co.prof, 4, s);
 #define MSAE_RESCORE(DSEG)                                                                                         \
   hipLaunchKernelGGL(rescore_small_kernel<DSEG>, dim3(SMALL_RMAX, T), dim3(64), 0, s, a32, W_enc, b_enc, k, cand, tau, wstat, \
-                     rowc, zzx, z * z, set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
+                     rowc, zzx, z * z, guard_z_check2(co.seed != 0ull), set_feature, set_value, exact, viol, done, vals, idx, status, flagged, n_flagged)
   switch (dseg) { case 1: MSAE_RESCORE(1); break; case 2: MSAE_RESCORE(2); break; case 4: MSAE_RESCORE(4); break;
                   case 8: MSAE_RESCORE(8); break; default: return MSAE_ENOTIMPL; }
 #undef MSAE_RESCORE
@@ -532,6 +532,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
     ra.rowc = rowc; ra.colc = colc; ra.zz12 = zzx; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
+    ra.zc2 = guard_z_check2(pl.i8 && co.seed != 0ull);
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
@@ -890,6 +891,7 @@ int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const
   ra.cap = xp.cap;
   ra.T = T_valid; ra.d = d; ra.N = N; ra.k = k; ra.r_max = xp.r_max;
   ra.zz12 = z * z / 12.f; ra.z2 = z * z; ra.i8 = 0;
+  ra.zc2 = guard_z_check2(co.mode == 1 && co.seed != 0ull);   // (the records' z sigma came from shards running with the same options)
   ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
   ra.vals = vals; ra.idx = nullptr; ra.idx64 = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
   ra.fb_cap = T;

@@ -18,6 +18,7 @@ struct RescoreArgs {
   int set_feature; float set_value; int zero_feature;
   const f32x4 *rowc, *colc;           // error-band constants per token / per feature
   float zz12, z2; int i8;
+  float zc2;                          // (model check) a re-scored pair further than sqrt(zc2) sigma from its coarse value flags the token
   float *vals; int32_t *idx; int64_t *idx64; int32_t *status;   // idx / idx64: either may be null
   int *flagged; int *n_flagged; int fb_cap;
   int32_t *rows_out;                  // optional diagnostics (msae_options::rows_rescored)
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
   }
 
   MSAE_RTL(3);
-  const float zc2 = GUARD_Z_CHECK * GUARD_Z_CHECK;
+  const float zc2 = p.zc2;
   const bool guarded = !EXT && rc[3] != 0.f;     // the token's shape is outside the noise model (quant_x_kernel): exact path
   if (guarded) target = 0;                       // (no row is read for it here)
   if constexpr (PHASE == 1) {

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restri
                                                            const unsigned long long *__restrict__ cand,
                                                            const float *__restrict__ tau,
                                                            const f32x4 *__restrict__ wstat,
-                                                           const f32x4 *__restrict__ rowc, float zz12, float z2,
+                                                           const f32x4 *__restrict__ rowc, float zz12, float z2, float zc2,
                                                            int set_feature, float set_value,
                                                            unsigned long long *__restrict__ exact, int *__restrict__ viol,
                                                            int *__restrict__ done, float *__restrict__ vals, IdxOut idx,
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64) void rescore_small_kernel(const float *__restri
         const f32x4 rc = rowc[t], st = wstat[f];
         const float zs2 = __builtin_fmaf(rc[2], st[1], rc[0] * rc[0] * zz12 * st[2]);
         const float diff = pre - (upper - __builtin_sqrtf(zs2));
-        if (diff * diff * z2 > GUARD_Z_CHECK * GUARD_Z_CHECK * zs2 * 1.0001f + 1e-30f) atomicOr(viol + t, 1);
+        if (diff * diff * z2 > zc2 * zs2 * 1.0001f + 1e-30f) atomicOr(viol + t, 1);
       }
     }
   } else if (lane == 0) {

@@ -216,9 +216,11 @@ def test_band_width_matters(dev):
 
 
 def test_stale_operands_are_caught_by_the_model_check(dev):
-    """The coarse operands no longer describe the weights (W_enc edited in place after prepare): every
-    re-scored pair is far outside its band, so the tokens are flagged (reason 64) and recomputed exactly
-    -- the results are those of the NEW weights."""
+    """The coarse operands no longer describe the weights (W_enc edited in place after prepare, behind the API): the
+    re-scored pairs land far outside their bands, so the tokens are flagged (reason 64) and recomputed exactly -- the
+    results are those of the NEW weights.  A net, not a guarantee (Sae.invalidate_prepared / a refresh is the contract;
+    Prepared::valid covers what the API itself leaves stale): 10 % noise per row is ~9 band sigma per pair at this shape
+    (the dither's Hoeffding band is sqrt(3) wider than the round-to-nearest one, so the net is that much coarser)."""
     from msae import ops
 
     d, N, T, k = 1024, 16384, 2048, 32
@@ -226,7 +228,7 @@ def test_stale_operands_are_caught_by_the_model_check(dev):
     x = hostile.activations(T, d, dev, seed=12)
     prepared = ops.prepare_encoder(W)
     g = torch.Generator(device=dev).manual_seed(13)
-    W += 0.05 * torch.randn(N, d, generator=g, device=dev) / d ** 0.5       # 5 % relative noise on every row
+    W += 0.10 * torch.randn(N, d, generator=g, device=dev) / d ** 0.5       # 10 % relative noise on every row
     ops.set_status_detail(True)
     try:
         v, i, status = ops.encode_topk(x, W, b, bd, prepared, k)

@@ -5,7 +5,7 @@ OUT=gpurun_out/r05a
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu =="
-timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -s > $OUT/pytest_gpu.log 2>&1
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
 grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -5
 grep -E "residual-aligned|shape guard|soak 65536" $OUT/pytest_gpu.log
