@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     if (p.status) p.status[t] = ok ? 0 : reason;
     // msae_options::rows_rescored: [1 << 30: first round feature-major] | rounds << 24 | first-round rows << 12 | rows of W_enc
     // this token read (0: not verified here)
-    if (p.rows_out) p.rows_out[t] = ok ? (PHASE == 2 ? 1 << 30 : 0) | (rounds << 24) | (first_target << 12) | done : 0;
+    if (p.rows_out) p.rows_out[t] = ok ? (PHASE == 2 ? 1 << 30 : 0) | ((rounds & 0x3F) << 24) | ((first_target < 0xFFF ? first_target : 0xFFF) << 12) | (done < 0xFFF ? done : 0xFFF) : 0;   // (12-bit fields saturate)
     if (!ok) {
       const int slot = atomicAdd(p.n_flagged, 1);
       if (slot < p.fb_cap) p.flagged[slot] = t;

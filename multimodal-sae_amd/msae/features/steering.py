@@ -46,7 +46,11 @@ class SteeringController:
             # feature-sharded engine: all ranks meet in its collectives at every hooked forward, so their generation
             # loops must take the same number of steps.  Same RNG state on every rank (the model's generation_config
             # may sample), and HF's `synced_gpus`: a rank whose sequence hit EOS keeps stepping until all have.
-            torch.manual_seed(0x5AE)
+            # -- seeded ONCE per controller (re-seeding in every _generate made every sampled steering
+            # generation replay the same random stream); later generations continue the ranks' common stream
+            if not getattr(self, "_ranks_seeded", False):
+                torch.manual_seed(0x5AE)
+                self._ranks_seeded = True
             kw["synced_gpus"] = True
         with torch.no_grad():
             output = self.model.generate(**self.inputs, max_new_tokens=512, **kw)

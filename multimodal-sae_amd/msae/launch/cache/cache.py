@@ -80,11 +80,20 @@ def main(cfg: CacheConfig):
     filters = load_filter(cfg.filters_path, device=model.device) if cfg.filters_path else None
     # the reference's default: num_proc = cpu_count() // 2 (sae_auto_interp/sae/data.py:21) -- the same chunks, hence the same
     # cache row ids, as the reference produces on this machine
+    num_proc = max(1, (os.cpu_count() or 2) // 2)
     try:
-        dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=max(1, (os.cpu_count() or 2) // 2))
-    except ValueError:
-        # a dataset too small for that many shards (a shard without one complete chunk): the reference stops here; one
-        # shard gives it a chance
+        dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=num_proc)
+    except ValueError as e:
+        # ONLY the chunker's own "a shard without one complete chunk" (a dataset too small for num_proc shards): the
+        # reference stops here (sae/data.py); one shard gives the run a chance -- loudly, because the chunk boundaries, hence
+        # the cache's row ids, are then those of num_proc=1 and not what the reference would produce on this machine
+        # (ADVICE r4).  Any other ValueError (the tokenizer's) propagates.
+        if num_proc == 1 or "Not enough data to create a single complete batch" not in str(e):
+            raise
+        import warnings
+
+        warnings.warn(f"launch.cache: the dataset is too small for num_proc={num_proc} shards ({e}); re-chunking with "
+                      "num_proc=1 -- the cache's row ids follow the single-process chunk boundaries")
         dataset = chunk_and_tokenize(dataset, tokenizer, max_seq_len=cfg.ctx_len, num_proc=1)
     shard_size = 0
     if ddp:

@@ -199,6 +199,25 @@ def rescore_rows(buf: Tensor):
         _defaults.rows_rescored = prev
 
 
+@contextlib.contextmanager
+def _without_rows():
+    prev, _defaults.rows_rescored = _defaults.rows_rescored, None
+    try:
+        yield
+    finally:
+        _defaults.rows_rescored = prev
+
+
+def _opts_for(T: int, dev) -> "_OptsRef":
+    """The process defaults as the options of a call of T tokens on `dev` (see encode_topk: the statistics buffer only
+    where it is large enough)."""
+    rows = _defaults.rows_rescored
+    if rows is not None and (T > rows.numel() or rows.device != dev):
+        with _without_rows():
+            return _opts()
+    return _opts()
+
+
 _DEBUG_BOUNDS = os.environ.get("MSAE_DEBUG_BOUNDS", "0") not in ("", "0")
 
 
@@ -428,13 +447,25 @@ def mark_train_operands_fresh(W_enc: Tensor, tokens_next: int) -> None:
     _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, _defaults.coarse, tokens_next <= 256)
 
 
+def invalidate_train_operands(W_enc: Optional[Tensor] = None) -> None:
+    """Forget that the training loop's operand buffer of `W_enc` (all buffers when None) is fresh: the next training encode
+    rebuilds it.  `_refresh_train_operands` trusts the tensor's version counter, which `p.data.copy_()` / `.data.mul_()`, a
+    custom C op or an external optimiser writing through `.data` do NOT bump: call this wherever the weight is
+    edited that way (Sae.load / load_state_dict / set_decoder_norm_to_unit_norm / invalidate_prepared do).  MSAE_DEBUG_OPERANDS=1 rebuilds before
+    every training encode regardless."""
+    if W_enc is None:
+        _TRAIN_FRESH.clear()
+    else:
+        _TRAIN_FRESH.pop(_train_key(W_enc), None)
+
+
 def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
     """Per-step operands of a weight that changes every step: one buffer per parameter, rebuilt in
     place for the coarse mode in force and for the batch size of the ONE encode that follows (it runs in that mode on
     `tokens` tokens; the buffer is rebuilt before it is read again) -- unless the optimiser pass that produced this
     version of the weight has already rebuilt it (adam_rows_(refresh=...): no second sweep over W_enc)."""
     key = _train_key(W_enc)
-    fresh = _TRAIN_FRESH.get(key)
+    fresh = _TRAIN_FRESH.get(key) if os.environ.get("MSAE_DEBUG_OPERANDS", "0") in ("", "0") else None
     if fresh is not None and fresh == (W_enc._version, _defaults.coarse, fresh[2]) and (tokens > 256 or fresh[2]) \
             and key in _TRAIN_PREPARED:
         return _TRAIN_PREPARED[key]
@@ -469,6 +500,12 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     if T == 0:
         return vals, idx, status
     opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed)
+    rows = _defaults.rows_rescored
+    if rows is not None and (T > rows.numel() or rows.device != dev):
+        # rescore_rows(buf) serves encodes of <= buf.numel() tokens on buf's device; a larger call inside the block runs
+        # WITHOUT the statistics instead of writing past the buffer
+        with _without_rows():
+            opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed)
     ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
@@ -500,7 +537,7 @@ def shard_candidates(x: Tensor, b_enc_shard: Optional[Tensor], b_dec: Optional[T
     recs = torch.empty(T, stride, dtype=torch.uint8, device=dev)
     if T == 0:
         return recs
-    opts = _opts()
+    opts = _opts_for(T, dev)
     ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N_shard, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_shard_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(be), _hip.ptr(bd),
@@ -534,7 +571,7 @@ def rescore_candidates(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec:
         _hip.check(lib.msae_rescore_candidates(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W), _hip.ptr(be),
                                                _hip.ptr(bd), T, T_valid, d, N, k, G, C, _hip.ptr(records), set_feature,
                                                set_value, zero_feature, _hip.ptr(vals), _hip.ptr(idx),
-                                               _hip.ptr(status), _hip.ptr(ws), ws.numel(), _opts().ref(),
+                                               _hip.ptr(status), _hip.ptr(ws), ws.numel(), _opts_for(T, dev).ref(),
                                                _hip.stream_of(xa)),
                    "msae_rescore_candidates")
     return vals, idx, status

@@ -177,6 +177,8 @@ class Sae(nn.Module):
         model and sends the token to the exact path -- but that is the slow path.)"""
         self._prepared = None
         self._prepared_key = None
+        if self.encoder.weight.is_cuda:
+            ops.invalidate_train_operands(self.encoder.weight)     # the training loop's per-parameter buffer as well
 
     def _prepared_weights(self) -> Optional[Tensor]:
         w = self.encoder.weight

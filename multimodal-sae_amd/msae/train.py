@@ -71,6 +71,9 @@ class SaeTrainStep:
                  dead_feature_threshold: int = 10_000_000, group=None, grad_acc_steps: int = 1,
                  micro_acc_steps: int = 1, lr_warmup_steps: int = 0, total_steps: Optional[int] = None,
                  init_b_dec: bool = False, fuse_next_step: bool = True):
+        from .parallel import _unpinned
+
+        group = _unpinned(group)          # (the default group is addressed as None: nothing here keeps it alive past its destroy)
         self.sae, self.auxk_alpha, self.group = sae, auxk_alpha, group
         self.dead_feature_threshold = dead_feature_threshold
         if lr is None:  # trainer.py:131: 2e-4 scaled by 1/sqrt(N / 2^14)

@@ -29,7 +29,7 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, d
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import synth
     from oracle import oracle
-    from msae.parallel import ShardedSae
+    from msae.parallel import ShardedSae, shutdown
 
     W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
     if cluster:
@@ -62,15 +62,13 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, d
         except RuntimeError as e:
             caught = "different activations" in str(e)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), caught=caught)
-        dist.barrier()
-        dist.destroy_process_group()
+        shutdown(eng)
         return
     out = eng.forward(xt)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(),
              i=out["top_indices"].numpy(), r=out["sae_out"].numpy(), redo=eng.second_round_tokens,
              k_loc=eng.k_loc)
-    dist.barrier()
-    dist.destroy_process_group()
+    shutdown(eng)
 
 
 @pytest.mark.parametrize("T,k,k_loc,cluster", [(13, 8, None, False), (8, 8, None, False),
@@ -147,7 +145,7 @@ def _cand_worker(rank, world, port, T, d, N, k, C, out_dir, cluster):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import synth
     from oracle import oracle
-    from msae.parallel import ShardedSae
+    from msae.parallel import ShardedSae, shutdown
 
     W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
     if cluster:
@@ -200,8 +198,7 @@ def _cand_worker(rank, world, port, T, d, N, k, C, out_dir, cluster):
     out = eng.forward(torch.from_numpy(x))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(), i=out["top_indices"].numpy(),
              r=out["sae_out"].numpy(), fallback=stats["fallback"])
-    dist.barrier()
-    dist.destroy_process_group()
+    shutdown(eng)
 
 
 @pytest.mark.parametrize("T,k,C,cluster", [(13, 8, 8, False), (8, 8, 16, False), (13, 16, 8, True)])
