@@ -26,6 +26,15 @@ still leaves a measured whole-job line ("headline" says which leg the line's val
 Optional real inputs (N = 1): --sae_path <dir with cfg.json + sae.safetensors> and/or
 --acts <file.safetensors holding one [T, d] tensor> replace the synthetic SAE / activations.
 
+Secondary records in the same line (N = 1, synthetic inputs; round-4 verdict items 1, 6): "k256" (the released checkpoint's k on
+the same batch), "zipf" (heavy-tailed feature usage: firing frequency proportional to 1 / rank, a handful of dense features),
+"exact_modes" (ms per step of the fused encode under msae_options::certified / ::exact on the bench batch) and "dither_off"
+(the round-to-nearest statistical mode of ABI 3 beside the dithered default the headline runs).
+
+`main(argv, rt)`: everything device-specific goes through a small runtime object (HipRuntime below); tests/test_bench_dryrun.py
+drives the same control flow -- legs, watchdog, JSON schema -- on CPU over gloo at world 8 with injected kernels, so the first real
+multi-GPU run cannot die in Python (round-4 verdict, item 3).
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -110,23 +119,63 @@ def load_real_inputs(dev, sae_path, acts_path, T):
     return out
 
 
+def host_cpu_info():
+    """(model string, physical cores, logical cpus) of the host (SURVEY 8d asks for both beside the CPU baseline)."""
+    model, phys = None, None
+    try:
+        ids = set()
+        cur = {}
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if ":" not in line:
+                    if "physical id" in cur or "core id" in cur:
+                        ids.add((cur.get("physical id"), cur.get("core id")))
+                    cur = {}
+                    continue
+                key, val = (t.strip() for t in line.split(":", 1))
+                cur[key] = val
+                if key == "model name" and model is None:
+                    model = val
+        if cur and ("physical id" in cur or "core id" in cur):
+            ids.add((cur.get("physical id"), cur.get("core id")))
+        phys = len(ids) or None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model or "unknown", phys or logical, logical
+
+
 def cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, sample_T=256, reps=5):
-    """The reference algorithm on torch-CPU operators (oracle.RefPort), timed on the host cores."""
+    """The reference algorithm on torch-CPU operators (oracle.RefPort), timed on the host cores: threads = the PHYSICAL
+    cores and half of them (hyper-threads and a second socket's NUMA hops do not help an f32 GEMM of this size), best
+    of the two reported, both stated."""
     from oracle import oracle
 
+    model, phys, logical = host_cpu_info()
     port = oracle.RefPort(W_enc.cpu(), b_enc.cpu(), W_dec.cpu(), b_dec.cpu(), k)
     xs = x[:sample_T].cpu()
-    port.forward(xs)  # warm-up
-    times = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        port.forward(xs)
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times))
-    return {"value": sample_T / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    tried = {}
+    prev = torch.get_num_threads()
+    try:
+        for n in sorted({max(1, phys), max(1, phys // 2)}, reverse=True):
+            torch.set_num_threads(n)
+            port.forward(xs)  # warm-up
+            times = []
+            for _ in range(reps if n == phys else max(2, reps // 2)):
+                t0 = time.perf_counter()
+                port.forward(xs)
+                times.append(time.perf_counter() - t0)
+            tried[n] = float(np.median(times))
+    finally:
+        torch.set_num_threads(prev)
+    best = min(tried, key=tried.get)
+    t = tried[best]
+    return {"value": sample_T / t, "unit": "tokens/s", "cores": best, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+            "threads_tried": {str(n): round(sample_T / v, 1) for n, v in tried.items()},
             "sample": f"T={sample_T} tokens of the same workload, median of {reps} calls of "
                       f"RefPort.forward (F.linear+relu, topk, eager scatter+matmul decode), f32, "
-                      f"{t * 1e3:.0f} ms/call"}
+                      f"{t * 1e3:.0f} ms/call with {best} threads"}
 
 
 class ClockSampler:
@@ -186,23 +235,142 @@ class ClockSampler:
                           "step: ~2/3 candidate GEMM at the package power limit, ~1/3 HBM-bound stages at the full clock)"}
 
 
+def csrc_sha16() -> str:
+    """Content hash of the kernel sources (the GPU box has no .git): ties a committed counter file to the tree it measured."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = REPO / "multimodal-sae_amd" / "csrc"
+    for f in sorted(src.glob("*")):
+        if f.suffix in (".hip", ".h", ".sh"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(kernel: str):
     """Counter bytes per launch of the dominant kernel from the COMMITTED PMC summary (separate rocprofv3 --pmc passes
-    of an earlier run of this command, tools/gpu_pmc.sh) -- not measured in this run.  -> (bytes or None, source)."""
+    of an earlier run of this command, tools/gpu_pmc.sh) -- not measured in this run.  The file carries the hash of the
+    csrc/ tree the passes ran on (`_csrc_sha16`, tools/pmc_traffic.py); `stale` says whether the benched tree differs.
+    -> (bytes or None, source, extra fields)."""
     f = REPO / "profiles" / "pmc_traffic.json"
     if f.exists():
         try:
             j = json.loads(f.read_text())
             e = j.get(kernel, {})
             extra = {k: e[k] for k in ("effective_sclk_mhz", "mfma_busy_frac", "duration_ms_in_counter_pass") if k in e}
-            return e.get("bytes_per_launch"), "profiles/pmc_traffic.json" + (
-                "@" + j["_commit"] if "_commit" in j else "") + " (rocprofv3 --pmc passes of an earlier run; L2->fabric bytes, Infinity-Cache hits included)", extra
+            then, now = j.get("_csrc_sha16"), csrc_sha16()
+            extra.update(csrc_sha16_at_counter_pass=then, csrc_sha16_benched=now, stale=(then != now))
+            return e.get("bytes_per_launch"), "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command; L2->fabric bytes, Infinity-Cache hits included)", extra
         except Exception:
             return None, None, {}
     return None, None, {}
 
 
-def main():
+def zipf_bias(x, b_dec, N, k, dev):
+    """Bias schedule of the "zipf" record: feature usage proportional to 1 / rank.  Target firing frequency
+    f_r = min(0.5, c / r), sum_r f_r = k (c = 2.6 at N = 131072, k = 32: five dense features firing on half of the tokens,
+    the top 1 % of the features above 2e-3, the tail below 1e-5 -- the heavy-tailed shape of a trained SAE, against
+    the uniform k / N = 2.4e-4 of random unit rows).  With random unit rows the pre-activation of a token is N(b_n, s^2),
+    s = |x - b_dec| / sqrt(d); a feature fires when it clears the common threshold theta s, so
+    b_n = s (theta - Phi^-1(1 - f_n)), theta = Phi^-1(1 - k / N).  Ranks are spread over the feature axis by a fixed permutation."""
+    a = x.float() - b_dec
+    s = float(a.norm(dim=1).mean()) / a.shape[1] ** 0.5
+    r = torch.arange(1, N + 1, dtype=torch.float64, device=dev)
+    lo, hi = 0.0, 100.0
+    for _ in range(60):                      # c with sum min(0.5, c / r) = k
+        c = 0.5 * (lo + hi)
+        if float(torch.clamp(c / r, max=0.5).sum()) > k:
+            hi = c
+        else:
+            lo = c
+    f = torch.clamp(c / r, max=0.5)
+    theta = float(torch.special.ndtri(torch.tensor(1.0 - k / N, dtype=torch.float64)))
+    b = s * (theta - torch.special.ndtri(1.0 - f))
+    perm = torch.randperm(N, generator=torch.Generator(device=dev).manual_seed(2718), device=dev)
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    out[perm] = b.float()
+    return out
+
+
+class HipRuntime:
+    """Everything of the bench that touches a device or a collective backend.  tests/test_bench_dryrun.py substitutes a CPU /
+    gloo runtime with injected kernels to run main()'s control flow without a GPU."""
+
+    backend = "nccl"            # == RCCL on ROCm
+    dry_run = False
+    d_model, width = D_MODEL, WIDTH
+
+    def device(self, local_rank: int):
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        return dev
+
+    def init_process_group(self, dev):
+        dist.init_process_group(self.backend, device_id=dev)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def clock_sampler(self, dev):
+        return ClockSampler(dev)
+
+    def make_inputs(self, dev, T, d, N, seed=0, rows=None, dec_rows=None):
+        return make_inputs(dev, T, d, N, seed=seed, rows=rows, dec_rows=dec_rows)
+
+    def engine(self, *a, **kw):
+        from msae.parallel import ShardedSae
+
+        return ShardedSae(*a, **kw)
+
+    def stage_profile(self, steps):
+        from msae import ops
+
+        return ops.StageProfile(steps)
+
+    def contexts(self, prof, rows_buf):
+        """context managers active around the timed loop: stage events + per-token re-score statistics"""
+        from msae import ops
+
+        return ops.profiling(prof), ops.rescore_rows(rows_buf)
+
+    def single_gpu_encode(self, x, W_full, b_full, b_dec, k):
+        from msae import ops
+
+        v, i, _ = ops.encode_topk(x, W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
+        return v, i
+
+    def options(self, **kw):
+        """context manager: process defaults of the fused encoder's options for a block (exact / certified / dither)"""
+        import contextlib
+
+        from msae import ops
+
+        @contextlib.contextmanager
+        def cm():
+            prev = (ops._defaults.exact, ops._defaults.dither, getattr(ops._defaults, "certified", False))
+            try:
+                if "exact" in kw:
+                    ops.set_exact(kw["exact"])
+                if "dither" in kw:
+                    ops.set_dither(kw["dither"])
+                if "certified" in kw:
+                    ops.set_certified(kw["certified"])
+                yield
+            finally:
+                ops.set_exact(prev[0])
+                ops.set_dither(prev[1], ops._defaults.dither_seed)
+                if hasattr(ops, "set_certified"):
+                    ops.set_certified(prev[2])
+
+        return cm()
+
+
+def main(argv=None, rt=None):
+    rt = rt or HipRuntime()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -211,12 +379,15 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--batches", type=int, default=4, help="distinct activation batches rotated through the timed loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the k256 / zipf / exact_modes / dither_off records (profiling runs)")
     ap.add_argument("--no-replicas", action="store_true",
                     help="N > 1: skip the second (token-sharded replicas, weak scaling) measurement")
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--sae_path", default=None, help="N = 1: checkpoint dir (cfg.json + sae.safetensors)")
     ap.add_argument("--acts", default=None, help="N = 1: safetensors file with one [T, d] activation tensor")
-    args = ap.parse_args()
+    ap.add_argument("--json-out", default=None, help="also write the JSON line to this file")
+    args = ap.parse_args(argv)
 
     # stdout carries exactly ONE line, the JSON record: whatever a library prints there (RCCL's version banner at
     # communicator creation, for one) goes to stderr instead
@@ -227,19 +398,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = rt.device(local_rank)
     ddp = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev)
+        rt.init_process_group(dev)
 
-    from msae import _hip, ops
-    from msae.parallel import ShardedSae
-
-    lib = _hip.load()
-    T, d, N, k = args.tokens, D_MODEL, WIDTH, args.k
+    T, d, N, k = args.tokens, rt.d_model, rt.width, args.k
     force = os.environ.get("MSAE_FORCE_COLLECTIVES") == "1"      # exercise the RCCL path on a 1-rank group
     sharded = ddp and (world > 1 or force)
     assert N % world == 0, "the feature axis must divide over the ranks"
@@ -252,15 +418,15 @@ def main():
     if sharded:
         # every rank keeps the whole f32 W_enc (2 GiB of 288 GB): the candidate-exchange mode re-scores a token's
         # candidates on the token's owner, and the check below encodes 256 tokens on one GPU
-        W_full, b_full, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=0, rows=(0, N), dec_rows=(0, N))
+        W_full, b_full, W_dec, b_dec, x = rt.make_inputs(dev, T, d, N, seed=0, rows=(0, N), dec_rows=(0, N))
         W_enc, b_enc = W_full[lo:hi], b_full[lo:hi]
-        engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
-                            force_collectives=force)
+        engine = rt.engine(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
+                           force_collectives=force)
         if os.environ.get("MSAE_SHARD_MODE", "both") != "topk":
-            engine_cand = ShardedSae(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
-                                     force_collectives=force, mode="candidates", W_enc_full=W_full, b_enc_full=b_full)
+            engine_cand = rt.engine(W_enc, b_enc, W_dec, b_dec, k, rank=rank, world=world, group=dist.group.WORLD,
+                                    force_collectives=force, mode="candidates", W_enc_full=W_full, b_enc_full=b_full)
     else:
-        W_enc, b_enc, W_dec, b_dec, x = make_inputs(dev, T, d, N, seed=rank)
+        W_enc, b_enc, W_dec, b_dec, x = rt.make_inputs(dev, T, d, N, seed=rank)
         if args.sae_path or args.acts:
             real = load_real_inputs(dev, args.sae_path, args.acts, T)
             if "W_enc" in real:
@@ -271,9 +437,9 @@ def main():
                 x = real["x"]
                 T = x.shape[0]
             elif x.shape[1] != d:
-                _, _, _, _, x = make_inputs(dev, T, d, 8192, seed=rank)
+                _, _, _, _, x = rt.make_inputs(dev, T, d, 8192, seed=rank)
             data = "user-supplied files: " + ", ".join(f"{n}={v}" for n, v in (("sae", args.sae_path), ("acts", args.acts)) if v)
-        engine = ShardedSae(W_enc, b_enc, W_dec, b_dec, k)
+        engine = rt.engine(W_enc, b_enc, W_dec, b_dec, k)
 
     def more_batches(x0, seed0):
         """The timed loop streams DISTINCT activation batches (round-3 verdict: one batch fed to every step keeps its
@@ -282,45 +448,45 @@ def main():
         enough, else reused."""
         if args.acts:
             return [x0]
-        return [x0] + [make_inputs(dev, T, d, 8192, seed=seed0 + 7919 * j)[4] for j in range(1, args.batches)]
+        return [x0] + [rt.make_inputs(dev, T, d, min(N, 8192), seed=seed0 + 7919 * j)[4] for j in range(1, args.batches)]
 
     rows_buf = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
     sampler_out = {}
 
-    def timed(eng, xin, steps, warmup, profile):
+    def timed(eng, xin, steps, warmup, profile, gather=True):
         xs = xin if isinstance(xin, list) else [xin]
         for i in range(warmup):
-            eng.forward(xs[i % len(xs)], async_gather=eng.collective)
+            eng.forward(xs[i % len(xs)], async_gather=eng.collective, gather=gather)
         eng.synchronize()
-        torch.cuda.synchronize()
-        dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(steps)]
+        rt.sync()
+        dec_ev = [(rt.event(), rt.event()) for _ in range(steps)]
         prof = None
         if profile:   # stage events are recorded on the launch stream during the timed region
-            prof = ops.StageProfile(steps)
+            prof = rt.stage_profile(steps)
             eng.decode_events, eng.decode_event_i = dec_ev, 0
         if ddp:
             dist.barrier()
-        torch.cuda.synchronize()
-        sampler = ClockSampler(dev)
+        rt.sync()
+        sampler = rt.clock_sampler(dev)
+        ctx_a, ctx_b = rt.contexts(prof, rows_buf)
         t0 = time.perf_counter()
-        with sampler, ops.profiling(prof), ops.rescore_rows(rows_buf):
+        with sampler, ctx_a, ctx_b:
             for i in range(steps):
-                out = eng.forward(xs[i % len(xs)], async_gather=eng.collective)
+                out = eng.forward(xs[i % len(xs)], async_gather=eng.collective, gather=gather)
             eng.synchronize()
-            torch.cuda.synchronize()
+            rt.sync()
         if ddp:
             dist.barrier()
         el = time.perf_counter() - t0
         sampler_out.clear()
         sampler_out.update(sampler.summary())
         stage, dec_ms = np.zeros((0, 6)), float("nan")
-        if profile:
+        if profile and prof is not None:
             stage = prof.read().astype(np.float64)
             prof.close()
             if eng.decode_event_i:
                 dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev[: eng.decode_event_i]]))
-            eng.decode_events = None
+        eng.decode_events = None
         if ddp:
             tmax = torch.tensor([el], device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -334,13 +500,25 @@ def main():
            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
            "dtype": ("int8" if os.environ.get("MSAE_COARSE", "int8")[0] != "b" else "bf16") +
                     " MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
-           "data": data}
+           "data": data,
+           "dither": "off (round to nearest: statistical contract)" if os.environ.get("MSAE_DITHER", "1")[0] == "0" else
+                     "on (default: stochastically rounded int8 operands, per-call seeds -- the miss bound holds for every input)"}
+    if rt.dry_run:
+        res["dry_run"] = "CPU / gloo with injected kernels: control flow only, no number in this line is a measurement"
+    if ddp:
+        # what the communicator itself reports (the line of a multi-GPU run must show that RCCL really spanned the ranks)
+        res["collective_backend"] = dist.get_backend()
+        res["rccl_world"] = dist.get_world_size()
     emitted = threading.Event()
 
     def emit():
         if rank == 0 and not emitted.is_set():
             emitted.set()
-            print(json.dumps(res), file=json_out, flush=True)
+            line = json.dumps(res)
+            print(line, file=json_out, flush=True)
+            if args.json_out:
+                with open(args.json_out, "w") as fh:
+                    fh.write(line + "\n")
 
     def on_stall():
         res["error"] = f"a collective leg did not finish within {SHARDED_LEG_TIMEOUT_S} s"
@@ -349,16 +527,66 @@ def main():
 
     watchdog = None
     if sharded:
-        watchdog = threading.Timer(SHARDED_LEG_TIMEOUT_S, on_stall)
+        watchdog = threading.Timer(float(os.environ.get("MSAE_BENCH_WATCHDOG_S", SHARDED_LEG_TIMEOUT_S)), on_stall)
         watchdog.daemon = True
         watchdog.start()
 
+    FAIL_KEY, DONE_KEY = "msae_bench_failed", "msae_bench_line_printed"
+
     def fail(msg):
-        """A leg raised on this rank: rank 0 prints what res holds (the last completed leg is its headline); the other
-        ranks are ended by their watchdogs or by the launcher."""
+        """A leg raised on this rank.  Rank 0 prints what res holds (the last completed leg is its headline) and ends the
+        job.  Any other rank tells rank 0 through the rendezvous store (its peers are parked in a collective this rank will
+        never join, and a launcher that sees a rank die kills rank 0 before it can print), then waits to be ended: rank 0's
+        monitor prints the line within seconds; the watchdogs are the backstop."""
         res["error"] = msg
-        emit()
-        os._exit(0 if rank == 0 else 1)
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+        if rank == 0:
+            emit()
+            os._exit(0)
+        t_end = time.time() + float(os.environ.get("MSAE_BENCH_WATCHDOG_S", SHARDED_LEG_TIMEOUT_S)) + 30.0
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.set(FAIL_KEY, msg)
+            while time.time() < t_end and not store.check([DONE_KEY]):
+                time.sleep(0.25)
+        except Exception:  # noqa: BLE001 -- the store lives on rank 0: unreachable means rank 0 has ended
+            pass
+        os._exit(1)
+
+    if sharded and rank == 0:
+        def monitor():
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:  # noqa: BLE001
+                return
+            while not emitted.is_set():
+                try:
+                    if store.check([FAIL_KEY]):
+                        res["error"] = store.get(FAIL_KEY).decode(errors="replace")
+                        emit()
+                        store.set(DONE_KEY, "1")
+                        time.sleep(1.0)             # (the failed rank reads the key and leaves before the store does)
+                        os._exit(0)
+                except Exception:  # noqa: BLE001
+                    return
+                time.sleep(1.0)
+
+        threading.Thread(target=monitor, daemon=True).start()
+
+    def stage_fields(stage, dec_ms, out, kk):
+        """stage clocks + re-score statistics of one timed loop -> dict"""
+        rec = {}
+        if len(stage):
+            rec["stage_ms"] = {n: float(v) for n, v in zip(STAGES, stage.mean(0))}
+            rec["stage_ms"]["decode"] = dec_ms
+        rec["fast_path_verified_frac"] = float((out["status"] == 0).float().mean().item())
+        rb = rows_buf[: out["status"].shape[0]] if out["status"].shape[0] <= rows_buf.shape[0] else rows_buf
+        got = rb[rb > 0]
+        if got.numel():
+            rec["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())
+            rec["rescore_rounds_per_token"] = float(((got >> 24) & 0x3F).float().mean().item())
+            rec["rescore_feature_major"] = bool(((got >> 30) & 1).any().item())
+        return rec
 
     def roofline_fields(stage, dec_ms, out, rows, tokens_decoded, with_traffic):
         mean = stage.mean(0)
@@ -380,21 +608,12 @@ def main():
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": float(mean[3])}
         if pmc_extra:   # from the same committed counter passes: GRBM_GUI_ACTIVE / 8 / the kernel's duration THERE, MFMA-busy share
             res["roofline"]["counter_pass"] = pmc_extra
-        res["stage_ms"] = {n: float(v) for n, v in zip(STAGES, mean)}
-        res["stage_ms"]["decode"] = dec_ms
+        res.update(stage_fields(stage, dec_ms, out, k))
         bytes_dec = tokens_decoded * (k * d * 4 + k * 8 + d * 4)
         # ALGORITHMIC bytes / time: W_dec rows shared by tokens are served by L2 / Infinity Cache, so this can exceed
         # the HBM rate; it is not an HBM measurement (the counter bytes are in profiles/)
         res["decode_algorithmic_gbs"] = {"achieved": bytes_dec / (dec_ms * 1e-3) / 1e9, "unit": "GB/s",
                                          "bytes_per_token": k * d * 4 + k * 8 + d * 4}
-        res["fast_path_verified_frac"] = float((out["status"] == 0).float().mean().item())
-        # msae_options::rows_rescored of the LAST step's encode: f32 rows of W_enc read per verified token (floor: k)
-        rb = rows_buf[: out["status"].shape[0]] if out["status"].shape[0] <= rows_buf.shape[0] else rows_buf
-        got = rb[rb > 0]
-        if got.numel():
-            res["rows_rescored_per_token"] = float((got & 0xFFF).float().mean().item())
-            res["rescore_rounds_per_token"] = float(((got >> 24) & 0x3F).float().mean().item())
-            res["rescore_feature_major"] = bool(((got >> 30) & 1).any().item())
         res["clock"] = dict(sampler_out)
 
     workload = ("BASELINE configs[1]: d_model=%d width=%d k=%d, %%s %s activations/step resident in HBM, %s" % (
@@ -409,15 +628,76 @@ def main():
                            "parallelism": "single GPU", "distinct_batches": len(xs)})
         if len(stage):
             roofline_fields(stage, dec_ms, out, N, T, with_traffic=True)
+        # ---- secondary records (same batches; never the headline).  Each is guarded: a failure is recorded, not raised.
+        if not args.no_secondary and not (args.sae_path or args.acts) and world == 1:
+            sec_steps, sec_warm = max(3, min(args.steps, 10)), 2
+
+            def record(name, fn):
+                try:
+                    res[name] = fn()
+                except Exception as e:  # noqa: BLE001 -- the headline is owed whatever a secondary leg does
+                    res[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+            def run_k256():
+                e2 = rt.engine(W_enc, b_enc, W_dec, b_dec, 256)
+                el, o, st, dm = timed(e2, xs, sec_steps, sec_warm, profile=True)
+                rec = {"k": 256, "ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
+                       "note": "the released 131k checkpoint's k (train/sae/README.md:33-45); same batches"}
+                rec.update(stage_fields(st, dm, o, 256))
+                return rec
+
+            def run_zipf():
+                bz = zipf_bias(xs[0], b_dec, N, k, dev)
+                e3 = rt.engine(W_enc, bz, W_dec, b_dec, k)
+                el, o, st, dm = timed(e3, xs, sec_steps, sec_warm, profile=True)
+                idx = o["top_indices"]
+                counts = torch.bincount(idx.flatten(), minlength=N).float()
+                top1 = counts.sort(descending=True).values[: max(1, N // 100)].sum() / max(1.0, float(counts.sum()))
+                rec = {"ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
+                       "share_of_latents_on_the_top_1pct_features": float(top1),
+                       "features_fired_in_batch": int((counts > 0).sum()),
+                       "note": "heavy-tailed feature usage: firing frequency ~ 1/rank via the encoder bias (zipf_bias), "
+                               "a handful of dense features on ~half of the tokens; weights and batches as the headline"}
+                rec.update(stage_fields(st, dm, o, k))
+                return rec
+
+            def run_modes():
+                out_m = {}
+                for mode in ("certified", "exact"):
+                    try:
+                        with rt.options(**{mode: True}):
+                            el, o, _, _ = timed(engine, xs[:1], 2, 1, profile=False)
+                        out_m[mode] = {"ms_per_step": el / 2 * 1e3,
+                                       "status_0_frac": float((o["status"] == 0).float().mean().item())}
+                    except Exception as e:  # noqa: BLE001
+                        out_m[mode] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                out_m["note"] = ("whole step (encode + decode) under msae_options::certified (two int8 planes per operand, "
+                                 "deterministic band) and ::exact (every token through the f32 MFMA path); the headline is "
+                                 "the default: dithered int8 candidate pass")
+                return out_m
+
+            def run_dither_off():
+                with rt.options(dither="off"):
+                    e4 = rt.engine(W_enc, b_enc, W_dec, b_dec, k)      # (its operands are prepared under the option)
+                    el, o, st, dm = timed(e4, xs, sec_steps, sec_warm, profile=True)
+                rec = {"ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
+                       "note": "msae_options::dither = OFF: round-to-nearest int8 operands, the statistical contract of ABI 3"}
+                rec.update(stage_fields(st, dm, o, k))
+                return rec
+
+            record("k256", run_k256)
+            record("zipf", run_zipf)
+            record("exact_modes", run_modes)
+            record("dither_off", run_dither_off)
     else:
         # ---- leg 0: token-sharded replicas, the reference's own multi-GPU mode (launch/cache/cache.py:66; weak
         # scaling).  Every rank holds the WHOLE SAE and encodes its own batch; no data-path collective, so nothing in
         # it can wedge.  It is the PROVISIONAL headline: if a feature-sharded leg below raises or stalls on this node,
         # the printed line still carries a measured whole-job number and names the leg that failed.
         if not args.no_replicas:
-            _, _, _, _, x_own = make_inputs(dev, T, d, 8192, seed=1 + rank)        # this rank's own batches
+            _, _, _, _, x_own = rt.make_inputs(dev, T, d, min(N, 8192), seed=1 + rank)        # this rank's own batches
             x_own = more_batches(x_own, 1 + rank)
-            rep = ShardedSae(W_full, b_full, W_dec, b_dec, k)
+            rep = rt.engine(W_full, b_full, W_dec, b_dec, k)
             el_r, out_r, stage_r, dec_r = timed(rep, x_own, args.steps, args.warmup, profile=True)
             del rep, x_own
             par = f"dp{world}: token-sharded replicas, {T} tokens/step/GPU, no data-path collective"
@@ -436,8 +716,9 @@ def main():
         shard_modes = res["shard_modes"] = {}
         xs = more_batches(x, 0)                      # the same batches on every rank
         x_last = xs[(args.steps - 1) % len(xs)]      # the batch of the step whose outputs are checked
-        chk_v, chk_i, _ = ops.encode_topk(x_last[:256], W_full, b_full, b_dec, ops.prepare_encoder(W_full), k)
-        same = lambda o: bool(torch.equal(chk_i, o["top_indices"][:256]) and torch.equal(chk_v, o["top_acts"][:256]))
+        n_chk = min(256, T)
+        chk_v, chk_i = rt.single_gpu_encode(x_last[:n_chk], W_full, b_full, b_dec, k)
+        same = lambda o: bool(torch.equal(chk_i, o["top_indices"][:n_chk]) and torch.equal(chk_v, o["top_acts"][:n_chk]))
         best = None
         legs = [("per_shard_topk", engine, "per-shard exact top-%d, RCCL all-gather + merge" % engine.k_loc)]
         if engine_cand is not None:
@@ -468,6 +749,15 @@ def main():
                                                   f"reconstruction"})
                 if len(st):
                     roofline_fields(st, dm, o, n_loc, -(-T // world), with_traffic=False)
+            # beside the timed step, never inside it: the same leg with the reconstruction left token-sharded (what a
+            # token-sharded consumer needs: no 16 KiB/token all-gather), and each collective of the step on its own
+            try:
+                el_n, _, _, _ = timed(eng, xs, args.steps, min(args.warmup, 2), profile=False, gather=False)
+                shard_modes[name]["ms_per_step_no_recon_gather"] = el_n / args.steps * 1e3
+                shard_modes[name]["collective_ms"] = {a: round(b, 4) for a, b in
+                                                      eng.time_collectives(T, d, steps=5, sync=rt.sync).items()}
+            except Exception as e:  # noqa: BLE001
+                shard_modes[name]["side_measurements_error"] = f"rank {rank}: {type(e).__name__}: {e}"[:300]
         if best is None:
             res["sharded_bit_identical_to_single_gpu_on_256_tokens"] = False
             res["error"] = ("no feature-sharded leg reproduced the single-GPU encode on this node" +
@@ -476,14 +766,15 @@ def main():
                 m = shard_modes["per_shard_topk"]
                 res.update(value=T / (m["ms_per_step"] * 1e-3), ms_per_step=m["ms_per_step"], scaling="strong")
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.sae_path or args.acts):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.sae_path or args.acts) and not rt.dry_run:
         res["cpu_baseline"] = cpu_baseline(W_enc, b_enc, W_dec, b_dec, x, k, args.cpu_sample)
     emit()
     if ddp:
-        dist.barrier()
         if watchdog is not None:
             watchdog.cancel()
-        dist.destroy_process_group()
+        from msae.parallel import shutdown
+
+        shutdown(engine, engine_cand)
 
 
 if __name__ == "__main__":

@@ -173,6 +173,7 @@ class ShardedSae:
         self.decode_events = None
         self.decode_event_i = 0
         self._pending = None
+        self._recon_bufs: dict = {}
         self._second_round = None     # device-side count of second-round tokens (read by the property only)
         if k_loc is None:
             k_loc = default_k_loc(k, world) if self.collective else k
@@ -468,9 +469,20 @@ class ShardedSae:
         if not gather:
             return local
         d = local.shape[-1]
-        pad = torch.zeros(per, d, dtype=local.dtype, device=local.device)
-        pad[: hi - lo] = local
-        full = torch.empty(self.world * per, d, dtype=local.dtype, device=local.device)
+        # send / receive buffers from a ring of two per shape (round-4 verdict: a 128-MiB `full` + `pad` were allocated in
+        # every call): the reconstruction returned by call i stays valid until call i + 2 overwrites it -- a streaming loop
+        # consumes it before that, and the asynchronous gather of call i is joined at the top of call i + 1 (decode)
+        key = (per, d, local.dtype, local.device)
+        ring = self._recon_bufs.get(key)
+        if ring is None:
+            if len(self._recon_bufs) > 4:
+                self._recon_bufs.clear()
+            ring = self._recon_bufs[key] = [[torch.zeros(per, d, dtype=local.dtype, device=local.device),
+                                             torch.empty(self.world * per, d, dtype=local.dtype, device=local.device)]
+                                            for _ in range(2)] + [0]
+        pad, full = ring[ring[2]]
+        ring[2] ^= 1
+        pad[: hi - lo] = local                   # (rows beyond this rank's slice stay zero from the allocation)
         work = dist.all_gather_into_tensor(full, pad, group=self.group, async_op=async_gather)
         if async_gather:
             self._pending = (work, pad, full)        # keep the buffers alive until joined
@@ -489,19 +501,66 @@ class ShardedSae:
         self.synchronize()
         self.group = None
 
-    def forward(self, x: Tensor, async_gather: bool = False) -> dict:
+    def forward(self, x: Tensor, async_gather: bool = False, gather: bool = True) -> dict:
+        """encode -> decode.  gather=False leaves the reconstruction token-sharded (`sae_out` = this rank's
+        [T/G, d] slice: what a consumer that is itself token-sharded needs -- the caching path; no 16 KiB/token
+        all-gather)."""
         if self.collective and self.mode == "candidates" and x.shape[0] > self.local_decode_max_t:
             # the owner already holds its tokens' results: decode them while the result gather is in flight
             x = self._same_input(x)
             got = self._encode_candidates(x)
             if got is not None:
                 join, (lv, li), _keep = got
-                recon = self._decode_local(lv, li, x.shape[0], async_gather=async_gather)
+                recon = self._decode_local(lv, li, x.shape[0], gather=gather, async_gather=async_gather and gather)
                 vals, idx, status = join()
                 return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
         vals, idx, status = self.encode(x)
-        recon = self.decode(vals, idx, async_gather=async_gather)
+        recon = self.decode(vals, idx, gather=gather, async_gather=async_gather and gather)
         return {"sae_out": recon, "top_acts": vals, "top_indices": idx, "status": status}
+
+    def time_collectives(self, T: int, d: int, steps: int = 5, sync: Optional[Callable] = None) -> dict:
+        """Wall-clock milliseconds per call of each collective of one step, at this engine's sizes, run back to back on
+        otherwise idle devices (bench.py's per-leg `collective_ms`; every rank must call it).  Not part of any timed step."""
+        import time
+
+        if not self.collective:
+            return {}
+        dev = self.W_dec.device
+        sync = sync or ((lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None))
+        G = self.world
+        lo, hi, per = token_slice(T, self.rank, G)
+        out = {}
+
+        def clock(name, fn):
+            fn(); sync()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            sync()
+            out[name] = (time.perf_counter() - t0) / steps * 1e3
+
+        if self.mode == "candidates":
+            stride = 12 * self.n_cand + 8
+            send = torch.zeros(G, per, stride, dtype=torch.uint8, device=dev)
+            recv = torch.empty_like(send)
+            clock("all_to_all_records", lambda: dist.all_to_all_single(recv, send, group=self.group))
+            pack = torch.zeros(per, 2 * self.k + 1, dtype=torch.int32, device=dev)
+            fullp = torch.empty(G * per, 2 * self.k + 1, dtype=torch.int32, device=dev)
+            clock("all_gather_results", lambda: dist.all_gather_into_tensor(fullp, pack, group=self.group))
+        else:
+            p1 = torch.zeros(2, T, self.k_loc, dtype=torch.int32, device=dev)
+            f1 = torch.empty(2 * G, T, self.k_loc, dtype=torch.int32, device=dev)
+            clock("all_gather_pairs", lambda: dist.all_gather_into_tensor(f1, p1, group=self.group))
+            if self.k_loc < self.k_full:
+                p2 = torch.zeros(2, T, self.k_full, dtype=torch.int32, device=dev)
+                f2 = torch.empty(2 * G, T, self.k_full, dtype=torch.int32, device=dev)
+                clock("all_gather_second_round", lambda: dist.all_gather_into_tensor(f2, p2, group=self.group))
+        if T > self.local_decode_max_t:
+            pad = torch.zeros(per, d, dtype=torch.float32, device=dev)
+            full = torch.empty(G * per, d, dtype=torch.float32, device=dev)
+            clock("all_gather_reconstruction", lambda: dist.all_gather_into_tensor(full, pad, group=self.group))
+        return out
 
 
 class EmulatedShardGroup:

@@ -744,6 +744,11 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     assert modes["per_shard_topk"]["bit_identical_256"] is True
     assert modes["candidate_exchange"]["bit_identical_256"] is True
     assert "error" not in res["replicas"] and res["replicas"]["value"] > 0 and res["replicas"]["scaling"] == "weak"
+    # round 5: what the communicator reports, each collective of a step on its own, the leg without the reconstruction gather
+    assert res["collective_backend"] == "nccl" and res["rccl_world"] == 1
+    assert {"all_gather_pairs", "all_gather_reconstruction"} <= set(modes["per_shard_topk"]["collective_ms"])
+    assert {"all_to_all_records", "all_gather_results"} <= set(modes["candidate_exchange"]["collective_ms"])
+    assert modes["per_shard_topk"]["ms_per_step_no_recon_gather"] > 0
 
 
 @pytest.mark.parametrize("G", [2, 4, 8])

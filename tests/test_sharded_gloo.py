@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, diverge=False):
+def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, diverge=False, edits=None):
     for p in (REPO, REPO / "tests", REPO / "multimodal-sae_amd"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -39,8 +39,11 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, d
     n_loc = N // world
     lo, hi = rank * n_loc, (rank + 1) * n_loc
 
-    def encode_fn(xt, kk):
-        v, i = oracle.encode_topk(xt.numpy(), W_enc[lo:hi], b_enc[lo:hi], b_dec, kk)
+    def encode_fn(xt, kk, set_feature=-1, set_value=0.0, zero_feature=-1):
+        # an injected encode_fn receives the hooks' GLOBAL feature ids (the product's default one maps them itself)
+        loc = lambda f: f - lo if lo <= f < hi else -1
+        v, i = oracle.encode_topk(xt.numpy(), W_enc[lo:hi], b_enc[lo:hi], b_dec, kk, set_feature=loc(set_feature),
+                                  set_value=set_value, zero_feature=loc(zero_feature))
         return torch.from_numpy(v), torch.from_numpy(i).long(), torch.zeros(len(v), dtype=torch.int32)
 
     def decode_fn(idx, vals):
@@ -64,7 +67,14 @@ def _worker(rank, world, port, T, d, N, k, out_dir, k_loc=None, cluster=False, d
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), caught=caught)
         shutdown(eng)
         return
-    out = eng.forward(xt)
+    if edits:
+        assert not xt.requires_grad
+        keep = xt.clone()
+        v, i, _ = eng.encode(xt, **edits)
+        assert torch.equal(xt, keep)            # the caller's activations are never written (broadcast_input: private buffer)
+        out = {"top_acts": v, "top_indices": i, "sae_out": eng.decode(v, i)}
+    else:
+        out = eng.forward(xt)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(),
              i=out["top_indices"].numpy(), r=out["sae_out"].numpy(), redo=eng.second_round_tokens,
              k_loc=eng.k_loc)
@@ -96,6 +106,40 @@ def test_feature_sharded_equals_single_shard(tmp_path, T, k, k_loc, cluster):
         assert np.array_equal(g["r"], ref_r)
         if cluster:
             assert int(g["redo"]) > 0 and int(g["k_loc"]) == k_loc   # the second round really ran
+
+
+@pytest.mark.parametrize("world,T,k,k_loc,cluster,edits,diverge", [
+    (4, 5, 8, None, False, None, False),
+    (4, 257, 16, 6, True, None, False),                      # forced second round, T % G != 0
+    (8, 1, 8, None, False, None, False),                     # T < G: seven ranks own no token of the decode
+    (8, 13, 16, 4, True, None, False),
+    (8, 16, 8, None, False, {"set_feature": 777, "set_value": 9.5, "zero_feature": 130}, True),   # hook edits + broadcast_input
+    (4, 13, 8, 3, True, {"zero_feature": 5}, False),
+])
+def test_feature_sharded_world_4_and_8(tmp_path, world, T, k, k_loc, cluster, edits, diverge):
+    """Round-4 verdict, item 3: the per-shard top-k scheme over gloo at world 4 and 8 -- token counts below G and not
+    divisible by G (ranks with an empty token slice in the sharded decode), the truncated lists with a forced second round,
+    the hooks' edits by global feature id, broadcast_input with diverged ranks: every rank's merged result and reconstruction
+    equal the single-shard oracle bit for bit."""
+    import synth
+    from oracle import oracle
+
+    d, N = 64, 1024
+    mp.spawn(_worker, args=(world, _free_port(), T, d, N, k, str(tmp_path), k_loc, cluster, diverge, edits),
+             nprocs=world, join=True)
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0
+    x = synth.activations(T, d, seed=32)
+    ref_v, ref_i = oracle.encode_topk(x, W_enc, b_enc, b_dec, k, **(edits or {}))
+    ref_r = oracle.decode(ref_i, ref_v, W_dec, b_dec)
+    for rank in range(world):
+        g = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(g["i"], ref_i), f"rank {rank}: merged indices differ"
+        assert np.array_equal(g["v"], ref_v) and np.array_equal(g["r"], ref_r), rank
+        if cluster and k_loc is not None:
+            assert int(g["redo"]) > 0 and int(g["k_loc"]) == max(k_loc, -(-k // world))
 
 
 def test_broadcast_input_makes_diverged_ranks_agree(tmp_path, monkeypatch):
@@ -199,6 +243,28 @@ def _cand_worker(rank, world, port, T, d, N, k, C, out_dir, cluster):
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), v=out["top_acts"].numpy(), i=out["top_indices"].numpy(),
              r=out["sae_out"].numpy(), fallback=stats["fallback"])
     shutdown(eng)
+
+
+@pytest.mark.parametrize("world,T,k,C,cluster", [(4, 5, 8, 8, False), (4, 257, 16, 8, True), (8, 1, 8, 8, False),
+                                                 (8, 13, 16, 8, True), (8, 16, 8, 16, False)])
+def test_candidate_exchange_world_4_and_8(tmp_path, world, T, k, C, cluster):
+    """mode="candidates" over gloo at world 4 and 8: the all-to-all's padded token slices (T = 1: seven ranks re-score
+    nothing; 13 and 257 do not divide), the result all-gather, owners whose lists overflow (cluster)."""
+    import synth
+    from oracle import oracle
+
+    d, N = 64, 1024
+    mp.spawn(_cand_worker, args=(world, _free_port(), T, d, N, k, C, str(tmp_path), cluster), nprocs=world, join=True)
+    W_enc, b_enc, W_dec, b_dec = synth.sae_weights(d, N, seed=31)
+    if cluster:
+        b_enc = b_enc.copy()
+        b_enc[: N // world // 4] += 3.0
+    x = synth.activations(T, d, seed=32)
+    ref_v, ref_i = oracle.encode_topk(x, W_enc, b_enc, b_dec, k)
+    ref_r = oracle.decode(ref_i, ref_v, W_dec, b_dec)
+    for rank in range(world):
+        g = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(g["i"], ref_i) and np.array_equal(g["v"], ref_v) and np.array_equal(g["r"], ref_r), rank
 
 
 @pytest.mark.parametrize("T,k,C,cluster", [(13, 8, 8, False), (8, 8, 16, False), (13, 16, 8, True)])

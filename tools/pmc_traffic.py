@@ -45,5 +45,13 @@ if len(sys.argv) > 3:
             out[name].update(effective_sclk_mhz=cyc / (ms * 1e3), grbm_cycles_per_xcd=cyc, duration_ms_in_counter_pass=ms)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in d[ks[0]]:
                 out[name]["mfma_busy_frac"] = d[ks[0]]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * cyc)
+# the tree the counter passes ran on (bench.py compares it with the tree it benches: roofline.counter_pass.stale)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    out["_csrc_sha16"] = bench.csrc_sha16()
+except Exception as e:  # noqa: BLE001
+    out["_csrc_sha16"] = None
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
