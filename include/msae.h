@@ -110,6 +110,17 @@ enum {
  *                 Outputs of verified tokens do not depend on the seeds (they are the exact path's bits); which tokens fall
  *                 back may.  Costs ~sqrt(3) of band width: measured rows re-scored per token and step time in DESIGN.md
  *                 section 5.  Applies to the int8 pass (all batch sizes); the bf16 pass keeps its statistical model.
+ *   certified     (ABI 4) != 0: msae_encode_topk[_i64] runs the CERTIFIED candidate pass: both operands as two int8 planes
+ *                 (15 bits; x_lo.W_hi + x_hi.W_lo, a rounded shift by 7, then x_hi.W_hi in one int32 accumulator -- three
+ *                 times the MFMA work of the default pass) and a DETERMINISTIC error band: Cauchy-Schwarz bounds of every
+ *                 dropped term (the planes' rounding residuals, the lo.lo product, the shift's rounding, the f32 chain's own
+ *                 gamma_d, the f32 evaluation of the bound), evaluated per (token, feature) from exact norms
+ *                 (csrc/encode_cert.h derives it).  No probability and no assumption about the data is left: for EVERY input a
+ *                 token reported status 0 carries exactly the exact path's top-k.  ~3x the default's step time on the bench
+ *                 batch, ~9x faster than `exact`.  Needs `certified_operands` = the buffer of
+ *                 msae_encoder_prepare_certified (2 d bytes per feature); `prepared` may be NULL.  Massive-activation dims have
+ *                 no separate tile here: a token whose largest dim dwarfs the rest by > ~100x gets a wide band and ends in the
+ *                 in-call exact path (time, never a wrong answer).  Shapes without the pass (d % 128, N % 8192) run the exact path.
  *   dither_seed   (ABI 4) 0: the library draws a seed per call (process-random base + atomic counter through a 64-bit
  *                 mixer -- the one piece of process state the library keeps); != 0: the seed of THIS call (reproducible
  *                 candidate sets: tests, A/B runs). */
@@ -126,6 +137,9 @@ typedef struct msae_options {
   int32_t dither;         /* MSAE_DITHER_* (ABI 3: reserved, 0) */
   int32_t *rows_rescored; /* device int32[T] or NULL */
   uint64_t dither_seed;   /* 0 = drawn by the library */
+  int32_t certified;      /* 0 / 1 (ABI 4) */
+  int32_t reserved2;      /* 0 */
+  const void *certified_operands;   /* device buffer of msae_encoder_prepare_certified, or NULL */
 } msae_options;
 /* Fills *opts with the defaults (coarse_mode MSAE_COARSE_DEFAULT, guard_z 0, no detail, no profile). */
 void msae_options_init(msae_options *opts);
@@ -160,6 +174,11 @@ int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void 
  * msae_encoder_prepare = NULL options = the defaults: dithered with a drawn seed).  Two prepares with the same non-zero seed
  * build identical operands. */
 int msae_encoder_prepare_opts(const float *W_enc, int N, int d, void *prepared, const msae_options *opts, void *stream);
+/* Operands of the certified pass (msae_options::certified): two int8 planes of every row of W_enc (tile-major), the rows'
+ * exact norms for the deterministic band, and the biases rounded up by 2^-20 |b| (b_enc may be NULL = zeros).  Once per weight
+ * (and bias) load; msae_encoder_certified_bytes(N, d) bytes (0: the shape has no certified pass -- MSAE_ENOTIMPL here). */
+size_t msae_encoder_certified_bytes(int N, int d);
+int msae_encoder_prepare_certified(const float *W_enc, const float *b_enc, int N, int d, void *operands, void *stream);
 /* Same buffer after a weight update (one training step): rebuilds only the operands that the coarse
  * mode of `opts` reads -- the other mode's operands go stale, so call msae_encoder_prepare again before
  * encoding in the other mode. */

@@ -1,0 +1,218 @@
+// encode_cert.h -- the CERTIFIED candidate pass of the fused encoder (msae_options::certified; round-4 verdict, item 1b): both
+// operands as TWO int8 planes (15 bits), three MFMA segments, a DETERMINISTIC error band.  Host dispatch: encode_fused.hip
+// (run_cert); the GEMM is gemm_mfma.h's kernel with GemmOperands::cert set.
+//
+// Operands.  a_c = sxf (X_c + dx_c),  X_c = 128 xh_c + xl_c  (xh in [-127, 127], xl in [-64, 63], |dx_c| <= 1/2 + 2e-3)
+//            w_c = swf (W_c + dw_c),  W_c = 128 wh_c + wl_c  likewise, per feature row,
+// sxf = max|a_t| / 16319, swf = max|W_n| / 16319.  The real-number dot product is
+//   r = sum a_c w_c = sxf swf [ 16384 hh + 128 (hl + lh) + ll + sum dx_c W_c + sum X_c dw_c + sum dx_c dw_c ],
+// hh = sum xh wh etc.  The GEMM accumulates  acc = hh + rshift7_round(hl + lh)  in int32 -- segment 1: x_lo x W_hi, segment 2:
+// x_hi x W_lo, then acc = (acc + 64) >> 7, then segment 3: x_hi x W_hi -- so with sx = 128 sxf, sw = 128 swf (the hi planes' steps)
+//   v = float(acc) sx sw + b      and      |r + b - v| <= sxf swf [ |ll| + 8192 + |dx . W| + |X . dw| + |dx . dw| ] + (f32 roundings).
+// The EXACT pre-activation p of the contract is the ascending-k f32 fma chain, |p - (r + b)| <= gamma_(d+2) (|a| . |w|) + 2^-24 |b|.
+// Cauchy-Schwarz on every term gives a bound that is a sum of (per-token) x (per-feature) products,
+//   X = A_t (swf |dw_n| + g |W_n|_f32)                      A_t = max(|a_t|, sxf |X_t|),  g = max(d + 8, 1024) 2^-24
+//   Y = sxf |dx_t| . swf (|W_n|_int + |dw_n|)
+//   Z = sxf 64 sqrt(d) . swf (|wl_n| + 8192 / (64 sqrt(d)))        (|xl_t| <= 64 sqrt(d))
+// and (X + Y + Z)^2 <= 3 (X^2 + Y^2 + Z^2), which is exactly the three-term form the kernels already evaluate
+//   band^2 = P_t Q_n + R_t (Si_n + M_t^2 So_n),  R_t = sx_t^2 zzx:
+//   P_t = 3 A_t^2,  Q_n = (swf |dw_n| + g |W_n|)^2,   zzx = 3 / 16384 (R_t = 3 sxf^2),
+//   M_t = |dx_t|,   So_n = (swf (|W_n|_int + |dw_n|))^2,   Si_n = (64 sqrt(d) swf |wl_n| + 8192 swf)^2,
+// every factor inflated by CERT_SLACK for the f32 evaluation of the norms and of the band itself; the roundings that scale with
+// |b_n| (the bias add of p and of v) are covered by handing the GEMM the bias b_n + 2^-20 |b_n| (upper values a hair higher).
+// No assumption about the data is left: a feature with p >= v_k has u = v + band >= p >= v_k and is re-scored, whatever the
+// weights and activations are.  Massive-activation dims get no tile of their own here -- a token whose largest dim dwarfs the
+// rest by more than ~100x has a wide band (sxf grows with it), many rows to re-score, and in the end the in-call exact path:
+// time, never a wrong answer.
+#pragma once
+#include "encode_defs.h"
+
+namespace {
+
+constexpr unsigned CERT_MAGIC = 0x4D534143u;   // "MSAC"
+constexpr float CERT_SLACK = 1.004f;
+constexpr float CERT_ZZX = 3.f / 16384.f;
+constexpr int CERT_QMAX = 16319;
+
+// certified operand buffer: 256-B header | b_up f32 [N] | colc f32x4 [N] (feature order) | colc main-row order [N - S] |
+// colc sample order [S] | W planes tile-major, main rows [(N - S) / 256][2 nkd][256][128 B] (k-tile index: plane * nkd + kt,
+// plane 0 = lo, 1 = hi) | W planes tile-major, sample rows [S / 256][2 nkd][256][128 B]
+struct CertPrepared {
+  unsigned magic;
+  int N, d, S;
+  size_t off_bup, off_colc, off_colc_p, off_colc_s, off_w, off_ws, bytes;
+};
+inline bool cert_shape_ok(int N, int d) { return i8_shape_ok(N, d) && d <= 65536; }
+inline CertPrepared make_cert_prepared(int N, int d) {
+  CertPrepared p{};
+  p.magic = CERT_MAGIC; p.N = N; p.d = d; p.S = N / SAMPLE_STRIDE;
+  size_t o = 256;
+  auto take = [&](size_t b) { size_t at = o; o += msae_align_up(b, 256); return at; };
+  p.off_bup = take((size_t)N * 4);
+  p.off_colc = take((size_t)N * 16);
+  p.off_colc_p = take((size_t)(N - p.S) * 16);
+  p.off_colc_s = take((size_t)p.S * 16);
+  p.off_w = take((size_t)(N - p.S) * d * 2);
+  p.off_ws = take((size_t)p.S * d * 2);
+  p.bytes = o;
+  return p;
+}
+
+// two-plane split of a 15-bit integer
+__device__ __forceinline__ void cert_split(int q, int &hi, int &lo) {
+  hi = (q + 64) >> 7;
+  lo = q - hi * 128;
+}
+
+// ---- W side (once per weight load): one 256-thread workgroup per feature row -------------------------------------------
+__global__ __launch_bounds__(256) void cert_prepare_rows_kernel(const float *__restrict__ W, const float *__restrict__ b_enc,
+                                                                int N, int d, float *__restrict__ b_up,
+                                                                f32x4 *__restrict__ colc, f32x4 *__restrict__ colc_p,
+                                                                f32x4 *__restrict__ colc_s, signed char *__restrict__ wp,
+                                                                signed char *__restrict__ wsp) {
+  __shared__ float red[5][4];
+  const int n = blockIdx.x;
+  const float *row = W + (size_t)n * d;
+  float m = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  __syncthreads();
+  const float swf = m > 0.f ? m / (float)CERT_QMAX : 1.f;
+  const float inv = 1.f / swf;
+  const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
+  const size_t prow = samp ? (size_t)(n / SAMPLE_STRIDE) : (size_t)main_row(n);
+  signed char *dst = samp ? wsp : wp;
+  float s_w2 = 0.f, s_q2 = 0.f, s_l2 = 0.f, s_e2 = 0.f;
+  for (int c = threadIdx.x * 16; c < d; c += 4096) {
+    i32x4 ph, pl;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q4);
+      unsigned wh = 0, wl = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = v[e] * inv;
+        int q = (int)rintf(sv);
+        q = q > CERT_QMAX ? CERT_QMAX : (q < -CERT_QMAX ? -CERT_QMAX : q);
+        int hi, lo;
+        cert_split(q, hi, lo);
+        const float eps = sv - (float)q, fq = (float)q, fl = (float)lo;
+        s_w2 = __builtin_fmaf(v[e], v[e], s_w2);
+        s_q2 = __builtin_fmaf(fq, fq, s_q2);
+        s_l2 = __builtin_fmaf(fl, fl, s_l2);
+        s_e2 = __builtin_fmaf(eps, eps, s_e2);
+        wh |= ((unsigned)hi & 0xFFu) << (8 * e);
+        wl |= ((unsigned)lo & 0xFFu) << (8 * e);
+      }
+      ph[q4] = (int)wh; pl[q4] = (int)wl;
+    }
+    // row `prow` of the operand whose rows hold 2 d bytes: plane 0 (lo) at columns [0, d), plane 1 (hi) at [d, 2 d)
+    *reinterpret_cast<i32x4 *>(dst + packed_off(prow, c, 2 * d)) = pl;
+    *reinterpret_cast<i32x4 *>(dst + packed_off(prow, d + c, 2 * d)) = ph;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_w2 += __shfl_xor(s_w2, off, 64); s_q2 += __shfl_xor(s_q2, off, 64);
+    s_l2 += __shfl_xor(s_l2, off, 64); s_e2 += __shfl_xor(s_e2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[1][threadIdx.x >> 6] = s_w2; red[2][threadIdx.x >> 6] = s_q2; red[3][threadIdx.x >> 6] = s_l2; red[4][threadIdx.x >> 6] = s_e2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float w2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), q2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float l2 = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]), e2 = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+    const float sd = __builtin_sqrtf((float)d);
+    // |dw| as computed carries the rounding of v * inv (<= 2e-3 per element at |sv| <= 16319): + 2e-3 sqrt(d)
+    const float ne = (__builtin_sqrtf(e2) + 2e-3f * sd) * CERT_SLACK;
+    const float nw = __builtin_sqrtf(w2) * CERT_SLACK, nq = __builtin_sqrtf(q2) * CERT_SLACK, nl = __builtin_sqrtf(l2) * CERT_SLACK;
+    const float g = (float)(d + 8 > 1024 ? d + 8 : 1024) * 5.9604645e-8f;   // (floor: the f32 compare of u with tau, see header)
+    const float bq = (swf * ne + g * nw) * CERT_SLACK;
+    const float bs = swf * (nq + ne) * CERT_SLACK;
+    const float bi = swf * (64.f * sd * nl + 8192.f) * CERT_SLACK;
+    const f32x4 cc = {128.f * swf, bq * bq, bi * bi, bs * bs};   // (sw, Q, Si, So)
+    colc[n] = cc;
+    if (samp) colc_s[n / SAMPLE_STRIDE] = cc; else colc_p[main_row(n)] = cc;
+    const float b = b_enc ? b_enc[n] : 0.f;
+    b_up[n] = b + 9.5367432e-7f * fabsf(b);                       // + 2^-20 |b|: the roundings of the bias adds of p and of v
+  }
+}
+
+// ---- x side (every call): one 256-thread workgroup per token row of the padded tile -------------------------------------
+// a32 holds x - b_dec (prep_x_kernel).  rowc[t] = (sx = 128 sxf, M = |dx_t|, P = 3 A_t^2, flag)
+__global__ __launch_bounds__(256) void cert_quant_x_kernel(const float *__restrict__ a32, int T, int d,
+                                                           signed char *__restrict__ xp, f32x4 *__restrict__ rowc,
+                                                           const unsigned *__restrict__ magic) {
+  __shared__ float red[4][4];
+  const int t = blockIdx.x;
+  if (t >= T) {
+    for (int c = threadIdx.x * 16; c < 2 * d; c += 4096)
+      *reinterpret_cast<i32x4 *>(xp + packed_off((size_t)t, c, 2 * d)) = i32x4{0, 0, 0, 0};
+    if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float *row = a32 + (size_t)t * d;
+  float m = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  __syncthreads();
+  const float sxf = m > 0.f ? m / (float)CERT_QMAX : 1.f;
+  const float inv = 1.f / sxf;
+  float s_a2 = 0.f, s_q2 = 0.f, s_e2 = 0.f;
+  for (int c = threadIdx.x * 16; c < d; c += 4096) {
+    i32x4 ph, pl;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c + 4 * q4);
+      unsigned wh = 0, wl = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sv = v[e] * inv;
+        int q = (int)rintf(sv);
+        q = q > CERT_QMAX ? CERT_QMAX : (q < -CERT_QMAX ? -CERT_QMAX : q);
+        int hi, lo;
+        cert_split(q, hi, lo);
+        const float eps = sv - (float)q, fq = (float)q;
+        s_a2 = __builtin_fmaf(v[e], v[e], s_a2);
+        s_q2 = __builtin_fmaf(fq, fq, s_q2);
+        s_e2 = __builtin_fmaf(eps, eps, s_e2);
+        wh |= ((unsigned)hi & 0xFFu) << (8 * e);
+        wl |= ((unsigned)lo & 0xFFu) << (8 * e);
+      }
+      ph[q4] = (int)wh; pl[q4] = (int)wl;
+    }
+    *reinterpret_cast<i32x4 *>(xp + packed_off((size_t)t, c, 2 * d)) = pl;
+    *reinterpret_cast<i32x4 *>(xp + packed_off((size_t)t, d + c, 2 * d)) = ph;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_a2 += __shfl_xor(s_a2, off, 64); s_q2 += __shfl_xor(s_q2, off, 64); s_e2 += __shfl_xor(s_e2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[1][threadIdx.x >> 6] = s_a2; red[2][threadIdx.x >> 6] = s_q2; red[3][threadIdx.x >> 6] = s_e2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), q2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float e2 = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+    const float sd = __builtin_sqrtf((float)d);
+    const float A = fmaxf(__builtin_sqrtf(a2), sxf * __builtin_sqrtf(q2)) * CERT_SLACK;
+    const float M = (__builtin_sqrtf(e2) + 2e-3f * sd) * CERT_SLACK;
+    // a certified buffer that is not one (wrong pointer, never prepared): every token to the exact path
+    rowc[t] = f32x4{128.f * sxf, M, 3.f * A * A * CERT_SLACK, *magic == CERT_MAGIC ? 0.f : 1.f};
+  }
+}
+
+}  // namespace

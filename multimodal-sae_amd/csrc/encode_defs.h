@@ -98,6 +98,8 @@ struct CallOpts {
   // Stochastic rounding of the int8 operands (msae_options::dither): seed != 0 <=> on.  The seed of THIS call: the caller's, or
   // drawn here (draw_seed) -- activations are rounded with it in an encode, the weights in a prepare / refresh.
   unsigned long long seed;
+  int cert;              // msae_options::certified: two-plane operands, deterministic band (encode_cert.h)
+  const void *cert_ops;  // ... and msae_encoder_prepare_certified's buffer
 };
 // 64-bit finaliser of splitmix64 (also the device-side hash of the dither, encode_prep.h)
 __host__ __device__ inline unsigned long long mix64(unsigned long long z) {
@@ -118,6 +120,7 @@ inline unsigned long long draw_seed() {
 }
 inline bool resolve_opts(const msae_options *o, CallOpts &c) {
   c.mode = -1; c.z = 0.f; c.detail = 0; c.prof = nullptr; c.exact = 0; c.rows_out = nullptr; c.seed = 0ull;
+  c.cert = 0; c.cert_ops = nullptr;
   int dither = 0;
   if (o) {
     // `size` is the caller's sizeof: a caller compiled against ABI 2's header (no `exact`) is served with exact = 0
@@ -128,6 +131,10 @@ inline bool resolve_opts(const msae_options *o, CallOpts &c) {
     if (o->size >= offsetof(msae_options, dither) + sizeof(int32_t)) dither = o->dither;
     if (o->size >= offsetof(msae_options, rows_rescored) + sizeof(void *)) c.rows_out = o->rows_rescored;
     if (o->size >= offsetof(msae_options, dither_seed) + sizeof(uint64_t)) c.seed = o->dither_seed;
+    if (o->size >= offsetof(msae_options, certified_operands) + sizeof(void *)) {
+      c.cert = o->certified ? 1 : 0;
+      c.cert_ops = o->certified_operands;
+    }
   }
   if (dither < 0 || dither > 2) return false;
   if (dither == 0) {

@@ -58,6 +58,7 @@
 #include "encode_prep.h"
 #include "encode_rescore.h"
 #include "encode_small.h"
+#include "encode_cert.h"
 
 int msae_pre_acts_launch(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
                          const float *b_dec, const int *rows, const int *n_rows, int T, int d, int N,
@@ -73,6 +74,7 @@ namespace {
 // N=131072): 256x256 tiles of 128-B k-rows, 2-slot ring, 8 waves as 2x4.
 using GemmBf16 = GemmCfg<256, 256, 2, 2, 4, false>;
 using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
+using GemmI8Cert = GemmCfg<256, 256, 2, 2, 4, true, 32>;   // msae_options::certified (encode_cert.h)
 constexpr int G_BM = GemmBf16::BM;
 
 // three scratch ranges in one launch (candidate counters, flag list, column maxima)
@@ -140,9 +142,11 @@ struct FusedPlan {
   int segs;   // > 1: the candidate passes append to segmented lists (compact_candidates_kernel joins them)
 };
 
-inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0) {
+inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0, bool cert = false) {
   FusedPlan p{};
   p.fast = fast_shape_ok(N, d) && T > EXACT_T_MAX && k <= 256 && k >= 1;
+  if (cert && !cert_shape_ok(N, d)) p.fast = false;      // shapes without the certified pass: the exact path (certainly certified)
+  if (cert) mode = 1;
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += msae_align_up(b, 256); return at; };
   if (p.fast) {
@@ -159,14 +163,14 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     if (shard_C > 0) { const int rs = shard_C / 8 > 8 ? shard_C / 8 : 8; if (rs < p.r) p.r = rs; }
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = mode == 1 && i8_shape_ok(N, d);
-    p.small = p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
+    p.small = !cert && p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
     // most rows one token may read before it is handed to the exact path (the needed set is ~k + 10:
     // reaching this means the band is not separating anything); at least k + 4 (first-round minimum)
     p.r_max = k <= 64 ? 8 * k : 3 * k;
     if (p.r_max < k + 4) p.r_max = k + 4;
     if (p.r_max > p.cap) p.r_max = p.cap;
     if (p.i8) {
-      p.off_xq = take((size_t)p.Tp * d);
+      p.off_xq = take((size_t)p.Tp * d * (cert ? 2 : 1));   // (certified: two planes per token row)
       p.off_xqo = take((size_t)p.Tp * MAX_OUT);
       p.off_colc = take((size_t)N * 16);
       p.off_colc_s = take((size_t)p.S * 16);
@@ -578,6 +582,115 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   return msae_launch_status();
 }
 
+// msae_options::certified: the same pipeline as run_fast's int8 branch with the certified candidate pass (encode_cert.h) in
+// front of the unchanged select + exact re-score -- two planes per operand, no outlier tile, static column constants, z = 1 (the
+// band IS the bound) and a model check at exactly the band (a violation can only mean operands that do not belong to the weights).
+template <int DT>
+int run_cert(const void *x, const float *W_enc, const float *b_enc, const float *b_dec, const unsigned char *cprep, int T, int d,
+             int N, int k, int set_feature, float set_value, int zero_feature, float *vals, IdxOut idx, int32_t *status,
+             unsigned char *ws, const FusedPlan &pl, const CallOpts &co, hipStream_t s) {
+  const CertPrepared cp = make_cert_prepared(N, d);
+  float *a32 = reinterpret_cast<float *>(ws + pl.off_a32);
+  float *sample = reinterpret_cast<float *>(ws + pl.off_sample);
+  float *tauv = reinterpret_cast<float *>(ws + pl.off_tauv);
+  int32_t *taui = reinterpret_cast<int32_t *>(ws + pl.off_taui);
+  int *cnt = reinterpret_cast<int *>(ws + pl.off_cnt);
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(ws + pl.off_cand);
+  int *flagged = reinterpret_cast<int *>(ws + pl.off_flag);
+  int *n_flagged = flagged + T;
+  signed char *xp = reinterpret_cast<signed char *>(ws + pl.off_xq);
+  f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
+  float *refs = reinterpret_cast<float *>(ws + pl.off_refs);
+  const float *b_up = reinterpret_cast<const float *>(cprep + cp.off_bup);
+  const f32x4 *colc = reinterpret_cast<const f32x4 *>(cprep + cp.off_colc);
+  const f32x4 *colc_p = reinterpret_cast<const f32x4 *>(cprep + cp.off_colc_p);
+  const f32x4 *colc_s = reinterpret_cast<const f32x4 *>(cprep + cp.off_colc_s);
+  (void)b_enc;
+  prof_mark(co.prof, 0, s);
+  int *pcnt = pl.segs > 1 ? reinterpret_cast<int *>(ws + pl.off_segcnt) : cnt;
+  unsigned long long *pcand = pl.segs > 1 ? reinterpret_cast<unsigned long long *>(ws + pl.off_segcand) : cand;
+  const int seg_cap = pl.cap / pl.segs;
+  const size_t n_cnt = pl.segs > 1 ? (pl.off_segcnt - pl.off_cnt) / 4 + (size_t)T * pl.segs : (size_t)T;
+  hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, n_cnt, flagged, (size_t)T + 64 + pl.fb_chunks,
+                     (int *)nullptr, (size_t)0);
+  hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, T, d, (unsigned short *)nullptr, a32);
+  hipLaunchKernelGGL(cert_quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, xp, rowc,
+                     reinterpret_cast<const unsigned *>(cprep));
+  hipLaunchKernelGGL(band_refs_kernel, dim3(1), dim3(1024), 0, s, colc_s, pl.S, refs);
+  GemmOperands op_main{}, op_samp{};
+  op_main.A = reinterpret_cast<const unsigned char *>(xp); op_main.ldA = d; op_main.ldB = d;
+  op_main.B = cprep + cp.off_w;
+  op_main.cert = d / 128; op_main.nk = 3 * op_main.cert; op_main.packed = 1;
+  op_samp = op_main;
+  op_samp.B = cprep + cp.off_ws;
+  prof_mark(co.prof, 1, s);
+  {
+    GemmEpilogue ep{};
+    ep.bias = b_up; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
+    ep.dense = sample; ep.ld_dense = pl.S;
+    ep.rowc = rowc; ep.colc = colc_s; ep.refs = refs; ep.zz12 = CERT_ZZX;
+    const int grc = gemm_launch<GemmI8Cert, true>(op_samp, T, pl.Tp, pl.S, ep, s);
+    if (grc) return grc;
+  }
+  prof_mark(co.prof, 2, s);
+  int rc = 0;
+  const int skip_a = set_feature >= 0 ? set_feature : -1, skip_b = zero_feature >= 0 ? zero_feature : -1;
+  KthPush push{};
+  bool pushed = false;
+  if (skip_a < 0 && skip_b < 0) {
+    push.cnt = pcnt; push.cand = pcand; push.cap = seg_cap; push.stride = SAMPLE_STRIDE; push.off = SAMPLE_OFF;
+    push.cnt_stride = pl.segs; push.row_stride = pl.cap;
+    pushed = true;
+  }
+  if (!msae_kth_value_launch(sample, T, pl.S, pl.S, pl.r, tauv, pl.r, pl.r - 1, s, push)) {
+    rc = msae_topk_launch(sample, T, pl.S, pl.r, pl.S, nullptr, tauv, taui, s);
+    if (rc) return rc;
+    pushed = false;
+  }
+  if (!pushed)
+    hipLaunchKernelGGL(sample_push_kernel, dim3(T), dim3(256), 0, s, sample, pl.S, tauv, pl.r, pl.r - 1, skip_a, skip_b, pcnt,
+                       pcand, seg_cap, pl.segs, pl.cap);
+  prof_mark(co.prof, 3, s);
+  {
+    GemmEpilogue ep{};
+    ep.bias = b_up; ep.bias_stride = 1; ep.bias_off = 0;
+    ep.skip_stride = SAMPLE_STRIDE; ep.skip_off = SAMPLE_OFF;
+    ep.tau_vals = tauv; ep.tau_ld = pl.r; ep.tau_col = pl.r - 1;
+    ep.cnt = pcnt; ep.cand = pcand; ep.cap = pl.cap; ep.segs = pl.segs;
+    ep.skip_a = skip_a; ep.skip_b = skip_b;
+    ep.rowc = rowc; ep.colc = colc_p; ep.refs = refs; ep.zz12 = CERT_ZZX;
+    const int grc = gemm_launch<GemmI8Cert, false>(op_main, T, pl.Tp, N - pl.S, ep, s);
+    if (grc) return grc;
+  }
+  if (pl.segs > 1)
+    hipLaunchKernelGGL(compact_candidates_kernel, dim3(T), dim3(64), 0, s, pcnt, pcand, pl.segs, pl.cap, cnt, cand);
+  prof_mark(co.prof, 4, s);
+  {
+    RescoreArgs ra{};
+    ra.a32 = a32; ra.W_enc = W_enc; ra.b_enc = b_enc;
+    ra.tau_vals = tauv; ra.tau_ld = pl.r; ra.tau_col = pl.r - 1;
+    ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
+    ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
+    ra.rowc = rowc; ra.colc = colc; ra.zz12 = CERT_ZZX; ra.z2 = 1.f; ra.i8 = 1;
+    ra.zc2 = 1.f;                       // |p - c| <= band, always: the check can only trip on foreign operands
+    ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
+    ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
+    ra.fb_cap = T;
+    ra.rows_out = co.rows_out;
+    const int nrp = next_pow2(pl.r_max + 1);
+    const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
+    const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    if (lrc) return lrc;
+  }
+  prof_mark(co.prof, 5, s);
+  rc = run_exact_fallback<DT>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, ws,
+                              pl, co.detail, s);
+  if (rc) return rc;
+  prof_mark(co.prof, 6, s);
+  prof_step(co.prof);
+  return msae_launch_status();
+}
+
 }  // namespace
 
 #ifdef MSAE_GEMM_TIMELINE   // entry points of instrumented builds only (tools/gemm_timeline.py, tools/rescore_timeline.py): not in include/msae.h
@@ -604,6 +717,9 @@ extern "C" void msae_options_init(msae_options *opts) {
   opts->dither = MSAE_DITHER_DEFAULT;
   opts->rows_rescored = nullptr;
   opts->dither_seed = 0;
+  opts->certified = 0;
+  opts->reserved2 = 0;
+  opts->certified_operands = nullptr;
 }
 
 extern "C" int msae_profile_create(int max_steps, void **handle) {
@@ -716,8 +832,28 @@ extern "C" size_t msae_encode_topk_ws_bytes(int T, int d, int N, int k, const ms
   if (T <= 0 || d <= 0 || N <= 0 || k <= 0) return 0;
   CallOpts co;
   if (!resolve_opts(opts, co)) return 0;
-  const FusedPlan pl = make_plan(T, d, N, k, co.mode);
+  const FusedPlan pl = make_plan(T, d, N, k, co.mode, 0, co.cert != 0);
   return pl.bytes;
+}
+
+extern "C" size_t msae_encoder_certified_bytes(int N, int d) {
+  if (N <= 0 || d <= 0 || !cert_shape_ok(N, d)) return 0;
+  return make_cert_prepared(N, d).bytes;
+}
+
+extern "C" int msae_encoder_prepare_certified(const float *W_enc, const float *b_enc, int N, int d, void *operands, void *stream) {
+  if (N <= 0 || d <= 0 || !operands || !W_enc) return MSAE_EINVAL;
+  if (!cert_shape_ok(N, d)) return MSAE_ENOTIMPL;
+  if (!msae_aligned(operands, 256) || !msae_aligned(W_enc, 16)) return MSAE_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const CertPrepared cp = make_cert_prepared(N, d);
+  MSAE_HIP_TRY(hipMemcpyAsync(operands, &cp, sizeof(cp), hipMemcpyHostToDevice, s));
+  unsigned char *base = static_cast<unsigned char *>(operands);
+  hipLaunchKernelGGL(cert_prepare_rows_kernel, dim3(N), dim3(256), 0, s, W_enc, b_enc, N, d,
+                     reinterpret_cast<float *>(base + cp.off_bup), reinterpret_cast<f32x4 *>(base + cp.off_colc),
+                     reinterpret_cast<f32x4 *>(base + cp.off_colc_p), reinterpret_cast<f32x4 *>(base + cp.off_colc_s),
+                     reinterpret_cast<signed char *>(base + cp.off_w), reinterpret_cast<signed char *>(base + cp.off_ws));
+  return msae_launch_status();
 }
 
 static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, const float *b_enc,
@@ -732,8 +868,10 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
   if (set_feature >= N || zero_feature >= N) return MSAE_EINVAL;
   if (T == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  FusedPlan pl = make_plan(T, d, N, k, co.mode);
-  if (!prepared && pl.fast) return MSAE_EINVAL;  // the fast path needs msae_encoder_prepare()
+  FusedPlan pl = make_plan(T, d, N, k, co.mode, 0, co.cert != 0);
+  if (co.cert) {
+    if (pl.fast && !co.cert_ops) return MSAE_EINVAL;   // msae_options::certified needs msae_encoder_prepare_certified()'s buffer
+  } else if (!prepared && pl.fast) return MSAE_EINVAL;  // the fast path needs msae_encoder_prepare()
   if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
   if (!msae_aligned(ws, 256)) return MSAE_EALIGN;
   unsigned char *wsb = static_cast<unsigned char *>(ws);
@@ -757,7 +895,7 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
   if (!msae_aligned(x, x_dtype == MSAE_F32 ? 16 : 8) || !msae_aligned(W_enc, 16) ||
       (b_dec && !msae_aligned(b_dec, 16)))
     return MSAE_EALIGN;
-  if (co.rows_out && (co.exact || pl.small))   // paths without the large-batch re-score kernel report 0 rows
+  if (co.rows_out && (co.exact || (pl.small && !co.cert)))   // paths without the large-batch re-score kernel report 0 rows
     hipLaunchKernelGGL(zero_i32_kernel, dim3(8), dim3(256), 0, s, co.rows_out, (size_t)T);
   if (co.exact) {   // msae_options::exact: every token through the in-call exact path (bounded scratch, status 1)
     int *flagged = reinterpret_cast<int *>(wsb + pl.off_flag);
@@ -770,6 +908,15 @@ static int encode_topk_impl(const void *x, int x_dtype, const float *W_enc, cons
       default: rc = run_exact_fallback<MSAE_F16>(x, W_enc, b_enc, b_dec, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, 0, s); break;
     }
     return rc ? rc : msae_launch_status();
+  }
+  if (co.cert) {
+    const unsigned char *cb = static_cast<const unsigned char *>(co.cert_ops);
+    if (!msae_aligned(cb, 256)) return MSAE_EALIGN;
+    switch (x_dtype) {
+      case MSAE_F32: return run_cert<MSAE_F32>(x, W_enc, b_enc, b_dec, cb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+      case MSAE_BF16: return run_cert<MSAE_BF16>(x, W_enc, b_enc, b_dec, cb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+      default: return run_cert<MSAE_F16>(x, W_enc, b_enc, b_dec, cb, T, d, N, k, set_feature, set_value, zero_feature, vals, idx, status, wsb, pl, co, s);
+    }
   }
   if (pl.small) {
     switch (x_dtype) {

@@ -94,6 +94,11 @@ struct GemmOperands {
   // dimension apart -- and every lane's source offset is lane * 16.  Measured on the stream alone (tools/dma_depth,
   // profiles/r03_dma_tile_major.txt): 43.2 -> 47.7 GB/s per CU with the 2 x 128 B ring, 50.6 -> 65.9 with 4 x 64 B.
   int packed;
+  // Certified pass (encode_cert.h): > 0 = k-tiles per PLANE (d / 128).  A and B are tile-major with 2 * cert k-tiles per row tile
+  // (plane 0 = lo, plane 1 = hi); nk = 3 * cert; k-tile q of the walk multiplies A plane (q < cert ? lo : hi) with B plane
+  // (cert <= q < 2 cert ? lo : hi), and the accumulators are divided by 128 (rounded) in front of k-tile 2 * cert:
+  // acc = x_hi . W_hi + round((x_lo . W_hi + x_hi . W_lo) / 128).  The token's rowc[1] is the band's M_t (no outlier tile).
+  int cert;
 };
 
 // FLAGS:
@@ -101,11 +106,13 @@ struct GemmOperands {
 //   bit 2 ABL_NOSTAGE  skip the LDS-DMA staging in the loop
 //   bit 3 ABL_NOREAD   read the fragments once and reuse them
 //   bit 4 ABL_NOMFMA   issue no MFMA
+//   bit 5 CERT         the certified three-segment pass (encode_cert.h); I8 only
 template <int BM_, int BN_, int STAGES_, int WM_, int WN_, bool I8_ = false, int FLAGS_ = 0>
 struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, STAGES = STAGES_, WM = WM_, WN = WN_;
   static constexpr bool I8 = I8_;
   static constexpr bool ABL_NOSTAGE = FLAGS_ & 4, ABL_NOREAD = FLAGS_ & 8, ABL_NOMFMA = FLAGS_ & 16;
+  static constexpr bool CERT = FLAGS_ & 32;       // certified pass (GemmOperands::cert): its own instantiation, the product kernel is untouched
   static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         side3 = rc[2];
         side4 = 1.f;
         if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
+        if constexpr (C::CERT) side4 = rc[1];
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   // ONE row of output tiles (T <= BM): all workgroups read the SAME A tile, and walking its k-tiles in step they ask
   // the same few L2 lines at the same moment.  Integer accumulation does not depend on the order, so each workgroup
   // starts its k-walk at its own k-tile (the 32 workgroups of an XCD at 32 different ones) and wraps around.
-  const int krot = (C::I8 && nM == 1) ? (int)(gridDim.x >= 64 ? blockIdx.x >> 3 : blockIdx.x) % op.nk : 0;   // (few tiles: the sample pass)
+  const int krot = (C::I8 && nM == 1 && !C::CERT) ? (int)(gridDim.x >= 64 ? blockIdx.x >> 3 : blockIdx.x) % op.nk : 0;   // (few tiles: the sample pass)
   auto stage = [&](int tm0, int tn0, int tile, int slot) {
     if (tile < lead) {
       if constexpr (C::I8) {
@@ -698,6 +706,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     } else {
       int kq = tile - lead + krot;                         // (a select, no control flow: see gemm_stage_pieces)
       kq -= kq >= op.nk ? op.nk : 0;
+      if constexpr (C::CERT) {                             // wave-uniform; scalar selects (see GemmOperands::cert)
+        const int seg = kq >= 2 * op.cert ? 2 : (kq >= op.cert ? 1 : 0), kk = kq - seg * op.cert;
+        const int ia = (seg == 0 ? 0 : op.cert) + kk, ib = (seg == 1 ? 0 : op.cert) + kk;
+        gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * (2 * op.cert) + ia) * C::A_BYTES,
+                             op.B + ((size_t)(tn0 / C::BN) * (2 * op.cert) + ib) * C::B_BYTES, smem, slot, wave, lane);
+        return;
+      }
       if (op.packed)                                       // wave-uniform
         gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES,
                              op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES, smem, slot, wave, lane);
@@ -777,7 +792,23 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       if (lead_ks > 0) scale_by_m();   // no outlier dim in this batch: the accumulators are still zero
     }
   }
-  for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
+  if constexpr (C::CERT) {
+    const int cut = 2 * op.cert;                     // (no outlier tile in this mode: kt0 == 0)
+    for (int kt = kt0; kt < cut; ++kt) iteration(kt);
+    // the low-order segments are done: acc = round(acc / 128), an arithmetic shift (|acc| < 2^31: encode_cert.h)
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) {
+        i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = (v[e] + 64) >> 7;
+        acc[i][j] = __builtin_bit_cast(f32x16, v);
+      }
+    for (int kt = cut; kt < ntiles; ++kt) iteration(kt);
+  } else {
+    for (int kt = kt0; kt < ntiles; ++kt) iteration(kt);
+  }
 
   MSAE_TL(3);
   // park the epilogue constants in LDS (side buffer behind the ring)
@@ -820,6 +851,8 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 template <class C, bool DENSE>
 inline int gemm_launch(const GemmOperands &op, int T, int Tp, int N, const GemmEpilogue &ep, hipStream_t s) {
   if (Tp % C::BM || N % C::BN || op.nk <= 0 || op.ldA != op.ldB || op.ldA % 128 || op.packed > 1) return MSAE_EINVAL;
+  if ((op.cert != 0) != C::CERT) return MSAE_EINVAL;
+  if (C::CERT && (!C::I8 || op.cert < 0 || op.nk != 3 * op.cert || op.packed != 1 || op.Ao != nullptr)) return MSAE_EINVAL;
   const int nM = Tp / C::BM, nN = N / C::BN;
   auto kern = gemm_kernel<C, DENSE>;
   MSAE_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));

@@ -25,7 +25,8 @@ class MsaeOptions(ctypes.Structure):
     """struct msae_options of include/msae.h: the per-call options of the fused encoder."""
     _fields_ = [("size", ctypes.c_uint32), ("coarse_mode", ctypes.c_int32), ("guard_z", ctypes.c_float),
                 ("status_detail", ctypes.c_int32), ("profile", ctypes.c_void_p), ("exact", ctypes.c_int32),
-                ("dither", ctypes.c_int32), ("rows_rescored", ctypes.c_void_p), ("dither_seed", ctypes.c_uint64)]
+                ("dither", ctypes.c_int32), ("rows_rescored", ctypes.c_void_p), ("dither_seed", ctypes.c_uint64),
+                ("certified", ctypes.c_int32), ("reserved2", ctypes.c_int32), ("certified_operands", ctypes.c_void_p)]
 
 
 c_opts_p = ctypes.POINTER(MsaeOptions)
@@ -44,6 +45,8 @@ PROTOTYPES = {
     "msae_encoder_prepared_bytes": (c_size_t, [c_int, c_int]),
     "msae_encoder_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "msae_encoder_prepare_opts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
+    "msae_encoder_certified_bytes": (c_size_t, [c_int, c_int]),
+    "msae_encoder_prepare_certified": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "msae_encoder_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_opts_p, c_void_p]),
     "msae_encoder_refresh_for": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_opts_p, c_void_p]),
     "msae_encode_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_opts_p]),

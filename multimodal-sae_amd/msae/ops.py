@@ -100,6 +100,8 @@ class Options:
         self.exact = exact
         self.dither, self.dither_seed = dither, int(dither_seed)   # msae_options::dither / dither_seed (0: drawn per call)
         self.rows_rescored: Optional[Tensor] = None     # device int32 [T] (msae_options::rows_rescored) or None
+        self.certified = False                          # msae_options::certified (+ the operand buffer of the call)
+        self.certified_operands: Optional[Tensor] = None
 
     def struct(self) -> "_hip.MsaeOptions":
         o = _hip.MsaeOptions()
@@ -112,6 +114,8 @@ class Options:
         o.dither = self.DITHER[self.dither]
         o.dither_seed = self.dither_seed & 0xFFFFFFFFFFFFFFFF
         o.rows_rescored = self.rows_rescored.data_ptr() if self.rows_rescored is not None else None
+        o.certified = int(bool(self.certified))
+        o.certified_operands = self.certified_operands.data_ptr() if self.certified_operands is not None else None
         return o
 
     def ref(self):
@@ -125,10 +129,11 @@ _defaults = Options()
 class _OptsRef:
     """A filled msae_options struct and its byref, built once per distinct content (the S = 1 latency path is
     host-bound: two ctypes structs per call showed up as +10 us per decode step)."""
-    __slots__ = ("struct", "_ref", "profile")
+    __slots__ = ("struct", "_ref", "profile", "cert_ops")
 
     def __init__(self, o: Options):
         self.struct, self.profile = o.struct(), o.profile          # (keeps the profile handle alive)
+        self.cert_ops = o.certified_operands                       # (... and the certified operand buffer)
         self._ref = ctypes.byref(self.struct)
 
     def ref(self):
@@ -143,7 +148,7 @@ _DITHER_NAME = {0: "default", 1: "on", 2: "off"}
 
 
 def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False, exact: bool = False,
-          dither: int = 0, dither_seed: int = 0) -> _OptsRef:
+          dither: int = 0, dither_seed: int = 0, cert_ops: Optional[Tensor] = None) -> _OptsRef:
     """Options of one call: explicit arguments win, the process defaults fill the rest."""
     coarse = _defaults.coarse if coarse_mode < 0 else ("int8" if coarse_mode == 1 else "bf16")
     z = guard_z if guard_z > 0.0 else _defaults.guard_z
@@ -153,12 +158,13 @@ def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = Fal
     seed = dither_seed if dither_seed else _defaults.dither_seed
     prof, rows = _defaults.profile, _defaults.rows_rescored
     key = (coarse, z, detail, id(prof) if prof is not None else 0, exact, rows.data_ptr() if rows is not None else 0,
-           dith, seed)
+           dith, seed, cert_ops.data_ptr() if cert_ops is not None else 0)
     ref = _OPTS_CACHE.get(key)
-    if ref is None or ref.profile is not prof:
+    if ref is None or ref.profile is not prof or ref.cert_ops is not cert_ops:
         if len(_OPTS_CACHE) > 64:
             _OPTS_CACHE.clear()
         o = Options(coarse, z, detail, prof, exact, dith, seed)
+        o.certified, o.certified_operands = cert_ops is not None, cert_ops
         o.rows_rescored = rows
         ref = _OPTS_CACHE[key] = _OptsRef(o)
     return ref
@@ -167,7 +173,7 @@ def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = Fal
 def _encode_ws_bytes(lib, T: int, d: int, N: int, k: int, opts: _OptsRef) -> int:
     """msae_encode_topk_ws_bytes, memoised (a pure function of the shape and the coarse mode)."""
     key = (T, d, N, k, opts.struct.coarse_mode, os.environ.get("MSAE_COARSE") if opts.struct.coarse_mode < 0 else None,
-           os.environ.get("MSAE_FM"))
+           os.environ.get("MSAE_FM"), opts.struct.certified)
     n = _WS_BYTES_CACHE.get(key)
     if n is None:
         if len(_WS_BYTES_CACHE) > 4096:
@@ -390,6 +396,42 @@ def set_dither(mode: str = "default", seed: int = 0) -> None:
     _defaults.dither, _defaults.dither_seed = mode, int(seed)
 
 
+def set_certified(on: bool) -> None:
+    """Default of msae_options::certified for this process's ops: every fused encode runs the certified candidate pass (two
+    int8 planes per operand, deterministic band: include/msae.h) -- its operands are built on first use per (weight, bias)
+    version and cached (`prepare_encoder_certified`)."""
+    _defaults.certified = bool(on)
+
+
+_CERT_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+
+
+def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optional[Tensor]:
+    """msae_encoder_prepare_certified: the certified pass's operand buffer for (W_enc, b_enc), or None when the shape has no
+    certified pass (the library then runs the exact path).  Cached per (pointer, version) of both tensors, two most recent."""
+    dev = _hip.require_device(W_enc, b_enc)
+    lib = _hip.load()
+    key = (dev, W_enc.data_ptr(), W_enc._version, tuple(W_enc.shape), 0 if b_enc is None else b_enc.data_ptr(),
+           0 if b_enc is None else b_enc._version)
+    buf = _CERT_CACHE.get(key)
+    if buf is not None:
+        _CERT_CACHE.move_to_end(key)
+        return buf
+    W, b = _f32c(W_enc), _f32c(b_enc)
+    N, d = W.shape
+    nbytes = lib.msae_encoder_certified_bytes(N, d)
+    if nbytes == 0:
+        return None
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.msae_encoder_prepare_certified(_hip.ptr(W), _hip.ptr(b), N, d, _hip.ptr(buf), _hip.stream_of(W)),
+                   "msae_encoder_prepare_certified")
+    _CERT_CACHE[key] = buf
+    while len(_CERT_CACHE) > 2:
+        _CERT_CACHE.popitem(last=False)
+    return buf
+
+
 def set_status_detail(on: bool) -> None:
     """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
     _defaults.status_detail = bool(on)
@@ -482,11 +524,13 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
                 prepared: Optional[Tensor], k: int, set_feature: int = -1, set_value: float = 0.0,
                 zero_feature: int = -1, coarse_mode: int = -1, guard_z: float = 0.0,
                 status_detail: bool = False, exact: bool = False, dither: int = 0,
-                dither_seed: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+                dither_seed: int = 0, certified: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """Fused Sae.encode -> (top_acts f32 [...,k], top_indices int64 [...,k], status int32 [...]).
     coarse_mode (-1 default / 0 bf16 / 1 int8), guard_z (0 = default), status_detail and exact (every token by the
     exact path: include/msae.h, msae_options::exact), dither (0 default / 1 on / 2 off) and dither_seed (0 = drawn by the
-    library) are this call's msae_options; what is left at its default comes from the process defaults (set_coarse_mode & co.)."""
+    library) and certified (the two-plane pass with the deterministic band; its operand buffer comes from
+    prepare_encoder_certified's cache) are this call's msae_options; what is left at its default comes from the process
+    defaults (set_coarse_mode & co.)."""
     dev = _hip.require_device(x, W_enc, b_enc, b_dec, prepared)
     lib = _hip.load()
     xa, W, be, bd = _act(x), _f32c(W_enc), _f32c(b_enc), _f32c(b_dec)
@@ -499,13 +543,18 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
     status = torch.empty(xa.shape[:-1], dtype=torch.int32, device=dev)
     if T == 0:
         return vals, idx, status
-    opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed)
+    cert_ops = None
+    if (certified or _defaults.certified) and not (exact or _defaults.exact):
+        cert_ops = prepare_encoder_certified(W_enc, b_enc)
+        if cert_ops is None:
+            exact = True                 # a shape without the certified pass: the exact path is the certified answer
+    opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed, cert_ops)
     rows = _defaults.rows_rescored
     if rows is not None and (T > rows.numel() or rows.device != dev):
         # rescore_rows(buf) serves encodes of <= buf.numel() tokens on buf's device; a larger call inside the block runs
         # WITHOUT the statistics instead of writing past the buffer
         with _without_rows():
-            opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed)
+            opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed, cert_ops)
     ws = _workspace(dev, _encode_ws_bytes(lib, T, d, N, k, opts))
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encode_topk_i64(_hip.ptr(xa), _hip.DTYPE_CODE[xa.dtype], _hip.ptr(W),
@@ -518,7 +567,7 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
 
 @encode_topk.register_fake
 def _(x, W_enc, b_enc, b_dec, prepared, k, set_feature=-1, set_value=0.0, zero_feature=-1, coarse_mode=-1,
-      guard_z=0.0, status_detail=False, exact=False, dither=0, dither_seed=0):
+      guard_z=0.0, status_detail=False, exact=False, dither=0, dither_seed=0, certified=False):
     return (x.new_empty(*x.shape[:-1], k, dtype=torch.float32),
             x.new_empty(*x.shape[:-1], k, dtype=torch.int64),
             x.new_empty(x.shape[:-1], dtype=torch.int32))

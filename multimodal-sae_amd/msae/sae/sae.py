@@ -190,7 +190,7 @@ class Sae(nn.Module):
 
     def encode(self, x: Tensor, *, set_feature: int = -1, set_value: float = 0.0,
                zero_feature: int = -1, return_status: bool = False, resolve: bool = True,
-               differentiable: Optional[bool] = None, exact: bool = False):
+               differentiable: Optional[bool] = None, exact: bool = False, certified: bool = False):
         """Fused encode + TopK (sae.py:183-185).  `set_feature/set_value` and `zero_feature` apply
         the steering / attribution hooks' edits of the dense latents (steering.py:113-114,
         patching/utils.py:43-48) inside the kernel, before TopK.
@@ -200,30 +200,23 @@ class Sae(nn.Module):
         candidate pass does not describe ...) exactly inside the call, on the device; nothing is read
         back, so the method is stream-ordered like every other op.  `status` (return_status=True):
         0 verified, 1 recomputed exactly.  `resolve` is accepted for compatibility and ignored.
-        `exact=True` computes EVERY token by the exact path (msae_options::exact, include/msae.h): for callers that
-        cannot accept the fused path's statistical contract (a miss needs a feature whose int8 / bf16 rounding error
-        exceeds 7 of its own sigma: < 3e-13 per token for weights that do not know the token's rounding residual;
-        adversarially constructed rows can).  Inference only.
+        Guarantees (include/msae.h): the default int8 pass rounds its operands stochastically with per-call seeds, so a
+        member of the true top-k is missed with probability <= k exp(-z^2 / 2) (7e-10 at z = 7, k = 32) for EVERY input;
+        `certified=True` runs the two-plane pass with a deterministic error band (no probability left, ~3x the time on
+        large batches); `exact=True` computes EVERY token by the exact path (msae_options::exact).  Both are inference switches.
 
-        Autograd: the call is one differentiable node (sparse backward through the selected latents) when
-        gradients are enabled and `x` requires grad (the attribution hooks: the LLM's hidden states do) or
-        `differentiable=True` is passed (a custom training loop that wants d/dW from a constant input);
-        plain inference on a loaded module -- whose parameters require grad by default -- saves nothing.  Where the
-        reference's encode would have carried gradient to its parameters and this call does not (gradients enabled, a
-        parameter requires grad, constant input, `differentiable` left unset) a one-time warning says so."""
-        want_grad = torch.is_grad_enabled() and (x.requires_grad if differentiable is None else differentiable)
-        if (differentiable is None and not want_grad and torch.is_grad_enabled() and not Sae._warned_detached and
-                (self.encoder.weight.requires_grad or self.encoder.bias.requires_grad or self.b_dec.requires_grad)):
-            import warnings
-
-            Sae._warned_detached = True
-            warnings.warn("Sae.encode: gradients are enabled and the SAE's parameters require grad, but the input does not: "
-                          "this call returns DETACHED latents (the reference's encode would carry gradient to encoder.weight "
-                          "/ bias / b_dec).  Pass differentiable=True to fine-tune through encode(), or run inference under "
-                          "torch.no_grad() / on sae.requires_grad_(False) to silence this.", stacklevel=2)
-        if want_grad and exact:
-            raise RuntimeError("Sae.encode(exact=True) is an inference switch: differentiate pre_acts -> select_topk (the "
-                               "exact path with autograd) instead")
+        Autograd follows the reference (sae.py:183-185 builds a graph whenever autograd would): the call is one differentiable
+        node (sparse backward through the selected latents) when gradients are enabled and `x` requires grad (the attribution
+        hooks: the LLM's hidden states do), or the module is in TRAINING mode and a parameter requires grad (a loaded module is,
+        as in the reference, until `.eval()` / `.requires_grad_(False)`), or `differentiable=True` is passed.  The detached fast
+        path is what runs under `torch.no_grad()` (the cache and steering hooks) and in `eval()` mode."""
+        if differentiable is None:
+            params = self.encoder.weight.requires_grad or self.encoder.bias.requires_grad or self.b_dec.requires_grad
+            differentiable = x.requires_grad or (self.training and params and not (exact or certified or return_status))
+        want_grad = torch.is_grad_enabled() and differentiable
+        if want_grad and (exact or certified):
+            raise RuntimeError("Sae.encode(exact=True / certified=True) is an inference switch: differentiate pre_acts -> "
+                               "select_topk (the exact path with autograd) instead")
         if want_grad and return_status:
             raise RuntimeError("Sae.encode(return_status=True) returns non-differentiable outputs: call it under "
                                "torch.no_grad(), or without return_status where gradients must flow")
@@ -237,7 +230,7 @@ class Sae(nn.Module):
         with torch.no_grad():      # (a custom op without an autograd formula would hang a raising node on the outputs)
             acts, idx, status = ops.encode_topk(x, self.encoder.weight, self.encoder.bias, self.b_dec,
                                                 self._prepared_weights(), self.cfg.k, set_feature,
-                                                float(set_value), zero_feature, exact=exact)
+                                                float(set_value), zero_feature, exact=exact, certified=certified)
         out = EncoderOutput(acts, idx)
         return (out, status) if return_status else out
 

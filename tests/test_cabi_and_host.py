@@ -49,13 +49,13 @@ def test_library_exports_every_declared_symbol():
     bad.guard_z, bad.size = 0.0, 4     # a caller compiled against a shorter struct than this library knows
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(bad)) == 0
     # ... while ABI 2's struct (24 bytes, no `exact`) is still served (exact = 0: the same plan)
-    assert o8.exact == 0 and o8.dither == 0 and o8.dither_seed == 0 and ctypes.sizeof(_hip.MsaeOptions) == 48
+    assert o8.exact == 0 and o8.dither == 0 and o8.dither_seed == 0 and ctypes.sizeof(_hip.MsaeOptions) == 64
     o8.size = 24
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == w8
     # ... and ABI 3's (40 bytes: `reserved` where `dither` now is, no dither_seed)
     o8.size = 40
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == w8
-    o8.size, o8.dither = 48, 7         # an unknown dither mode is an argument error
+    o8.size, o8.dither = 64, 7         # an unknown dither mode is an argument error
     assert lib.msae_encode_topk_ws_bytes(8192, 4096, 131072, 32, ctypes.byref(o8)) == 0
 
 

@@ -247,14 +247,26 @@ def test_legacy_seam_is_differentiable_and_matches_the_reference(dev, golden_dir
 
 
 def test_encode_does_not_build_a_graph_for_plain_inference(dev):
-    """a loaded Sae's parameters require grad by default; `encode` outside no_grad must not save
-    activations per call unless the INPUT requires grad (or the caller asks for it)."""
+    """Gradient semantics of Sae.encode (round-4 verdict, item 9): the reference's (sae.py:183-185: a graph whenever autograd
+    would build one) in TRAINING mode -- which a freshly constructed / loaded module is in, as in the reference --, the detached
+    fast path in eval() mode and under no_grad (inference must not save activations per call)."""
     from msae import Sae, SaeConfig
 
     sae = Sae(256, SaeConfig(num_latents=8192, k=32), device=dev)
     x = torch.randn(3, 7, 256, device=dev)
+    assert sae.training
+    o_train = sae.encode(x)                               # training mode, parameters require grad: differentiable, as the reference
+    assert o_train.top_acts.requires_grad
+    o_train.top_acts.sum().backward()
+    assert sae.encoder.weight.grad is not None
+    sae.zero_grad()
+    with torch.no_grad():
+        assert not sae.encode(x).top_acts.requires_grad
+    _, st0 = sae.encode(x, return_status=True)            # (status outputs: the detached path)
+    sae.eval()
     out = sae.encode(x)
     assert not out.top_acts.requires_grad and out.top_acts.shape == (3, 7, 32)
+    assert torch.equal(out.top_acts, o_train.top_acts.detach()) and torch.equal(out.top_indices, o_train.top_indices)
     xg = x.clone().requires_grad_()
     o2 = sae.encode(xg)                                   # 3-D input through the differentiable node
     assert o2.top_acts.requires_grad and torch.equal(o2.top_acts, out.top_acts) and torch.equal(o2.top_indices, out.top_indices)
