@@ -48,6 +48,7 @@ def _workspace(dev: torch.device, nbytes: int) -> Tensor:
 def release_workspaces() -> None:
     """Drop every cached scratch buffer (they are re-created on demand)."""
     _WS.clear()
+    _CERT_CACHE.clear()
 
 
 # ---- per-call options of the fused encoder (struct msae_options) ------------------------------------------
@@ -408,15 +409,16 @@ _CERT_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 
 def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optional[Tensor]:
     """msae_encoder_prepare_certified: the certified pass's operand buffer for (W_enc, b_enc), or None when the shape has no
-    certified pass (the library then runs the exact path).  Cached per (pointer, version) of both tensors, two most recent."""
+    certified pass (the library then runs the exact path).  Cached per (pointer, version) of both tensors, two most recent
+    (weights edited through `.data` do not bump the version: call release_workspaces() after such an edit)."""
     dev = _hip.require_device(W_enc, b_enc)
     lib = _hip.load()
     key = (dev, W_enc.data_ptr(), W_enc._version, tuple(W_enc.shape), 0 if b_enc is None else b_enc.data_ptr(),
            0 if b_enc is None else b_enc._version)
-    buf = _CERT_CACHE.get(key)
-    if buf is not None:
+    hit = _CERT_CACHE.get(key)
+    if hit is not None:
         _CERT_CACHE.move_to_end(key)
-        return buf
+        return hit[0]
     W, b = _f32c(W_enc), _f32c(b_enc)
     N, d = W.shape
     nbytes = lib.msae_encoder_certified_bytes(N, d)
@@ -426,7 +428,9 @@ def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optiona
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encoder_prepare_certified(_hip.ptr(W), _hip.ptr(b), N, d, _hip.ptr(buf), _hip.stream_of(W)),
                    "msae_encoder_prepare_certified")
-    _CERT_CACHE[key] = buf
+    # the entry HOLDS the tensors it was built from: while it lives their storage cannot be freed and handed to another
+    # weight matrix with the same (pointer, version) -- a key of pointers alone would then serve the old operands
+    _CERT_CACHE[key] = (buf, W_enc, b_enc)
     while len(_CERT_CACHE) > 2:
         _CERT_CACHE.popitem(last=False)
     return buf
