@@ -2,7 +2,7 @@
 """Soak of the fused encoder's verification rule: >= 1 M tokens, fused vs exact path, every token.
 
     python tools/soak_fused.py [--tokens 1048576] [--kind trained_like] [--N 131072] [--d 4096]
-                               [--k 32] [--coarse int8|bf16] [--out gpurun_out/soak.json]
+                               [--k 32] [--coarse int8|bf16|certified] [--out gpurun_out/soak.json]
 
 For every batch of 8192 fresh activations the fused msae_encode_topk result is compared bit for bit
 with msae_pre_acts_f32 + msae_topk_f32 on the same tokens.  "silent" = a token reported verified
@@ -45,7 +45,10 @@ def main(argv=None):
     ap.add_argument("--acts", default=None, help="safetensors file with [T, d] activations instead of synthetic ones")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
-    ops.set_coarse_mode(a.coarse)
+    if a.coarse == "certified":          # msae_options::certified (two planes per operand, deterministic band)
+        ops.set_certified(True)
+    else:
+        ops.set_coarse_mode(a.coarse)
     ops.set_guard_z(a.z)
     ops.set_status_detail(True)
     if a.sae_path:
