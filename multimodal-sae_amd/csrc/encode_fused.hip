@@ -353,6 +353,43 @@ int run_small(const void *x, const float *W_enc, const float *b_enc, const float
   return msae_launch_status();
 }
 
+// select + exact re-score of the candidate lists (RescoreArgs filled by the caller): token-major, or with the FEATURE-major first
+// round where the plan has it and the cost model says it pays (encode_rescore.h).  Shared by run_fast and run_cert.
+template <int DT>
+int rescore_stage(RescoreArgs &ra, const FusedPlan &pl, const void *x, const float *b_dec, const float *W_enc,
+                  const float *b_enc, const float *a32, unsigned long long *cand, unsigned char *ws, int T, int d, int N, int k,
+                  hipStream_t s) {
+  const int nrp = next_pow2(pl.r_max + 1);
+  const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
+  int lrc;
+  // (fm_dot_kernel reads x in 16-B pieces; the entry points ask 8 B of a 16-bit x)
+  if (pl.fm && msae_aligned(x, 16) && fm_pays(T, k, N, d, DT == MSAE_F32 ? 4 : 2)) {
+    int *fcount = reinterpret_cast<int *>(ws + pl.off_fmcount);
+    int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
+    float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);
+    ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
+    ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max; ra.fm_cand = cand;
+    ra.fm_rank = reinterpret_cast<int *>(fpre);
+    ra.fm_defer = reinterpret_cast<int *>(ws + pl.off_fmdefer);
+    MSAE_HIP_TRY(hipMemsetAsync(ra.fm_defer, 0, (size_t)T * 2 * 4, s));
+    MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
+    lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    if (lrc) return lrc;
+    const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK, G = fm_group_lanes(T, k, N);
+    hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64);
+    hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64, pairs);
+    hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, ra.fm_rank, pl.r_max, fcount, pairs);
+    const long max_slots = (long)T * pl.r_max + (long)N * (G - 1);
+    const dim3 dgrid((unsigned)((max_slots + 63) / 64));
+    if (G == 16) hipLaunchKernelGGL((fm_dot_kernel<DT, 16>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
+    else hipLaunchKernelGGL((fm_dot_kernel<DT, 4>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
+    lrc = launch_select_rescore<false, 2>(ra, T, k, smem, (const float *)a32, W_enc, s);
+  } else {
+    lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+  }
+  return lrc;
+}
+
 template <int DT>
 int run_fast(const void *x, const float *W_enc, const float *b_enc, const float *b_dec,
              const Prepared &pp, const unsigned char *prepared, int T, int d, int N, int k,
@@ -541,34 +578,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
     ra.rows_out = co.rows_out;
-    const int nrp = next_pow2(pl.r_max + 1);
-    const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
-    int lrc;
-    // (fm_dot_kernel reads x in 16-B pieces; the entry points ask 8 B of a 16-bit x)
-    if (pl.fm && msae_aligned(x, 16) && fm_pays(T, k, N, d, DT == MSAE_F32 ? 4 : 2)) {
-      int *fcount = reinterpret_cast<int *>(ws + pl.off_fmcount);
-      int2 *pairs = reinterpret_cast<int2 *>(ws + pl.off_fmpairs);
-      float *fpre = reinterpret_cast<float *>(ws + pl.off_fmpre);
-      ra.fm_count = fcount; ra.fm_target = reinterpret_cast<int *>(ws + pl.off_fmtarget);
-      ra.fm_keys = reinterpret_cast<unsigned long long *>(ws + pl.off_fmkeys); ra.fm_pre = fpre; ra.fm_rcap = pl.r_max; ra.fm_cand = cand;
-      ra.fm_rank = reinterpret_cast<int *>(fpre);
-      ra.fm_defer = reinterpret_cast<int *>(ws + pl.off_fmdefer);
-      MSAE_HIP_TRY(hipMemsetAsync(ra.fm_defer, 0, (size_t)T * 2 * 4, s));
-      MSAE_HIP_TRY(hipMemsetAsync(fcount, 0, ((size_t)N + 1) * 4, s));
-      lrc = launch_select_rescore<false, 1>(ra, T, k, smem, (const float *)a32, W_enc, s);
-      if (lrc) return lrc;
-      const int scan_blocks = (N + FM_SCAN_BLOCK - 1) / FM_SCAN_BLOCK, G = fm_group_lanes(T, k, N);
-      hipLaunchKernelGGL(fm_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64);
-      hipLaunchKernelGGL(fm_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, fcount, N, G, fcount + N + 64, pairs);
-      hipLaunchKernelGGL(fm_scatter_kernel, dim3(T), dim3(256), 0, s, ra.fm_target, ra.fm_keys, ra.fm_rank, pl.r_max, fcount, pairs);
-      const long max_slots = (long)T * pl.r_max + (long)N * (G - 1);
-      const dim3 dgrid((unsigned)((max_slots + 63) / 64));
-      if (G == 16) hipLaunchKernelGGL((fm_dot_kernel<DT, 16>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
-      else hipLaunchKernelGGL((fm_dot_kernel<DT, 4>), dgrid, dim3(64), 0, s, x, b_dec, W_enc, b_enc, pairs, fcount + N, d, pl.r_max, fpre);
-      lrc = launch_select_rescore<false, 2>(ra, T, k, smem, (const float *)a32, W_enc, s);
-    } else {
-      lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
-    }
+    const int lrc = rescore_stage<DT>(ra, pl, x, b_dec, W_enc, b_enc, a32, cand, ws, T, d, N, k, s);
     if (lrc) return lrc;
   }
   prof_mark(co.prof, 5, s);
@@ -677,9 +687,7 @@ int run_cert(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
     ra.rows_out = co.rows_out;
-    const int nrp = next_pow2(pl.r_max + 1);
-    const size_t smem = ((size_t)pl.cap + nrp) * 8 + 64;
-    const int lrc = launch_select_rescore<false>(ra, T, k, smem, (const float *)a32, W_enc, s);
+    const int lrc = rescore_stage<DT>(ra, pl, x, b_dec, W_enc, b_enc, a32, cand, ws, T, d, N, k, s);
     if (lrc) return lrc;
   }
   prof_mark(co.prof, 5, s);
