@@ -12,12 +12,14 @@
 namespace {
 
 constexpr int SAMPLE_STRIDE = 32, SAMPLE_OFF = 13;
-// Tokens one pass of the in-call exact fallback absorbs: its dense scratch rows are budgeted at 1 GiB
-// (2048 rows at N = 131072), never fewer than 128 and never more than the call has tokens.  The
+// Tokens one pass of the in-call exact fallback absorbs: its dense scratch rows are budgeted at 4 GiB
+// (8192 rows at N = 131072; 1 GiB until round 5: the bench batch then enqueued four passes = eight empty
+// launches + a count kernel per step, ~30 us of a 5.9 ms step, for scratch nobody touches unless a token is
+// flagged -- 288 GB of HBM make the other trade), never fewer than 128 and never more than the call has tokens.  The
 // exact kernels take the flagged count from device memory and loop over it; ceil(T / capacity) passes
 // are enqueued (the ones without work exit at once), so EVERY flagged token is recomputed inside the
 // call whatever their number -- no host round trip, no "unresolved" leftovers.
-constexpr size_t FB_BUDGET_BYTES = (size_t)1 << 30;
+constexpr size_t FB_BUDGET_BYTES = (size_t)4 << 30;
 inline int fallback_capacity(int T, int N) {
   size_t cap = FB_BUDGET_BYTES / ((size_t)N * 4);
   const size_t t128 = ((size_t)T + 127) / 128 * 128;
