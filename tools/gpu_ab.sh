@@ -5,7 +5,7 @@ OUT=gpurun_out/ab; mkdir -p $OUT
 for rep in 1 2; do
   for lib in "$@"; do
     n=$(basename $lib .so)
-    MSAE_HIP_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${n}_$rep.json 2>/dev/null
+    MSAE_HIP_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/${n}_$rep.json 2>/dev/null
     python - <<PY
 import json
 r=json.load(open("$OUT/${n}_$rep.json"))

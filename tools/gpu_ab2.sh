@@ -9,7 +9,7 @@ for rep in $(seq 1 $REPS); do
   for spec in "$@"; do
     name=$(echo "$spec" | cut -d'|' -f1); lib=$(echo "$spec" | cut -d'|' -f2); envs=$(echo "$spec" | cut -d'|' -f3)
     ( [ -n "$lib" ] && export MSAE_HIP_LIB=$lib; for e in $envs; do export $e; done
-      timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > $OUT/${name}_$rep.json 2>$OUT/${name}_$rep.err )
+      timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary $EXTRA > $OUT/${name}_$rep.json 2>$OUT/${name}_$rep.err )
     python - <<PY
 import json
 try:

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))

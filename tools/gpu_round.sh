@@ -4,7 +4,7 @@
 # real-input runner.  Everything lands in gpurun_out/ (merged back by gpurun); each step has its own timeout.
 cd "$(dirname "$0")/.."
 OUT=gpurun_out
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 mkdir -p $OUT
 export TMPDIR=/tmp
 (nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -8) > $OUT/host.txt 2>&1
@@ -18,10 +18,10 @@ echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
 echo "== bench =="
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/${R}_bench.json
-MSAE_COARSE=bf16 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${R}_bench_bf16.json 2>> $OUT/bench.err; echo "bench bf16 exit $?"
+MSAE_COARSE=bf16 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/${R}_bench_bf16.json 2>> $OUT/bench.err; echo "bench bf16 exit $?"
 echo "== rocprof kernel stats =="
 rm -rf $OUT/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f | cut -c1-160; done
 find $OUT/prof -name "*kernel_trace*" -size +2M -delete
 echo "== PMC passes =="
@@ -35,12 +35,16 @@ echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_1M_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
+timeout 900 python tools/soak_fused.py --tokens 524288 --N 131072 --d 4096 --coarse certified --out $OUT/${R}_soak_512k_trained_like_c2_certified.json >> $OUT/soak.log 2>&1; echo "soak c2 certified exit $?"
+MSAE_DITHER=0 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2_dither_off.json >> $OUT/soak.log 2>&1; echo "soak c2 dither-off exit $?"
 echo "== feature-major re-score: A/B, probe, k = 256 soak, fuzz with the route forced on / off =="
 timeout 400 bash tools/gpu_fm_ab.sh > $OUT/${R}_fm_rescore.txt 2>&1; cat $OUT/${R}_fm_rescore.txt | cut -c1-220
 KS=256 timeout 250 bash tools/gpu_fm.sh > /dev/null 2>&1; cp $OUT/fm/kernel_stats_k256.csv $OUT/${R}_k256_kernel_stats.csv 2>/dev/null
 [ -x tools/bin/fm_rescore_probe ] && timeout 200 tools/bin/fm_rescore_probe > $OUT/${R}_fm_rescore_probe.txt 2>&1 < /dev/null
 timeout 600 python tools/soak_fused.py --tokens 262144 --N 131072 --d 4096 --k 256 --out $OUT/${R}_soak_k256_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak k256 exit $?"
 (MSAE_FM=1 timeout 400 python tools/fuzz_fused.py 1500 11; MSAE_FM=0 timeout 400 python tools/fuzz_fused.py 1500 11; timeout 400 python tools/fuzz_fused.py 1500 12) 2>&1 | grep -i "cases" > $OUT/${R}_fuzz.txt; cat $OUT/${R}_fuzz.txt
+echo "== exact path kernel (pre_acts_f32) =="
+timeout 120 python tools/f32_probe.py 10 2>&1 | tail -1 | tee $OUT/${R}_f32_rate.txt
 echo "== shapes / latency / shard emulation / training =="
 timeout 600 python tools/sanity_shapes.py > $OUT/${R}_other_shapes.txt 2>&1; cat $OUT/${R}_other_shapes.txt | grep "T="
 timeout 300 python tools/latency_small_T.py > $OUT/${R}_latency_small_T.txt 2>&1; grep "T=" $OUT/${R}_latency_small_T.txt
