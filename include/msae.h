@@ -30,11 +30,17 @@
  * multiply-add chains (v_mfma_f32_32x32x2_f32 / v_fma_f32), bit-identical to oracle/sae_oracle.c.
  * msae_encode_topk selects candidates with an int8 (or bf16) MFMA pass and re-scores them with the exact f32
  * chain, so its outputs are bit-identical to msae_pre_acts_f32 + msae_topk_f32 for every token it
- * VERIFIES: all features whose coarse value plus z sigma(token, feature) of the operand type's
- * rounding noise reaches the exact k-th value were re-scored (z = 7: a feature is missed only if its
- * own error exceeds 7 of its own sigma, < 3e-13 per token; every re-scored pair also checks the
- * error model).  Tokens it cannot verify are reported in `status` and recomputed by the exact path
- * inside the same call.
+ * VERIFIES: all features whose coarse value plus the error band of the pair (token, feature) reaches the exact
+ * k-th value were re-scored.  Tokens it cannot verify are reported in `status` and recomputed by the exact path
+ * inside the same call.  WHAT THE BAND GUARANTEES depends on the mode (msae_options):
+ *   default    int8 operands rounded STOCHASTICALLY with seeds drawn per call / per prepare (`dither`): for EVERY input a
+ *              member of the true top-k is missed with probability <= k exp(-z^2 / 2) over the library's own randomness
+ *              (Hoeffding; 7e-10 per token at z = 7, k = 32; guard_z = 8: 4e-13).  No assumption about the data.
+ *   certified  two int8 planes per operand, three MFMA segments, a DETERMINISTIC Cauchy-Schwarz band: no probability
+ *              left; ~2.5x the default's step time on large batches (`certified`).
+ *   exact      every token through the f32 MFMA path (`exact`); ~20x.
+ *   dither off / bf16 pass: the statistical contract of ABI <= 3 (z = 7 of the rounding-noise MODEL, < 3e-13 per token under
+ *              it; the model is checked on every re-scored pair) -- kept for A/B runs and for callers pinned to ABI 3.
  */
 #ifndef MSAE_H_
 #define MSAE_H_
