@@ -497,8 +497,8 @@ def invalidate_train_operands(W_enc: Optional[Tensor] = None) -> None:
     """Forget that the training loop's operand buffer of `W_enc` (all buffers when None) is fresh: the next training encode
     rebuilds it.  `_refresh_train_operands` trusts the tensor's version counter, which `p.data.copy_()` / `.data.mul_()`, a
     custom C op or an external optimiser writing through `.data` do NOT bump: call this wherever the weight is
-    edited that way (Sae.load / load_state_dict / set_decoder_norm_to_unit_norm / invalidate_prepared do).  MSAE_DEBUG_OPERANDS=1 rebuilds before
-    every training encode regardless."""
+    edited that way (`Sae.invalidate_prepared`, which `Sae.load_from_disk` ends with, does).  MSAE_DEBUG_OPERANDS=1 rebuilds
+    before every training encode regardless."""
     if W_enc is None:
         _TRAIN_FRESH.clear()
     else:
