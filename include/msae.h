@@ -71,8 +71,14 @@ enum {
  * fill what you need; NULL wherever a `const msae_options *` is taken means "all defaults".  Calls with
  * different options may run concurrently from different threads / streams.
  *   coarse_mode   operand type of the candidate pass: MSAE_COARSE_INT8 (per-token / per-feature scales, massive-
- *                 activation dims in a separately scaled k-tile), MSAE_COARSE_BF16, or MSAE_COARSE_DEFAULT
- *                 (environment MSAE_COARSE=bf16|int8, else int8).  Either way the candidates are re-scored with
+ *                 activation dims in a separately scaled k-tile), MSAE_COARSE_BF16, MSAE_COARSE_FP8 (ABI 4; OCP e4m3
+ *                 operands with per-token / per-feature scales through v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate --
+ *                 the "fp8 MFMA encoder path" of BASELINE configs[4]; batches of any size run the 256-row tile kernel;
+ *                 its prepared operands take the int8 operands' place in the buffer, so msae_encoder_prepare_opts /
+ *                 _refresh with the SAME mode must precede the encode -- an encode in a mode whose operands the buffer
+ *                 does not hold computes every token by the exact path; statistical contract like the bf16 pass, and
+ *                 ~2x the rows to re-score: slower than int8) or MSAE_COARSE_DEFAULT
+ *                 (environment MSAE_COARSE=bf16|int8|fp8, else int8).  Either way the candidates are re-scored with
  *                 the exact f32 chain, so outputs do not depend on it; the workspace size does (pass the same
  *                 options to the *_ws_bytes helper).
  *   guard_z       width z of the candidate pass's error band in standard deviations of its per-(token, feature)
@@ -130,7 +136,7 @@ enum {
  *   dither_seed   (ABI 4) 0: the library draws a seed per call (process-random base + atomic counter through a 64-bit
  *                 mixer -- the one piece of process state the library keeps); != 0: the seed of THIS call (reproducible
  *                 candidate sets: tests, A/B runs). */
-enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1 };
+enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1, MSAE_COARSE_FP8 = 2 };
 enum { MSAE_DITHER_DEFAULT = 0, MSAE_DITHER_ON = 1, MSAE_DITHER_OFF = 2 };
 typedef struct msae_options {
   uint32_t size;          /* sizeof(msae_options) of the caller's header (ABI 2's 24-byte and ABI 3's 40-byte structs are

@@ -44,6 +44,8 @@ constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 constexpr unsigned PREP_BF16 = 1u;   // W_bf16 + bf16 sample rows
 constexpr unsigned PREP_I8 = 2u;     // Wq row-major, tile-major (+ sample copies)
 constexpr unsigned PREP_FRAG = 4u;   // Wq fragment-major (+ sample copy): the weight-stream kernels of <= 128 tokens
+constexpr unsigned PREP_F8 = 8u;     // fp8 (e4m3) operands, tile-major: ALL rows in the row-major int8 region (off_wq), the sample rows in off_wqsp
+                                     // -- they overwrite int8 operands, so PREP_I8 / PREP_FRAG and PREP_F8 exclude each other
 
 __host__ __device__ inline bool fast_shape_ok(int N, int d) {
   return N % (SAMPLE_STRIDE * 256) == 0 && d % 64 == 0;  // sample width N/32 must tile by BN = 256
@@ -91,7 +93,7 @@ inline Prepared make_prepared(int N, int d) {
 // with the call.
 struct ProfState;
 struct CallOpts {
-  int mode;          // coarse-pass operand type: 0 = bf16, 1 = int8
+  int mode;          // coarse-pass operand type: 0 = bf16, 1 = int8, 2 = fp8 (e4m3)
   float z;           // width of the error band: u = coarse + z*sigma
   int detail;        // status = 1 | reason << 8 for tokens recomputed in the call
   ProfState *prof;   // stage timing handle or null
@@ -147,9 +149,9 @@ inline bool resolve_opts(const msae_options *o, CallOpts &c) {
   else if (c.seed == 0ull) c.seed = draw_seed();
   if (c.mode < 0) {
     const char *e = getenv("MSAE_COARSE");
-    c.mode = (e && e[0] == 'b') ? 0 : 1;
+    c.mode = (e && e[0] == 'b') ? 0 : ((e && e[0] == 'f') ? 2 : 1);
   }
-  if (c.mode != 0 && c.mode != 1) return false;
+  if (c.mode != 0 && c.mode != 1 && c.mode != 2) return false;
   if (c.z == 0.f) {
     const char *e = getenv("MSAE_GUARD_Z");
     const float v = e ? (float)atof(e) : 0.f;
@@ -181,6 +183,13 @@ constexpr float GUARD_E0_SX = 4.f * 7.f * 0.288675f;   // 4 bands of z = 7: 8.08
 __host__ __device__ inline float x_round_var(bool dither) { return dither ? 0.25f * 1.001f : 1.f / 12.f; }
 constexpr float GUARD_ZETA = MSAE_GUARD_ZETA;   // first round reaches zeta sigma below the k-th coarse value
 constexpr float BF16_REL_VAR2 = 5.5e-6f;  // variance of the sum of two relative bf16 roundings (2 x 2^-16/3 x E[1/m^2])
+// fp8 (e4m3: 4 significant bits, half an ulp = 2^-4 of the binade): 2 x 2^-8/3 x E[1/m^2] = 256 x the bf16 figure.  Elements below
+// the format's normal range round on an ABSOLUTE grid instead: after the per-token / per-feature scaling (largest element -> 224,
+// inside OCP e4m3's 448 and FNUZ's 240) the subnormal step is at most 2^-9 of a scaled unit; their variance enters the band as
+// sx^2 |W_n|^2 v_abs + sw_n^2 |a_t|^2 v_abs, v_abs = 2^-18 / 3 (a factor 4 of slack on (2^-10)^2 / 3 for either format).
+constexpr float FP8_REL_VAR2 = 256.f * 5.5e-6f;
+constexpr float FP8_ABS_VAR = 3.8146973e-6f / 3.f;
+constexpr float FP8_MAX = 224.f;
 
 // index output of one call: 32-bit (msae_encode_topk), 64-bit (msae_encode_topk_i64), never both null
 struct IdxOut { int32_t *i32; int64_t *i64; };

@@ -75,6 +75,7 @@ namespace {
 using GemmBf16 = GemmCfg<256, 256, 2, 2, 4, false>;
 using GemmI8 = GemmCfg<256, 256, 2, 2, 4, true>;
 using GemmI8Cert = GemmCfg<256, 256, 2, 2, 4, true, 32>;   // msae_options::certified (encode_cert.h)
+using GemmF8 = GemmCfg<256, 256, 2, 2, 4, false, 64>;      // MSAE_COARSE_FP8: e4m3 operands (BASELINE configs[4])
 constexpr int G_BM = GemmBf16::BM;
 
 // three scratch ranges in one launch (candidate counters, flag list, column maxima)
@@ -133,7 +134,7 @@ inline void prof_step(ProfState *pf) {
 
 // ---- workspace carving -------------------------------------------------------------------------
 struct FusedPlan {
-  bool fast, i8, small, fm;
+  bool fast, i8, small, fm, f8;
   size_t off_fmcount, off_fmtarget, off_fmkeys, off_fmpairs, off_fmpre, off_fmdefer;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
@@ -163,6 +164,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     if (shard_C > 0) { const int rs = shard_C / 8 > 8 ? shard_C / 8 : 8; if (rs < p.r) p.r = rs; }
     p.cap = next_pow2(128 * p.r);           // 4x the expected count
     p.i8 = mode == 1 && i8_shape_ok(N, d);
+    p.f8 = mode == 2 && i8_shape_ok(N, d);     // (other shapes: the bf16 pass, whose operands an fp8 prepare builds as well)
     p.small = !cert && p.i8 && small_shape_ok(T, d, N, k) && getenv("MSAE_NO_SMALL_PATH") == nullptr;
     // most rows one token may read before it is handed to the exact path (the needed set is ~k + 10:
     // reaching this means the band is not separating anything); at least k + 4 (first-round minimum)
@@ -193,7 +195,7 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_stau = take((size_t)T * 4);
       p.off_sviol = take((size_t)T * 2 * 4);            // model-check flags [T] | finished-wave counters [T]
     }
-    p.off_xb = take(p.i8 ? 256 : (size_t)p.Tp * d * 2);
+    p.off_xb = take(p.i8 ? 256 : (size_t)p.Tp * d * (p.f8 ? 1 : 2));
     p.off_a32 = take((size_t)T * d * 4);
     p.off_sample = take((size_t)T * p.S * 4);
     const size_t tau_n = (size_t)T * p.r;
@@ -417,10 +419,12 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, n_cnt, flagged, (size_t)T + 64 + pl.fb_chunks,
                      pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d * COLMAX_PARTS : (size_t)0);
   if (!pl.i8)
-    hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
+    hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.f8 ? T : pl.Tp, d,
+                       pl.f8 ? (unsigned short *)nullptr : xb, a32);
 
   GemmOperands op_main{}, op_samp{};
-  const float z = co.z, zz12 = z * z / 12.f, zzx = z * z * x_round_var(pl.i8 && co.seed != 0ull);   // (see run_small)
+  // (see run_small; fp8: the band's absolute-grid terms, encode_defs.h)
+  const float z = co.z, zz12 = z * z / 12.f, zzx = pl.f8 ? z * z * FP8_ABS_VAR : z * z * x_round_var(pl.i8 && co.seed != 0ull);
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   f32x4 *cc_perm = nullptr;        // ... of the main pass in its own column order when it leaves the sample rows out
@@ -479,6 +483,19 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     op_samp = op_main;
     op_samp.B = skinny ? prepared + pp.off_wqsf : tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
+  } else if (pl.f8) {
+    // e4m3 operands: x scaled per token, W per feature (prepared), both tile-major like the int8 operands; no outlier tile (the
+    // format's own dynamic range takes the massive-activation dims), the main pass over ALL features like the bf16 pass
+    signed char *x8 = reinterpret_cast<signed char *>(xb);
+    hipLaunchKernelGGL(quant_x_fp8_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, x8, rowc, z * z, valid);
+    colc = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
+    colc_s = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf_s);
+    op_main.A = reinterpret_cast<const unsigned char *>(x8); op_main.ldA = d;
+    op_main.B = prepared + pp.off_wq; op_main.ldB = d;
+    op_main.nk = d / 128;
+    op_main.packed = 1;
+    op_samp = op_main;
+    op_samp.B = prepared + pp.off_wqsp;
   } else {
     hipLaunchKernelGGL(row_p4_kernel, dim3(T), dim3(256), 0, s, a32, T, d, rowc, z * z, valid);
     colc = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
@@ -502,6 +519,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                     : skinny == 128 ? gemm_skinny_launch<128, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 256 ? gemm_skinny_launch<256, true>(op_samp, T, d, pl.S, ep, s)
                     : pl.i8         ? gemm_launch<GemmI8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
+                    : pl.f8         ? gemm_launch<GemmF8, true>(op_samp, T, pl.Tp, pl.S, ep, s)
                                     : gemm_launch<GemmBf16, true>(op_samp, T, pl.Tp, pl.S, ep, s);
     if (grc) return grc;
   }
@@ -545,6 +563,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                     : skinny == 128 ? gemm_skinny_launch<128, false>(op_main, T, d, N_main, ep, s)
                     : skinny == 256 ? gemm_skinny_launch<256, false>(op_main, T, d, N_main, ep, s)
                     : pl.i8         ? gemm_launch<GemmI8, false>(op_main, T, pl.Tp, N_main, ep, s)
+                    : pl.f8         ? gemm_launch<GemmF8, false>(op_main, T, pl.Tp, N, ep, s)
                                     : gemm_launch<GemmBf16, false>(op_main, T, pl.Tp, N, ep, s);
     if (grc) return grc;
   }
@@ -555,7 +574,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     PackArgs pa{};
     pa.cnt = cnt; pa.cand = cand; pa.cap = pl.cap;
     pa.tau_vals = tauv; pa.tau_ld = pl.r; pa.tau_col = pl.r - 1;
-    pa.rowc = rowc; pa.colc = colc; pa.zz12 = zzx; pa.i8 = pl.i8 ? 1 : 0;
+    pa.rowc = rowc; pa.colc = colc; pa.zz12 = zzx; pa.i8 = (pl.i8 || pl.f8) ? 1 : 0;
     pa.C = shard->C; pa.row_offset = shard->row_offset; pa.stride = shard_record_bytes(shard->C);
     pa.recs = shard->recs;
     if (pl.cap <= 64 * 32) hipLaunchKernelGGL(pack_candidates_kernel<32>, dim3(T), dim3(64), 0, s, pa);
@@ -572,7 +591,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.tau_vals = tauv; ra.tau_ld = pl.r; ra.tau_col = pl.r - 1;
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
-    ra.rowc = rowc; ra.colc = colc; ra.zz12 = zzx; ra.z2 = z * z; ra.i8 = pl.i8 ? 1 : 0;
+    ra.rowc = rowc; ra.colc = colc; ra.zz12 = zzx; ra.z2 = z * z; ra.i8 = (pl.i8 || pl.f8) ? 1 : 0;   // (fp8: the three-term band as well)
     ra.zc2 = guard_z_check2(pl.i8 && co.seed != 0ull);
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
@@ -798,10 +817,14 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, un
     const bool i8 = i8_shape_ok(N, d);
     RowQuantOut ro = row_quant_out(base, p, modes, i8);
     ro.seed = seed;
-    if ((modes & 2) && i8)   // row statistics (both passes' error bands) + int8 operands
+    if ((modes & 2) && i8 && !(modes & 8))   // row statistics (both passes' error bands) + int8 operands
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
     else
       hipLaunchKernelGGL(row_stats_quant_kernel<false>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
+    if ((modes & 8) && i8)                    // fp8 operands where the int8 ones would be (PREP_F8)
+      hipLaunchKernelGGL(quant_w_fp8_kernel, dim3(N), dim3(256), 0, s, W_enc, N, d,
+                         reinterpret_cast<const f32x4 *>(base + p.off_colbf), reinterpret_cast<signed char *>(base + p.off_wq),
+                         reinterpret_cast<signed char *>(base + p.off_wqsp));
   }
   return msae_launch_status();
 }
@@ -811,7 +834,8 @@ extern "C" int msae_encoder_prepare_opts(const float *W_enc, int N, int d, void 
                                          void *stream) {
   CallOpts co;
   if (!resolve_opts(opts, co)) return MSAE_EINVAL;
-  return prepare_impl(W_enc, N, d, prepared, 3, co.seed, (hipStream_t)stream);
+  // (fp8: its operands take the int8 operands' place -- bf16 + fp8; every other mode: bf16 + int8, either pass can run)
+  return prepare_impl(W_enc, N, d, prepared, co.mode == 2 ? (1 | 8) : 3, co.seed, (hipStream_t)stream);
 }
 extern "C" int msae_encoder_prepare(const float *W_enc, int N, int d, void *prepared, void *stream) {
   return msae_encoder_prepare_opts(W_enc, N, d, prepared, nullptr, stream);
@@ -823,6 +847,7 @@ extern "C" int msae_encoder_refresh(const float *W_enc, int N, int d, void *prep
   CallOpts co;
   if (!resolve_opts(opts, co)) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
+  if (co.mode == 2) return prepare_impl(W_enc, N, d, prepared, 1 | 8, co.seed, (hipStream_t)stream);
   return prepare_impl(W_enc, N, d, prepared, i8 ? 2 : 1, co.seed, (hipStream_t)stream);
 }
 
@@ -833,6 +858,7 @@ extern "C" int msae_encoder_refresh_for(const float *W_enc, int N, int d, void *
   CallOpts co;
   if (!resolve_opts(opts, co) || T_next <= 0) return MSAE_EINVAL;
   const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
+  if (co.mode == 2) return prepare_impl(W_enc, N, d, prepared, 1 | 8, co.seed, (hipStream_t)stream);
   return prepare_impl(W_enc, N, d, prepared, (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0), co.seed, (hipStream_t)stream);
 }
 
@@ -1076,7 +1102,7 @@ extern "C" int msae_shard_candidates(const void *x, int x_dtype, const float *b_
   if (x_dtype != MSAE_F32 && x_dtype != MSAE_BF16 && x_dtype != MSAE_F16) return MSAE_EINVAL;
   if (T == 0) return 0;
   FusedPlan pl = make_plan(T, d, N, k, co.mode, C);
-  if (!pl.fast || !prepared || C > pl.cap) return MSAE_ENOTIMPL;   // shapes without the candidate pass: use msae_encode_topk per shard
+  if (!pl.fast || !prepared || C > pl.cap || pl.f8) return MSAE_ENOTIMPL;   // shapes / modes without the candidate exchange: msae_encode_topk per shard
   pl.small = false;
   if (ws_bytes < pl.bytes || !ws) return MSAE_EWS;
   if (!msae_aligned(ws, 256) || !msae_aligned(records, 8)) return MSAE_EALIGN;

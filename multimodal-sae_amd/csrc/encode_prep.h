@@ -109,7 +109,10 @@ __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W,
   if (threadIdx.x == 0) {
     const float q_bf = __builtin_sqrtf(s4);
     const f32x4 st = {scale, scale * scale * (dither ? 12.f * x_round_var(true) : 1.f), s2, q_bf};
-    const f32x4 cb = {1.f, q_bf, 0.f, 0.f};
+    // bf16 pass: only Q_bf is read.  fp8 pass (quant_w_fp8_kernel / GemmCfg::F8): (sw8, Q_bf, |W_n|^2, sw8^2) -- the value scale and
+    // the two absolute-grid terms of its band (encode_defs.h: FP8_ABS_VAR)
+    const float sw8 = m > 0.f ? m / FP8_MAX : 1.f;
+    const f32x4 cb = {sw8, q_bf, s2, sw8 * sw8};
     wstat[n] = st;
     colbf[n] = cb;
     if (samp) { wstat_s[n / SAMPLE_STRIDE] = st; colbf_s[n / SAMPLE_STRIDE] = cb; }
@@ -156,6 +159,68 @@ __global__ __launch_bounds__(256) void row_stats_quant_kernel(const float *__res
   row_stats_quant_row<QUANT>(W, blockIdx.x, d, o, red);
 }
 
+// ---- fp8 (e4m3) operands (BASELINE configs[4]) ----------------------------------------------------------------------------
+__device__ __forceinline__ int pack4_fp8(const f32x4 v) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  return w;
+}
+// W side, once per weight load: row n scaled by 1 / sw8 (colbf[n][0], written by row_stats_quant_kernel in front of this) -> e4m3,
+// tile-major: every row into `w8` (full width, row n), the sample rows also into `w8s`.  One 256-thread workgroup per row.
+__global__ __launch_bounds__(256) void quant_w_fp8_kernel(const float *__restrict__ W, int N, int d,
+                                                         const f32x4 *__restrict__ colbf, signed char *__restrict__ w8,
+                                                         signed char *__restrict__ w8s) {
+  const int n = blockIdx.x;
+  const float inv = 1.f / colbf[n][0];
+  const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
+  const float *row = W + (size_t)n * d;
+  for (int c = threadIdx.x * 16; c < d; c += 4096) {
+    i32x4 packed;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) packed[q] = pack4_fp8(*reinterpret_cast<const f32x4 *>(row + c + 4 * q) * inv);
+    *reinterpret_cast<i32x4 *>(w8 + packed_off((size_t)n, c, d)) = packed;
+    if (samp) *reinterpret_cast<i32x4 *>(w8s + packed_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
+  }
+}
+// x side, every call: one 256-thread workgroup per token row of the padded tile.  a32 holds x - b_dec.
+//   rowc[t] = (sx = max|a| / 224, M = |a|_2 / sx, P = z^2 FP8_REL_VAR2 |a|_4^2, flag)     (band: encode_defs.h)
+__global__ __launch_bounds__(256) void quant_x_fp8_kernel(const float *__restrict__ a32, int T, int d, signed char *__restrict__ x8,
+                                                         f32x4 *__restrict__ rowc, float z2, const unsigned *__restrict__ valid) {
+  __shared__ float red[3][4];
+  const int t = blockIdx.x;
+  if (t >= T) {
+    for (int c = threadIdx.x * 16; c < d; c += 4096) *reinterpret_cast<i32x4 *>(x8 + packed_off((size_t)t, c, d)) = i32x4{0, 0, 0, 0};
+    if (threadIdx.x == 0) rowc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const float *row = a32 + (size_t)t * d;
+  float m = 0.f, s2 = 0.f, s4 = 0.f;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float q = v[e] * v[e]; m = fmaxf(m, fabsf(v[e])); s2 += q; s4 = __builtin_fmaf(q, q, s4); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, off, 64)); s2 += __shfl_xor(s2, off, 64); s4 += __shfl_xor(s4, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s4; }
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  s4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  const float sx = m > 0.f ? m / FP8_MAX : 1.f, inv = 1.f / sx;
+  for (int c = threadIdx.x * 16; c < d; c += 4096) {
+    i32x4 packed;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) packed[q] = pack4_fp8(*reinterpret_cast<const f32x4 *>(row + c + 4 * q) * inv);
+    *reinterpret_cast<i32x4 *>(x8 + packed_off((size_t)t, c, d)) = packed;
+  }
+  if (threadIdx.x == 0)
+    rowc[t] = f32x4{sx, __builtin_sqrtf(s2) * inv, z2 * FP8_REL_VAR2 * __builtin_sqrtf(s4), (*valid & PREP_F8) ? 0.f : 1.f};
+}
+
 // pointers into a prepared buffer for the operand groups `modes` rebuilds (bit 1: int8 operands, bit 2: without the
 // fragment-major copies); stats are rebuilt by every mode
 inline RowQuantOut row_quant_out(unsigned char *base, const Prepared &p, int modes, bool i8) {
@@ -174,6 +239,7 @@ inline RowQuantOut row_quant_out(unsigned char *base, const Prepared &p, int mod
 }
 // which operand groups a prepare / refresh of `modes` leaves valid (Prepared::valid)
 inline unsigned prep_valid_bits(int modes, int N, int d) {
+  if ((modes & 8) && i8_shape_ok(N, d)) return ((modes & 1) ? PREP_BF16 : 0u) | PREP_F8;   // (fp8 operands sit where int8 ones would)
   return ((modes & 1) ? PREP_BF16 : 0u) | (((modes & 2) && i8_shape_ok(N, d)) ? (PREP_I8 | ((modes & 4) ? 0u : PREP_FRAG)) : 0u);
 }
 

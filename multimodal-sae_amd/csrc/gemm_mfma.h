@@ -107,12 +107,20 @@ struct GemmOperands {
 //   bit 3 ABL_NOREAD   read the fragments once and reuse them
 //   bit 4 ABL_NOMFMA   issue no MFMA
 //   bit 5 CERT         the certified three-segment pass (encode_cert.h); I8 only
+//   bit 6 F8           fp8 (e4m3) operands, f32 accumulate (I8 = false)
 template <int BM_, int BN_, int STAGES_, int WM_, int WN_, bool I8_ = false, int FLAGS_ = 0>
 struct GemmCfg {
   static constexpr int BM = BM_, BN = BN_, STAGES = STAGES_, WM = WM_, WN = WN_;
   static constexpr bool I8 = I8_;
   static constexpr bool ABL_NOSTAGE = FLAGS_ & 4, ABL_NOREAD = FLAGS_ & 8, ABL_NOMFMA = FLAGS_ & 16;
   static constexpr bool CERT = FLAGS_ & 32;       // certified pass (GemmOperands::cert): its own instantiation, the product kernel is untouched
+  // fp8 candidate pass (BASELINE configs[4]: "fp8 MFMA encoder path"): one byte per operand element exactly like int8 -- the SAME
+  // tile-major operands, LDS image, ring and hand-scheduled fragment reads -- multiplied by v_mfma_f32_32x32x16_fp8_fp8 (two per
+  // 16-byte fragment pair: the low and the high 8 bytes of the lanes) into f32 accumulators; per-token / per-feature scales in
+  // the epilogue as on the int8 path, the error band of the bf16 path's form (relative roundings).  I8_ must be false.
+  static constexpr bool F8 = FLAGS_ & 64;
+  static_assert(!(I8_ && (FLAGS_ & 64)), "fp8 accumulates in f32");
+  static constexpr bool SCALED = I8_ || F8;       // value = acc * sx[t] * sw[n] + bias (else: acc + bias)
   static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
   static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   static constexpr int ROWB = 128;               // bytes per tile row: 64 bf16 or 128 int8
@@ -241,10 +249,15 @@ __device__ __forceinline__ void gemm_mfma_step(f32x16 (&acc)[C::MI][C::NI], cons
   for (int i = 0; i < C::MI; ++i)
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) {
-      if constexpr (C::I8)   // the accumulator registers hold i32 on this path
+      if constexpr (C::I8) {  // the accumulator registers hold i32 on this path
         acc[i][j] = __builtin_bit_cast(
             f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
-      else
+      } else if constexpr (C::F8) {
+        typedef long i64x2 __attribute__((ext_vector_type(2)));
+        const i64x2 a2 = __builtin_bit_cast(i64x2, a[i]), b2 = __builtin_bit_cast(i64x2, b[j]);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[0], b2[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[1], b2[1], acc[i][j], 0, 0, 0);
+      } else
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
                                                             __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
     }
@@ -414,7 +427,7 @@ template <class C>
 __device__ __forceinline__ float gemm_band_sq(const float *side, int row, int col, float zz12) {
   const float *row_c = side, *col_c = side + C::BM;
   const float pz = row_c[3 * C::NT + row];
-  if constexpr (!C::I8) return pz * col_c[2 * C::NT + col];
+  if constexpr (!C::I8 && !C::F8) return pz * col_c[2 * C::NT + col];
   const float rs = row_c[C::NT + row], mf = row_c[4 * C::NT + row];
   const float rz = rs * rs * zz12;
   return __builtin_fmaf(pz, col_c[2 * C::NT + col], __builtin_fmaf(rz * mf * mf, col_c[4 * C::NT + col], rz * col_c[3 * C::NT + col]));
@@ -486,7 +499,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
       for (int e = 0; e < 16; ++e) {
         const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         tau[e] = row_c[row];
-        rs[e] = C::I8 ? row_c[C::NT + row] : 0.f;
+        rs[e] = C::SCALED ? row_c[C::NT + row] : 0.f;
         bt[e] = row_c[5 * C::NT + row];
       }
 #pragma unroll
@@ -500,6 +513,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
           if constexpr (C::I8) {
             const f32x2 a = {(float)__builtin_bit_cast(i32x16, acc[i][j])[e], (float)__builtin_bit_cast(i32x16, acc[i][j])[e + 1]};
             v = a * (rs2 * c_sw[j]) + c_bias[j];
+          } else if constexpr (C::F8) {
+            v = f32x2{acc[i][j][e], acc[i][j][e + 1]} * (rs2 * c_sw[j]) + c_bias[j];
           } else {
             v = f32x2{acc[i][j][e], acc[i][j][e + 1]} + c_bias[j];
           }
@@ -574,6 +589,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
           const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, t = m0 + row;
           float v;
           if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
+          else if constexpr (C::F8) v = acc[i][j][e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
           else v = acc[i][j][e] + c_bias[j];
           if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
         }
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         side3 = rc[2];
         side4 = 1.f;
         if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
-        if constexpr (C::CERT) side4 = rc[1];
+        if constexpr (C::CERT || C::F8) side4 = rc[1];
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
@@ -823,7 +839,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     float side5 = 0.f;
     if (tid_ < C::BM) {          // B_t: z sigma of this token against the reference feature
       float b2 = side3 * ref0;
-      if constexpr (C::I8) {
+      if constexpr (C::I8 || C::F8) {
         const float rz = side1 * side1 * ep.zz12;
         b2 = __builtin_fmaf(rz * side4 * side4, ref2, __builtin_fmaf(rz, ref1, b2));
       }
@@ -831,7 +847,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     } else if (tid_ < C::BM + C::BN) {   // h_n >= sqrt of every ratio to the reference feature (0/0 counts as 0)
       const float q = __int_as_float(side2);
       float h2 = q / ref0;
-      if constexpr (C::I8) {
+      if constexpr (C::I8 || C::F8) {
         h2 = fmaxf(h2, side3 / ref1);
         if (side4 > 0.f) h2 = fmaxf(h2, side4 / ref2);
       }

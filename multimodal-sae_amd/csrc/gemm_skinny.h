@@ -24,7 +24,7 @@ struct SkinnyCfg {
   // 150 us pass.
   static constexpr int BM = BM_, NWAVES = NW_, BN = 32 * NW_, WM = 1, WN = NW_, NT = 64 * NW_;
   static constexpr int TM = BM, TN = 32, MI = BM / 32, NI = 1;
-  static constexpr bool I8 = true;
+  static constexpr bool I8 = true, F8 = false, CERT = false, SCALED = true;   // (gemm_mfma.h's epilogue reads these)
   static constexpr int KC = (NW_ == 4 ? 32768 : 65536) / BM;   // bytes of k per A chunk
   // ADMA (the 256-token tile): the token rows travel L2 -> LDS by LDS-DMA (global_load_lds, as gemm_mfma.h's operands) instead of
   // through 32 registers per lane, which buys the B stream a second k-step in flight (UN = 2: 64 KB of weights in flight per CU

@@ -91,7 +91,7 @@ class StageProfile:
 
 
 class Options:
-    COARSE = {"default": -1, "bf16": 0, "int8": 1}
+    COARSE = {"default": -1, "bf16": 0, "int8": 1, "fp8": 2}
     DITHER = {"default": 0, "on": 1, "off": 2}
 
     def __init__(self, coarse: str = "default", guard_z: float = 0.0, status_detail: bool = False,
@@ -151,7 +151,7 @@ _DITHER_NAME = {0: "default", 1: "on", 2: "off"}
 def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = False, exact: bool = False,
           dither: int = 0, dither_seed: int = 0, cert_ops: Optional[Tensor] = None) -> _OptsRef:
     """Options of one call: explicit arguments win, the process defaults fill the rest."""
-    coarse = _defaults.coarse if coarse_mode < 0 else ("int8" if coarse_mode == 1 else "bf16")
+    coarse = _defaults.coarse if coarse_mode < 0 else {0: "bf16", 1: "int8", 2: "fp8"}[coarse_mode]
     z = guard_z if guard_z > 0.0 else _defaults.guard_z
     detail = bool(status_detail or _defaults.status_detail)
     exact = bool(exact or _defaults.exact)
@@ -365,7 +365,8 @@ topk.register_autograd(_topk_backward, setup_context=_topk_setup)
 
 
 def set_coarse_mode(mode: str) -> None:
-    """Default operand type of the fused encoder's candidate pass for this process's ops: "int8", "bf16" or
+    """Default operand type of the fused encoder's candidate pass for this process's ops: "int8", "bf16", "fp8" (e4m3
+    operands -- BASELINE configs[4]; its prepared operands take the int8 ones' place, so prepare under the mode you encode in) or
     "default" (environment MSAE_COARSE, else int8).  Outputs do not depend on it (candidates are re-scored
     exactly); speed does.  A host-layer default: the library itself takes the mode per call (msae_options)."""
     if mode not in Options.COARSE:

@@ -17,6 +17,7 @@ There is no CPU implementation: calling a compute method with CPU tensors raises
 from __future__ import annotations
 
 import json
+import os
 import re
 from fnmatch import fnmatch
 from pathlib import Path
@@ -182,7 +183,9 @@ class Sae(nn.Module):
 
     def _prepared_weights(self) -> Optional[Tensor]:
         w = self.encoder.weight
-        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        # (+ whether the fp8 pass is in force: its operands replace the int8 ones in the buffer)
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device,
+               ops._defaults.coarse == "fp8" or (ops._defaults.coarse == "default" and os.environ.get("MSAE_COARSE", "")[:1] == "f"))
         if self._prepared is None or self._prepared_key != key:
             self._prepared = ops.prepare_encoder(w)
             self._prepared_key = key

@@ -29,7 +29,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["int8", "bf16", "certified"])
+@pytest.fixture(params=["int8", "bf16", "certified", "fp8"])
 def coarse(request, dev):
     """Operand type of the candidate pass; "certified" = msae_options::certified (two int8 planes per operand, deterministic
     band): every bit-exactness test of this file runs in that mode as well."""
@@ -184,17 +184,24 @@ def test_small_T_path_on_heterogeneous_weights(dev, kind):
     assert n_fb <= 0.25 * n_tok, "the small-batch path should verify most tokens on its own"
 
 
-def test_width_262144_against_oracle(dev):
-    """BASELINE configs[4] width: fused == exact on every token, exact == CPU oracle on 16 tokens."""
+@pytest.mark.parametrize("mode", ["int8", "fp8"])
+def test_width_262144_against_oracle(dev, mode):
+    """BASELINE configs[4]: width 262144, with the int8 pass and with the "fp8 MFMA encoder path" the config names (e4m3
+    operands, MSAE_COARSE_FP8): fused == exact on every token, exact == CPU oracle on 16 tokens."""
     from msae import ops
     from oracle import oracle
 
     d, N, T, k = 4096, 262144, 1024, 32
     W, b, bd = hostile.weights("lognorm", N, d, dev, seed=7)
     x = hostile.activations(T, d, dev, seed=8)
-    _compare(ops, x, W, b, bd, k, "lognorm N=262144")
-    prepared = ops.prepare_encoder(W)
-    v, i, _ = ops.encode_topk(x[:16], W, b, bd, prepared, k)
+    ops.set_coarse_mode(mode)
+    try:
+        hist = _compare(ops, x, W, b, bd, k, f"lognorm N=262144 {mode}", max_fallback=0.1 if mode == "fp8" else 0.03)
+        assert hist["verified"] > 0.9 * T                # the candidate pass of the mode did the work
+        prepared = ops.prepare_encoder(W)
+        v, i, _ = ops.encode_topk(x[:16], W, b, bd, prepared, k)
+    finally:
+        ops.set_coarse_mode("int8")
     ref_v, ref_i = oracle.encode_topk(x[:16].float().cpu().numpy(), W.cpu().numpy(), b.cpu().numpy(),
                                       bd.cpu().numpy(), k)
     assert np.array_equal(i.cpu().numpy().astype(np.int32), ref_i)

@@ -277,7 +277,7 @@ def _rand_x(dev, T, d, seed):
     return x.to(torch.bfloat16)
 
 
-@pytest.fixture(params=["int8", "bf16", "certified"])
+@pytest.fixture(params=["int8", "bf16", "certified", "fp8"])
 def coarse(request, dev):
     """Both operand types of the fused encoder's candidate pass, and the certified pass (msae_options::certified: two int8 planes
     per operand, deterministic band); outputs must not depend on it."""
