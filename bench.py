@@ -351,8 +351,10 @@ class HipRuntime:
 
         @contextlib.contextmanager
         def cm():
-            prev = (ops._defaults.exact, ops._defaults.dither, getattr(ops._defaults, "certified", False))
+            prev = (ops._defaults.exact, ops._defaults.dither, getattr(ops._defaults, "certified", False), ops._defaults.coarse)
             try:
+                if "coarse" in kw:
+                    ops.set_coarse_mode(kw["coarse"])
                 if "exact" in kw:
                     ops.set_exact(kw["exact"])
                 if "dither" in kw:
@@ -362,6 +364,7 @@ class HipRuntime:
                 yield
             finally:
                 ops.set_exact(prev[0])
+                ops.set_coarse_mode(prev[3])
                 ops.set_dither(prev[1], ops._defaults.dither_seed)
                 if hasattr(ops, "set_certified"):
                     ops.set_certified(prev[2])
@@ -498,7 +501,7 @@ def main(argv=None, rt=None):
     res = {"metric": "tokens/sec through SAE encode+TopK+decode, d=4096 width=131072", "value": None,
            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-           "dtype": ("int8" if os.environ.get("MSAE_COARSE", "int8")[0] != "b" else "bf16") +
+           "dtype": {"b": "bf16", "f": "fp8 (e4m3)"}.get(os.environ.get("MSAE_COARSE", "int8")[:1], "int8") +
                     " MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
            "data": data,
            "dither": "off (round to nearest: statistical contract)" if os.environ.get("MSAE_DITHER", "1")[0] == "0" else
@@ -590,14 +593,15 @@ def main(argv=None, rt=None):
 
     def roofline_fields(stage, dec_ms, out, rows, tokens_decoded, with_traffic):
         mean = stage.mean(0)
-        i8 = os.environ.get("MSAE_COARSE", "int8")[0] != "b"
+        cm = {"b": "bf16", "f": "fp8"}.get(os.environ.get("MSAE_COARSE", "int8")[:1], "int8")
+        i8 = cm == "int8"
         # the int8 main pass of a batch of more than 256 tokens runs over 31/32 of the features (the sample pass has
         # scored the rest, encode_fused.hip: main_row): count the work the launch does, not the width
         width = rows - rows // 32 if (i8 and T > 256 and not os.environ.get("MSAE_GEMM_ROWMAJOR")) else rows
         ach = 2.0 * T * d * width / (float(mean[3]) * 1e-3) / 1e12
-        peak = PEAK_I8_TOPS if i8 else PEAK_BF16_TFLOPS
-        kname = "gemm_kernel<int8,THRESH>" if i8 else "gemm_kernel<bf16,THRESH>"
-        sustained = SUSTAINED_I8_TOPS if i8 else SUSTAINED_BF16_TFLOPS
+        peak = PEAK_BF16_TFLOPS if cm == "bf16" else PEAK_I8_TOPS         # (dense fp8 = dense int8 = 2x bf16, the guide)
+        kname = "gemm_kernel<%s,THRESH>" % cm
+        sustained = {"int8": SUSTAINED_I8_TOPS, "bf16": SUSTAINED_BF16_TFLOPS, "fp8": SUSTAINED_I8_TOPS}[cm]
         traffic, traffic_src, pmc_extra = load_traffic(kname) if with_traffic else (None, None, {})
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak,
@@ -685,7 +689,18 @@ def main(argv=None, rt=None):
                 rec.update(stage_fields(st, dm, o, k))
                 return rec
 
+            def run_fp8():
+                with rt.options(coarse="fp8"):
+                    e5 = rt.engine(W_enc, b_enc, W_dec, b_dec, k)      # (prepared under the mode: e4m3 operands)
+                    el, o, st, dm = timed(e5, xs, sec_steps, sec_warm, profile=True)
+                rec = {"ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
+                       "note": "MSAE_COARSE_FP8: the candidate pass on e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8) -- BASELINE "
+                               "configs[4]'s 'fp8 MFMA encoder path'; same exact outputs, a ~5x wider band than int8"}
+                rec.update(stage_fields(st, dm, o, k))
+                return rec
+
             record("k256", run_k256)
+            record("coarse_fp8", run_fp8)
             record("zipf", run_zipf)
             record("exact_modes", run_modes)
             record("dither_off", run_dither_off)

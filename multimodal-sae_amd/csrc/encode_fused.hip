@@ -171,15 +171,17 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
     p.r_max = k <= 64 ? 8 * k : 3 * k;
     if (p.r_max < k + 4) p.r_max = k + 4;
     if (p.r_max > p.cap) p.r_max = p.cap;
-    if (p.i8) {
-      p.off_xq = take((size_t)p.Tp * d * (cert ? 2 : 1));   // (certified: two planes per token row)
-      p.off_xqo = take((size_t)p.Tp * MAX_OUT);
+    if (p.i8 || p.f8) {   // the batch's massive-activation dims and the per-call column constants of the band
       p.off_colc = take((size_t)N * 16);
       p.off_colc_s = take((size_t)p.S * 16);
-      p.off_colc_p = take((size_t)N * 16);
+      p.off_colc_p = take(p.i8 ? (size_t)N * 16 : 0);
       p.off_colmax = take((size_t)d * 4 * COLMAX_PARTS);
       p.off_odims = take((size_t)(MAX_OUT + 1) * 4);
       p.off_isout = take((size_t)d);
+    }
+    if (p.i8) {
+      p.off_xq = take((size_t)p.Tp * d * (cert ? 2 : 1));   // (certified: two planes per token row)
+      p.off_xqo = take((size_t)p.Tp * MAX_OUT);
       p.off_wqo = take((size_t)N * MAX_OUT);
       p.off_wqos = take((size_t)p.S * MAX_OUT);
     }
@@ -417,10 +419,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
   const int seg_cap = pl.cap / pl.segs;
   const size_t n_cnt = pl.segs > 1 ? (pl.off_segcnt - pl.off_cnt) / 4 + (size_t)T * pl.segs : (size_t)T;
   hipLaunchKernelGGL(zero3_i32_kernel, dim3(64), dim3(256), 0, s, cnt, n_cnt, flagged, (size_t)T + 64 + pl.fb_chunks,
-                     pl.i8 ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr, pl.i8 ? (size_t)d * COLMAX_PARTS : (size_t)0);
-  if (!pl.i8)
-    hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.f8 ? T : pl.Tp, d,
-                       pl.f8 ? (unsigned short *)nullptr : xb, a32);
+                     (pl.i8 || pl.f8) ? reinterpret_cast<int *>(ws + pl.off_colmax) : (int *)nullptr,
+                     (pl.i8 || pl.f8) ? (size_t)d * COLMAX_PARTS : (size_t)0);
+  if (!pl.i8 && !pl.f8)
+    hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, pl.Tp, d, xb, a32);
 
   GemmOperands op_main{}, op_samp{};
   // (see run_small; fp8: the band's absolute-grid terms, encode_defs.h)
@@ -487,9 +489,19 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     // e4m3 operands: x scaled per token, W per feature (prepared), both tile-major like the int8 operands; no outlier tile (the
     // format's own dynamic range takes the massive-activation dims), the main pass over ALL features like the bf16 pass
     signed char *x8 = reinterpret_cast<signed char *>(xb);
-    hipLaunchKernelGGL(quant_x_fp8_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, x8, rowc, z * z, valid);
-    colc = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf);
-    colc_s = reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf_s);
+    unsigned *colmax = reinterpret_cast<unsigned *>(ws + pl.off_colmax);
+    int *odims = reinterpret_cast<int *>(ws + pl.off_odims);
+    unsigned char *is_out = ws + pl.off_isout;
+    f32x4 *cc_main = reinterpret_cast<f32x4 *>(ws + pl.off_colc), *cc_samp = reinterpret_cast<f32x4 *>(ws + pl.off_colc_s);
+    const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;
+    hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+                       colmax);
+    hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
+    hipLaunchKernelGGL(quant_x_fp8_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, (const unsigned char *)is_out, x8,
+                       rowc, z * z, valid);
+    hipLaunchKernelGGL(gather_wo_fp8_kernel, dim3(N / 32), dim3(256), 0, s, W_enc, N, d, (const int *)odims,
+                       reinterpret_cast<const f32x4 *>(prepared + pp.off_colbf), cc_main, cc_samp);
+    colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(x8); op_main.ldA = d;
     op_main.B = prepared + pp.off_wq; op_main.ldB = d;
     op_main.nk = d / 128;

@@ -7,6 +7,8 @@
 
 namespace {
 
+constexpr int MAX_OUT = 128;   // outlier dims of a batch (pick_outliers_kernel): they fit one int8 k-tile
+
 // W_bf16[n][c] = bf16(W[n][c]); sample row j = row j*SAMPLE_STRIDE + SAMPLE_OFF.  grid-stride over 8-element groups.
 __global__ __launch_bounds__(256) void prepare_weights_kernel(const float *__restrict__ W, int N,
                                                               int d, unsigned short *__restrict__ wb,
@@ -183,9 +185,17 @@ __global__ __launch_bounds__(256) void quant_w_fp8_kernel(const float *__restric
     if (samp) *reinterpret_cast<i32x4 *>(w8s + packed_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
   }
 }
-// x side, every call: one 256-thread workgroup per token row of the padded tile.  a32 holds x - b_dec.
-//   rowc[t] = (sx = max|a| / 224, M = |a|_2 / sx, P = z^2 FP8_REL_VAR2 |a|_4^2, flag)     (band: encode_defs.h)
-__global__ __launch_bounds__(256) void quant_x_fp8_kernel(const float *__restrict__ a32, int T, int d, signed char *__restrict__ x8,
+// x side, every call: one 256-thread workgroup per token row of the padded tile.  a32 holds x - b_dec; is_out / odims are the
+// batch's massive-activation dims (pick_outliers_kernel, as on the int8 path).  The band of a pair (encode_defs.h) is
+//   z^2 sigma^2 = z^2 v_rel [ |a_in|_4^2 |W_n|_4^2 + max_out(a^2) sum_out W_n[c]^2 ] + z^2 v_abs [ sx^2 |W_n|^2 + sw_n^2 |a|^2 ]
+// -- Cauchy-Schwarz on sum a_c^2 w_c^2 over the ordinary dims only: with the handful of x20 .. x1000 dims inside, |a|_4^2 is ~15x
+// the ordinary dims' and the band swallows hundreds of features (first build of this pass: 95 % of the tokens past r_max) --
+// in the three-term form  P_t Q_n + R_t (Si_n + M_t^2 So_n),  R_t = sx^2 z^2 v_abs:
+//   rowc[t] = (sx = max|a| / 224,  M = sqrt(v_rel / v_abs) max_out|a| / sx,  P = z^2 v_rel |a_in|_4^2,  flag)
+//   colc[n] = (sw8, Q = |W_n|_4^2 + (v_abs / v_rel) sqrt(d) sw8^2,  Si = |W_n|^2,  So = sum_out W_n[c]^2 + (v_abs / v_rel) n_out sw8^2)
+// (the W-side absolute term sw^2 |a|^2 <= sw^2 (sqrt(d) |a_in|_4^2 + n_out max_out a^2) rides in Q and So).
+__global__ __launch_bounds__(256) void quant_x_fp8_kernel(const float *__restrict__ a32, int T, int d,
+                                                         const unsigned char *__restrict__ is_out, signed char *__restrict__ x8,
                                                          f32x4 *__restrict__ rowc, float z2, const unsigned *__restrict__ valid) {
   __shared__ float red[3][4];
   const int t = blockIdx.x;
@@ -195,20 +205,25 @@ __global__ __launch_bounds__(256) void quant_x_fp8_kernel(const float *__restric
     return;
   }
   const float *row = a32 + (size_t)t * d;
-  float m = 0.f, s2 = 0.f, s4 = 0.f;
+  float m = 0.f, m_out = 0.f, s4 = 0.f;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(row + c);
+    const unsigned flags = *reinterpret_cast<const unsigned *>(is_out + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float q = v[e] * v[e]; m = fmaxf(m, fabsf(v[e])); s2 += q; s4 = __builtin_fmaf(q, q, s4); }
+    for (int e = 0; e < 4; ++e) {
+      const float av = fabsf(v[e]), q = av * av;
+      m = fmaxf(m, av);
+      if ((flags >> (8 * e)) & 0xFFu) m_out = fmaxf(m_out, av); else s4 = __builtin_fmaf(q, q, s4);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    m = fmaxf(m, __shfl_xor(m, off, 64)); s2 += __shfl_xor(s2, off, 64); s4 += __shfl_xor(s4, off, 64);
+    m = fmaxf(m, __shfl_xor(m, off, 64)); m_out = fmaxf(m_out, __shfl_xor(m_out, off, 64)); s4 += __shfl_xor(s4, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s4; }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = m_out; red[2][threadIdx.x >> 6] = s4; }
   __syncthreads();
   m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  m_out = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
   s4 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
   const float sx = m > 0.f ? m / FP8_MAX : 1.f, inv = 1.f / sx;
   for (int c = threadIdx.x * 16; c < d; c += 4096) {
@@ -218,7 +233,32 @@ __global__ __launch_bounds__(256) void quant_x_fp8_kernel(const float *__restric
     *reinterpret_cast<i32x4 *>(x8 + packed_off((size_t)t, c, d)) = packed;
   }
   if (threadIdx.x == 0)
-    rowc[t] = f32x4{sx, __builtin_sqrtf(s2) * inv, z2 * FP8_REL_VAR2 * __builtin_sqrtf(s4), (*valid & PREP_F8) ? 0.f : 1.f};
+    rowc[t] = f32x4{sx, __builtin_sqrtf(FP8_REL_VAR2 / FP8_ABS_VAR) * m_out * inv, z2 * FP8_REL_VAR2 * __builtin_sqrtf(s4),
+                    (*valid & PREP_F8) ? 0.f : 1.f};
+}
+// per-call column constants of the fp8 band (see quant_x_fp8_kernel): the f32 weights at the batch's outlier dims.
+// 8 threads per feature row, 32 rows per workgroup.
+__global__ __launch_bounds__(256) void gather_wo_fp8_kernel(const float *__restrict__ W, int N, int d, const int *__restrict__ odims,
+                                                           const f32x4 *__restrict__ colbf, f32x4 *__restrict__ colc,
+                                                           f32x4 *__restrict__ colc_s) {
+  __shared__ int s_dims[MAX_OUT];
+  if (threadIdx.x < MAX_OUT) s_dims[threadIdx.x] = odims[threadIdx.x];
+  __syncthreads();
+  const int n_out = odims[MAX_OUT];
+  const int n = blockIdx.x * 32 + (threadIdx.x >> 3);
+  float so = 0.f;
+  for (int j = threadIdx.x & 7; j < n_out; j += 8) {
+    const float w = W[(size_t)n * d + s_dims[j]];
+    so = __builtin_fmaf(w, w, so);
+  }
+  so += __shfl_xor(so, 1, 64); so += __shfl_xor(so, 2, 64); so += __shfl_xor(so, 4, 64);
+  if ((threadIdx.x & 7) == 0) {
+    const f32x4 st = colbf[n];               // (sw8, |W|_4^2, |W|^2, sw8^2)
+    const float ratio = FP8_ABS_VAR / FP8_REL_VAR2;
+    const f32x4 cc = {st[0], st[1] + ratio * __builtin_sqrtf((float)d) * st[3], st[2], so * 1.0001f + ratio * (float)n_out * st[3]};
+    colc[n] = cc;
+    if ((n % SAMPLE_STRIDE) == SAMPLE_OFF) colc_s[n / SAMPLE_STRIDE] = cc;
+  }
 }
 
 // pointers into a prepared buffer for the operand groups `modes` rebuilds (bit 1: int8 operands, bit 2: without the
@@ -274,7 +314,6 @@ __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict
   for (int e = 0; e < 4; ++e) atomicMax(cm + c + e, __float_as_uint(m[e]));  // values >= 0
 }
 
-constexpr int MAX_OUT = 128;   // outlier dims fit one int8 k-tile
 // single workgroup: dims whose column max exceeds 8x the mean column max (threshold raised until
 // at most MAX_OUT qualify).  odims[0..MAX_OUT) = dim or -1, is_out[d] byte flags.
 __global__ __launch_bounds__(1024) void pick_outliers_kernel(unsigned *__restrict__ colmax_bits, int d,
