@@ -96,8 +96,11 @@ def test_decode_bwd_acts_at_width_262144_vs_oracle(dev):
         ops.set_debug_bounds(False)
 
 
-def test_attribution_scores_at_width_262144(dev):
-    """config 5's scorer end to end on an SAE of width 262144: fused encode (k + 1 latents) -> decode ->
+@pytest.mark.parametrize("coarse", ["int8", "fp8"])
+def test_attribution_scores_at_width_262144(dev, coarse):
+    """(`coarse` = fp8: BASELINE configs[4] as worded -- "width=262144 SAE + attribution-patching grad x act feature scoring, fp8
+    MFMA encoder path" -- the scorer's encode on the e4m3 candidate pass; the latents are the exact path's bits either way.)
+    config 5's scorer end to end on an SAE of width 262144: fused encode (k + 1 latents) -> decode ->
     d(metric)/d(reconstruction) -> score[t, j] = act_j <g_t, W_dec[j]> - act_r <g_t, W_dec[r]> (the
     Attribution.batched_scores formula) against the direct definition: metric(clean) - metric(reconstruction
     with latent j zeroed, so that the (k+1)-th latent r enters) for a LINEAR metric, where the first-order score
@@ -105,6 +108,7 @@ def test_attribution_scores_at_width_262144(dev):
     from msae import Sae, SaeConfig, ops
 
     T, k = 512, 32
+    ops.set_coarse_mode(coarse)
     sae = Sae(D, SaeConfig(num_latents=N_C5, k=k), device=dev)
     with torch.no_grad():
         sae.encoder.weight.copy_(_unit_rows(N_C5, D, dev, seed=51))
@@ -114,8 +118,14 @@ def test_attribution_scores_at_width_262144(dev):
     x = torch.randn(T, D, generator=gx, device=dev).to(torch.bfloat16)
     probe = torch.randn(T, D, generator=gx, device=dev)              # metric(recon) = <probe, recon>, linear
     with torch.no_grad():
-        va, ia, st = ops.encode_topk(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec, sae._prepared_weights(),
-                                     k + 1)
+        try:
+            va, ia, st = ops.encode_topk(x, sae.encoder.weight, sae.encoder.bias, sae.b_dec, sae._prepared_weights(),
+                                         k + 1)
+        finally:
+            ops.set_coarse_mode("int8")
+        assert float((st == 0).float().mean()) > 0.9      # the candidate pass of the mode did the work
+        ve, ie = ops.topk(ops.pre_acts(x[:64], sae.encoder.weight, sae.encoder.bias, sae.b_dec), k + 1)
+        assert torch.equal(ia[:64], ie) and torch.equal(va[:64], ve)
         dots, _ = ops.decode_bwd(ia, va, sae.W_dec, probe, True, False)
         contrib = va * dots
         scores = (contrib[:, :k] - contrib[:, k:]) * (va[:, :k] > 0)
