@@ -456,7 +456,7 @@ def main():
             if name == "g13":
                 encode_decode_large_fixture(Sae, SaeConfig, "g13_d4096_n16384_t1024", 4096, 16384, [32, 256], 1024, 12, 13)
                 if args.full:
-                    encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 14, 15)
+                    encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 3, 15)
                 continue
             fn = globals()[name]
             fn(Sae, SaeConfig, cache_mod) if name in ("cache_fixture", "image_cache_fixture") else fn(Sae, SaeConfig)
@@ -475,7 +475,7 @@ def main():
     chunker_fixture()
     if args.full:
         encode_decode_fixture(Sae, SaeConfig, "g2_c2_d4096_n131072", 4096, 131072, [32, 256], 16, 3, 4)
-        encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 14, 15)
+        encode_decode_large_fixture(Sae, SaeConfig, "g13_c2_d4096_n131072_t320", 4096, 131072, [32, 256], 320, 3, 15)
 
 
 if __name__ == "__main__":
