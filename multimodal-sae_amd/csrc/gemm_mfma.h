@@ -204,6 +204,31 @@ __device__ __forceinline__ void gemm_stage_packed(const unsigned char *__restric
   }
 }
 
+// Tile-major operands, the wave's share as ONE block: with A_PIECES % PPW == 0 a wave's PPW pieces are PPW contiguous kilobytes of
+// ONE operand's 32-KB k-tile block and land in PPW contiguous kilobytes of the ring slot, and the instruction's immediate offset
+// is added to BOTH the global and the LDS address -- so four pieces share one SGPR base and one M0 (offsets 0 / 1 / 2 / 3 KiB).
+// Scalar work per wave and k-tile: ~12 SALU instead of ~90 (per piece: two 64-bit candidate bases, the A / B select, the LDS
+// address, M0).  `src` = the wave's first source byte, `dst` = its first LDS byte (both wave-uniform).
+template <class C>
+struct GemmWaveBlock {
+  static constexpr bool OK = C::A_PIECES % C::PPW == 0 && C::PPW % 4 == 0;
+};
+template <class C>
+__device__ __forceinline__ void gemm_stage_block(const unsigned char *__restrict__ src, unsigned char *dst_lds, int lane) {
+  const unsigned voff = (unsigned)lane << 4;
+#pragma unroll
+  for (int g = 0; g < C::PPW / 4; ++g) {
+    const unsigned char *sbase = src + g * 4096;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(dst_lds + g * 4096);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072"
+                 :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+  }
+}
+
 // this wave's even share (PPW pieces) of one k-tile
 template <class C>
 __device__ __forceinline__ void gemm_stage(const unsigned char *__restrict__ A,
@@ -722,17 +747,30 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     } else {
       int kq = tile - lead + krot;                         // (a select, no control flow: see gemm_stage_pieces)
       kq -= kq >= op.nk ? op.nk : 0;
+      // tile-major: the wave's share is one contiguous block of ONE operand (gemm_stage_block); only that operand's address is formed
+      [[maybe_unused]] const bool wa = wave * C::PPW < C::A_PIECES;                 // wave-uniform
+      [[maybe_unused]] const unsigned char *wop = wa ? op.A : op.B;
+      [[maybe_unused]] const size_t wrt = (size_t)(wa ? tm0 / C::BM : tn0 / C::BN);
+      [[maybe_unused]] const size_t wbytes = wa ? (size_t)C::A_BYTES : (size_t)C::B_BYTES;
+      [[maybe_unused]] const size_t win = (size_t)(wave * C::PPW - (wa ? 0 : C::A_PIECES)) * 1024;
+      [[maybe_unused]] unsigned char *wdst = smem + slot * C::STAGE_BYTES + wave * C::PPW * 1024;
       if constexpr (C::CERT) {                             // wave-uniform; scalar selects (see GemmOperands::cert)
         const int seg = kq >= 2 * op.cert ? 2 : (kq >= op.cert ? 1 : 0), kk = kq - seg * op.cert;
         const int ia = (seg == 0 ? 0 : op.cert) + kk, ib = (seg == 1 ? 0 : op.cert) + kk;
-        gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * (2 * op.cert) + ia) * C::A_BYTES,
-                             op.B + ((size_t)(tn0 / C::BN) * (2 * op.cert) + ib) * C::B_BYTES, smem, slot, wave, lane);
+        if constexpr (GemmWaveBlock<C>::OK)
+          gemm_stage_block<C>(wop + (wrt * (2 * op.cert) + (wa ? ia : ib)) * wbytes + win, wdst, lane);
+        else
+          gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * (2 * op.cert) + ia) * C::A_BYTES,
+                               op.B + ((size_t)(tn0 / C::BN) * (2 * op.cert) + ib) * C::B_BYTES, smem, slot, wave, lane);
         return;
       }
-      if (op.packed)                                       // wave-uniform
-        gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES,
-                             op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES, smem, slot, wave, lane);
-      else
+      if (op.packed) {                                     // wave-uniform
+        if constexpr (GemmWaveBlock<C>::OK)
+          gemm_stage_block<C>(wop + (wrt * op.nk + kq) * wbytes + win, wdst, lane);
+        else
+          gemm_stage_packed<C>(op.A + ((size_t)(tm0 / C::BM) * op.nk + kq) * C::A_BYTES,
+                               op.B + ((size_t)(tn0 / C::BN) * op.nk + kq) * C::B_BYTES, smem, slot, wave, lane);
+      } else
         gemm_stage<C>(op.A, op.B, op.ldA, tm0, tn0, (size_t)kq * C::ROWB, smem, slot, wave, sl_main);
     }
   };
