@@ -18,6 +18,7 @@ import collections
 import contextlib
 import ctypes
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -469,7 +470,10 @@ def prepare_encoder(W_enc: Tensor, out: Optional[Tensor] = None, active_mode_onl
 
 
 _TRAIN_PREPARED: dict = {}
-_TRAIN_FRESH: dict = {}      # key -> (weight version, coarse mode, covers batches of <= 256 tokens)
+# key -> (weight version, coarse mode, covers batches of <= 256 tokens, weak reference to the weight tensor).  The reference
+# pins the entry to ONE tensor object: the key is an address, and the caching allocator hands a freed parameter's address to
+# the next model of the same shape -- whose version counter can stand at the same value (the certified cache met exactly that).
+_TRAIN_FRESH: dict = {}
 
 
 def _train_key(W_enc: Tensor):
@@ -491,7 +495,7 @@ def train_operand_buffer(W_enc: Tensor) -> Tensor:
 
 def mark_train_operands_fresh(W_enc: Tensor, tokens_next: int) -> None:
     """The optimiser pass has just rebuilt train_operand_buffer(W_enc) from the updated weight (its version as of now)."""
-    _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, _defaults.coarse, tokens_next <= 256)
+    _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, _defaults.coarse, tokens_next <= 256, weakref.ref(W_enc))
 
 
 def invalidate_train_operands(W_enc: Optional[Tensor] = None) -> None:
@@ -513,14 +517,14 @@ def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
     version of the weight has already rebuilt it (adam_rows_(refresh=...): no second sweep over W_enc)."""
     key = _train_key(W_enc)
     fresh = _TRAIN_FRESH.get(key) if os.environ.get("MSAE_DEBUG_OPERANDS", "0") in ("", "0") else None
-    if fresh is not None and fresh == (W_enc._version, _defaults.coarse, fresh[2]) and (tokens > 256 or fresh[2]) \
-            and key in _TRAIN_PREPARED:
+    if fresh is not None and fresh[:2] == (W_enc._version, _defaults.coarse) and fresh[3]() is W_enc \
+            and (tokens > 256 or fresh[2]) and key in _TRAIN_PREPARED:
         return _TRAIN_PREPARED[key]
     buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True, tokens_next=tokens)
     if len(_TRAIN_PREPARED) > 8 and key not in _TRAIN_PREPARED:
         _TRAIN_PREPARED.clear(); _TRAIN_FRESH.clear()
     _TRAIN_PREPARED[key] = buf
-    _TRAIN_FRESH[key] = (W_enc._version, _defaults.coarse, tokens <= 256)
+    _TRAIN_FRESH[key] = (W_enc._version, _defaults.coarse, tokens <= 256, weakref.ref(W_enc))
     return buf
 
 
