@@ -41,6 +41,9 @@
  *   exact      every token through the f32 MFMA path (`exact`); ~20x.
  *   dither off / bf16 pass: the statistical contract of ABI <= 3 (z = 7 of the rounding-noise MODEL, < 3e-13 per token under
  *              it; the model is checked on every re-scored pair) -- kept for A/B runs and for callers pinned to ABI 3.
+ * Non-finite activations (+-inf / NaN, e.g. an overflowed bf16 residual stream): in every mode a token that holds one is
+ * recomputed by the exact path inside the call (status 1) -- its outputs are msae_pre_acts_f32 + msae_topk_f32's -- and the
+ * other tokens of the batch are unaffected (tests/test_gpu_hostile.py::test_non_finite_activations_stay_with_their_token).
  */
 #ifndef MSAE_H_
 #define MSAE_H_

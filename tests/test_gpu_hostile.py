@@ -434,3 +434,30 @@ def test_stale_operand_groups_fall_back_to_the_exact_path(dev):
     assert bool(((st & 0xFF) == 1).all()) and bool((((st >> 8) & 128) != 0).all())
     ops.prepare_encoder(W2, out=prepared)                          # a full prepare restores everything
     assert int(((run(64, 38) & 0xFF) == 0).sum()) >= 60 and int(((run(2048, 39) & 0xFF) == 0).sum()) > 0.95 * 2048
+
+
+@pytest.mark.parametrize("T", [4, 64, 200, 300, 2048])
+def test_non_finite_activations_stay_with_their_token(dev, coarse, T):
+    """+inf / -inf / NaN in a few tokens of a batch (an overflowed bf16 residual stream): every candidate-pass mode and every
+    batch-size class hands exactly those tokens to the in-call exact path -- their outputs are the exact kernels' -- and the
+    finite tokens of the same batch are bit-identical to the exact path (the batch-wide outlier-dim selection sees the
+    non-finite column maximum and must not let it touch anybody's result)."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W, b, bd = hostile.weights("trained_like", N, d, dev, seed=5)
+    prepared = ops.prepare_encoder(W)
+    x = hostile.activations(T, d, dev, seed=T).float()
+    for t, val in ((1, float("inf")), (2, float("-inf")), (3, float("nan"))):
+        x[t, 7 * t] = val
+    if T > 100:
+        x[T - 1, :] = float("nan")
+        x[T - 2, 5], x[T - 2, 6] = float("inf"), float("-inf")
+    for dt in (torch.float32, torch.bfloat16):
+        xx = x.to(dt)
+        v, i, st = ops.encode_topk(xx, W, b, bd, prepared, k, status_detail=True)
+        ev, ei = _exact(ops, xx, W, b, bd, k)
+        same = (v.view(torch.int32) == ev.view(torch.int32)).all(-1) & (i == ei).all(-1)   # (bit patterns: NaN == NaN)
+        assert bool(same.all()), (coarse, T, dt, (~same).nonzero().flatten().tolist()[:8])
+        bad = ~torch.isfinite(xx.float()).all(-1)
+        assert bool(((st & 0xFF)[bad] == 1).all()), (coarse, T, dt, (st & 0xFF)[bad].tolist())
