@@ -461,3 +461,33 @@ def test_non_finite_activations_stay_with_their_token(dev, coarse, T):
         assert bool(same.all()), (coarse, T, dt, (~same).nonzero().flatten().tolist()[:8])
         bad = ~torch.isfinite(xx.float()).all(-1)
         assert bool(((st & 0xFF)[bad] == 1).all()), (coarse, T, dt, (st & 0xFF)[bad].tolist())
+
+
+@pytest.mark.parametrize("T", [8, 64, 200, 300, 2048])
+def test_magnitude_extremes(dev, coarse, T):
+    """Zero tokens (x = b_dec, x = 0), tokens scaled by 1e30 / 1e-30 / 1e-42 (f32 denormals), entries at 3e38 (every square
+    overflows), one 1e20 entry beside ordinary dims: scales, norms and bands that overflow or vanish must end in the exact
+    path, never in a wrong verified token -- and must not disturb the ordinary tokens of the batch."""
+    from msae import ops
+
+    d, N, k = 1024, 16384, 32
+    W, b, bd = hostile.weights("trained_like", N, d, dev, seed=5)
+    prepared = ops.prepare_encoder(W)
+    x = hostile.activations(T, d, dev, seed=T).float()
+    x[0] = bd
+    x[1] = 0.0
+    x[2] *= 1e30
+    x[3] *= 1e-30
+    x[4] *= 1e-42
+    x[5] = torch.sign(x[5]) * 3e38
+    x[6, 11] = 1e20
+    x[7, 13] = -3e38
+    for dt in (torch.float32, torch.bfloat16):
+        xx = x.to(dt)
+        v, i, st = ops.encode_topk(xx, W, b, bd, prepared, k, status_detail=True)
+        ev, ei = _exact(ops, xx, W, b, bd, k)
+        same = (v.view(torch.int32) == ev.view(torch.int32)).all(-1) & (i == ei).all(-1)
+        assert bool(same.all()), (coarse, T, dt, (~same).nonzero().flatten().tolist()[:8])
+        assert int(((st & 0xFF) >= 2).sum()) == 0
+        if T > 8 and coarse != "fp8":       # (fp8: the 1e20 / 3e38 columns crowd the x20 dims out of the batch-wide outlier list)
+            assert float(((st & 0xFF)[8:] == 0).float().mean()) > 0.95
