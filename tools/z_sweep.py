@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Measured miss rate of the dithered candidate pass against its Hoeffding bound k exp(-z^2 / 2), for bands far narrower than
+the default z = 7: the fraction of tokens reported verified whose top-k differs from the exact path, per guard_z.
+
+    python tools/z_sweep.py [--tokens 524288] [--N 32768] [--d 1024] [--k 32] [--kind trained_like] [--out gpurun_out/z_sweep.json]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+for p in (REPO, REPO / "multimodal-sae_amd", REPO / "tests"):
+    sys.path.insert(0, str(p))
+
+import torch
+
+import hostile
+from msae import ops
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", type=int, default=1 << 19)
+    ap.add_argument("--kind", default="trained_like")
+    ap.add_argument("--N", type=int, default=32768)
+    ap.add_argument("--d", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--zs", default="1.5,2,2.5,3,4,5")
+    ap.add_argument("--dither", default="on")
+    ap.add_argument("--out", default=str(REPO / "gpurun_out" / "z_sweep.json"))
+    a = ap.parse_args(argv)
+    dev = torch.device("cuda:0")
+    ops.set_dither(a.dither)
+    ops.set_status_detail(True)
+    W, b, bd = hostile.weights(a.kind, a.N, a.d, dev, seed=41)
+    prepared = ops.prepare_encoder(W)
+    nb = a.tokens // a.batch
+    exact = []
+    for s in range(nb):                      # the exact answers once, the sweep re-uses them
+        x = hostile.activations(a.batch, a.d, dev, seed=20_000 + s)
+        pre = ops.pre_acts(x, W, b, bd)
+        ev, ei = ops.topk(pre, a.k)
+        del pre
+        exact.append((ev, ei))
+    rows = []
+    for z in [float(t) for t in a.zs.split(",")]:
+        ops.set_guard_z(z)
+        tot = dict(tokens=0, verified=0, verified_wrong=0, missing_members=0, wrong_after_fallback=0)
+        for s in range(nb):
+            x = hostile.activations(a.batch, a.d, dev, seed=20_000 + s)
+            v, i, st = ops.encode_topk(x, W, b, bd, prepared, a.k)
+            ev, ei = exact[s]
+            wrong = (i != ei).any(-1) | (v.view(torch.int32) != ev.view(torch.int32)).any(-1)
+            ver = (st & 0xFF) == 0
+            # members of the exact top-k (positive values) absent from the returned set
+            miss = ((ei.unsqueeze(-1) != i.unsqueeze(-2)).all(-1) & (ev > 0)).sum(-1)
+            tot["tokens"] += x.shape[0]
+            tot["verified"] += int(ver.sum())
+            tot["verified_wrong"] += int((wrong & ver).sum())
+            tot["missing_members"] += int(miss[ver].sum())
+            tot["wrong_after_fallback"] += int((wrong & ~ver).sum())
+        bound = min(1.0, a.k * math.exp(-z * z / 2))
+        rate = tot["verified_wrong"] / max(1, tot["verified"])
+        rows.append(dict(z=z, **tot, miss_rate_per_token=rate, hoeffding_bound_per_token=bound, within_bound=rate <= bound))
+        print(rows[-1], flush=True)
+    Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(a.out).write_text(json.dumps(dict(config=vars(a), rows=rows), indent=1))
+    assert all(r["wrong_after_fallback"] == 0 for r in rows)
+
+
+if __name__ == "__main__":
+    main()
