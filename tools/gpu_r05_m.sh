@@ -2,7 +2,4 @@
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/r05m
 mkdir -p $OUT
-timeout 600 python tools/z_sweep.py --out $OUT/z_sweep_n32768.json > $OUT/z_sweep.txt 2>&1; echo "exit $?"
-timeout 600 python tools/z_sweep.py --dither off --out $OUT/z_sweep_n32768_dither_off.json >> $OUT/z_sweep.txt 2>&1; echo "exit $?"
-timeout 900 python tools/z_sweep.py --N 131072 --d 4096 --tokens 131072 --out $OUT/z_sweep_c2.json >> $OUT/z_sweep.txt 2>&1; echo "exit $?"
-grep -v amdgpu.ids $OUT/z_sweep.txt | cut -c1-330
+(timeout 900 python tools/fuzz_fused.py 2500 21 int8,bf16,fp8,certified,int8_rn; MSAE_FM=1 timeout 600 python tools/fuzz_fused.py 1200 22 int8,certified,fp8; MSAE_FM=0 timeout 600 python tools/fuzz_fused.py 1200 23 int8,certified,fp8) 2>&1 | grep -i "cases\|MISMATCH\|Error\|Traceback" | cut -c1-400 > $OUT/fuzz_modes.txt; cat $OUT/fuzz_modes.txt

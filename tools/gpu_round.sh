@@ -42,7 +42,7 @@ timeout 400 bash tools/gpu_fm_ab.sh > $OUT/${R}_fm_rescore.txt 2>&1; cat $OUT/${
 KS=256 timeout 250 bash tools/gpu_fm.sh > /dev/null 2>&1; cp $OUT/fm/kernel_stats_k256.csv $OUT/${R}_k256_kernel_stats.csv 2>/dev/null
 [ -x tools/bin/fm_rescore_probe ] && timeout 200 tools/bin/fm_rescore_probe > $OUT/${R}_fm_rescore_probe.txt 2>&1 < /dev/null
 timeout 600 python tools/soak_fused.py --tokens 262144 --N 131072 --d 4096 --k 256 --out $OUT/${R}_soak_k256_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak k256 exit $?"
-(MSAE_FM=1 timeout 400 python tools/fuzz_fused.py 1500 11; MSAE_FM=0 timeout 400 python tools/fuzz_fused.py 1500 11; timeout 400 python tools/fuzz_fused.py 1500 12) 2>&1 | grep -i "cases" > $OUT/${R}_fuzz.txt; cat $OUT/${R}_fuzz.txt
+(MSAE_FM=1 timeout 400 python tools/fuzz_fused.py 1500 11; MSAE_FM=0 timeout 400 python tools/fuzz_fused.py 1500 11; timeout 400 python tools/fuzz_fused.py 1500 12; timeout 600 python tools/fuzz_fused.py 2500 21 int8,bf16,fp8,certified,int8_rn) 2>&1 | grep -i "cases" > $OUT/${R}_fuzz.txt; cat $OUT/${R}_fuzz.txt
 echo "== exact path kernel (pre_acts_f32) =="
 timeout 120 python tools/f32_probe.py 10 2>&1 | tail -1 | tee $OUT/${R}_f32_rate.txt
 echo "== shapes / latency / shard emulation / training =="
