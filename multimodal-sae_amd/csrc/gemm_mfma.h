@@ -315,13 +315,12 @@ __device__ __forceinline__ void gemm_read_frags(i32x4 (&a)[C::MI], i32x4 (&b)[C:
   a[2] = lds_read_b128<2 * 4096>(addrA); a[3] = lds_read_b128<3 * 4096>(addrA);
   b[0] = lds_read_b128<0 * 4096>(addrB); b[1] = lds_read_b128<1 * 4096>(addrB);
 }
-// `mid` runs behind the MFMAs of k-step AT (default: between k-steps 1 and 2, the reads of k-steps 2 and 3 in flight
-// across it): the waves that issue the next k-tile's LDS-DMA there instead of before their first MFMA (gemm_kernel:
-// stagger)
+// `mid(pos)` is called at every issue position of the k-tile: -1 behind the first fragment reads, 0 / 1 / 2 behind the MFMAs of
+// that k-step (the next reads in flight across it).  The waves that issue the next k-tile's LDS-DMA inside the compute phase
+// instead of before their first MFMA do it at position MSAE_GEMM_STAGGER_AT (gemm_kernel: stagger)
 template <class C, class F>
 __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], const unsigned char *sA,
                                                  int wr, int wc, int l31, int kh, F &&mid) {
-  constexpr int AT = MSAE_GEMM_STAGGER_AT;
   static_assert(C::KS == 4, "four k-steps per tile");
   const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)sA;
   const unsigned rowA = base + (unsigned)(wr * C::TM + l31) * 128u;
@@ -333,17 +332,18 @@ __device__ __forceinline__ void gemm_compute_asm(f32x16 (&acc)[C::MI][C::NI], co
   i32x4 a0[C::MI], b0[C::NI], a1[C::MI], b1[C::NI];
   gemm_read_frags<C>(a0, b0, rowA + off[0], rowB + off[0]);
   gemm_read_frags<C>(a1, b1, rowA + off[1], rowB + off[1]);
+  mid(-1);                         // (behind the first reads, in front of the first MFMA: measured worse than any other position)
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
   gemm_read_frags<C>(a0, b0, rowA + off[2], rowB + off[2]);
-  if constexpr (AT == 0) mid(0);
+  mid(0);
   lgkm_wait_tied<6, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
   gemm_read_frags<C>(a1, b1, rowA + off[3], rowB + off[3]);
-  if constexpr (AT == 1) mid(1);
+  mid(1);
   lgkm_wait_tied<6, C>(a0, b0);
   gemm_mfma_step<C>(acc, a0, b0);
-  if constexpr (AT == 2) mid(2);
+  mid(2);
   lgkm_wait_tied<0, C>(a1, b1);
   gemm_mfma_step<C>(acc, a1, b1);
 }
@@ -798,11 +798,12 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     };
     // (MSAE_GEMM_STAGGER, tuning.h: on by default since round 3 -- -4 % on the main pass together with tile-major operands, two
     // boxes: profiles/r03_ab_stagger_tile_major.txt, r03_ab_ring64_spilling_build.txt; 0 = off, 2 = odd waves)
-    // Waves w and w + 4 share a SIMD.  If both issue their eight LDS-DMA pieces right behind the barrier (~700
-    // cycles of issue each) the SIMD's MFMA pipe idles for that long in every k-tile; so the upper four waves
-    // start with MFMAs on the data already in LDS and issue their pieces between k-steps 1 and 2, while their
-    // partners -- done issuing -- keep the pipe busy.  ONE copy of the MFMA code: the two roles differ only in
-    // which of the two stage_next() call sites is taken.
+    // Waves w and w + 4 share a SIMD.  If both issue their LDS-DMA pieces right behind the barrier the SIMD's MFMA pipe idles
+    // for that long in every k-tile; so the upper four waves start with MFMAs on the data already in LDS and issue their pieces
+    // behind k-step MSAE_GEMM_STAGGER_AT, while their partners -- done issuing -- keep the pipe busy.  ONE copy of the MFMA
+    // code: the two roles differ only in which of the two stage_next() call sites is taken.  (Round 3, ~700 cycles of issue per
+    // wave: behind k-step 1.  Round 5, one block per wave = ~100 cycles: behind k-step 0 -- the pieces' time to land is what
+    // counts now; behind k-step 2 costs 9 %, everybody at the top 2 %: profiles/r05_ab_stagger_at.txt.)
     const bool late = MSAE_GEMM_STAGGER != 0 && (MSAE_GEMM_STAGGER == 2 ? (wave & 1) != 0 : wave >= C::NWAVES / 2) && !park_m && nM > 1;
     if constexpr (!C::ABL_NOSTAGE) {
       if (!late) stage_next();

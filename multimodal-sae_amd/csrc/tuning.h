@@ -11,8 +11,8 @@
 #ifndef MSAE_GEMM_STAGGER      // candidate GEMM: 1 = waves 4-7 issue their LDS-DMA pieces behind k-step MSAE_GEMM_STAGGER_AT
 #define MSAE_GEMM_STAGGER 1    // (-4 % on the main pass with tile-major operands: profiles/r03_ab_stagger_tile_major.txt); 0 = off, 2 = odd waves
 #endif
-#ifndef MSAE_GEMM_STAGGER_AT
-#define MSAE_GEMM_STAGGER_AT 1
+#ifndef MSAE_GEMM_STAGGER_AT   // 0 since the wave-block staging of round 5 (issue is ~100 cycles instead of ~700: the earlier the pieces leave,
+#define MSAE_GEMM_STAGGER_AT 0 // the better -- 3.93-3.97 ms against 4.04-4.07 behind k-step 1, two boxes: profiles/r05_ab_stagger_at.txt)
 #endif
 #ifndef MSAE_SK_UN             // weight-stream kernel: 64-B k-steps per B batch at 64 tokens (halved per doubling of the tile)
 #define MSAE_SK_UN 4
