@@ -244,7 +244,7 @@ __device__ __forceinline__ i32x4 gemm_frag(const unsigned char *tile, int row, i
 
 // tile id -> (tm, tn); see header.  Falls back to M-fastest order when the grid does not factor.
 __device__ __forceinline__ void gemm_map_tile(int b, int nM, int nN, int &tm, int &tn) {
-  constexpr int GM = 8, GN = 4;
+  constexpr int GM = MSAE_GEMM_GM, GN = MSAE_GEMM_GN;   // (tuning.h: 8 x 4)
   if (nM % GM == 0 && nN % GN == 0 && ((nM / GM) * (nN / GN)) % 8 == 0) {
     const int xcd = b & 7, slot = b >> 3;
     const int grp = slot / (GM * GN), w = slot % (GM * GN);

@@ -14,6 +14,10 @@
 #ifndef MSAE_GEMM_STAGGER_AT   // 0 since the wave-block staging of round 5 (issue is ~100 cycles instead of ~700: the earlier the pieces leave,
 #define MSAE_GEMM_STAGGER_AT 0 // the better -- 3.93-3.97 ms against 4.04-4.07 behind k-step 1, two boxes: profiles/r05_ab_stagger_at.txt)
 #endif
+#ifndef MSAE_GEMM_GM           // candidate GEMM: super-tile of output tiles an XCD's 32 workgroups work on together (gemm_map_tile): GM row tiles
+#define MSAE_GEMM_GM 8         // x GN column tiles, GM * GN = 32.  8 x 4 fetches 12 operand blocks per k-step for 32 tiles; 4 x 8 the same with the
+#define MSAE_GEMM_GN 4         // roles swapped, 16 x 2 / 2 x 16 fetch 18 (profiles/r05_ab_supertile.txt)
+#endif
 #ifndef MSAE_SK_UN             // weight-stream kernel: 64-B k-steps per B batch at 64 tokens (halved per doubling of the tile)
 #define MSAE_SK_UN 4
 #endif
