@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdlib>
+#include <chrono>
 #include <random>
 
 #include "common.h"
@@ -115,8 +116,14 @@ __host__ __device__ inline unsigned long long mix64(unsigned long long z) {
 // mutable process state of the library -- it is a random number generator.
 inline unsigned long long draw_seed() {
   static const unsigned long long base = [] {
-    std::random_device rd;
-    return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^ 0x6D736165ull;
+    unsigned long long b = 0x6D736165ull;
+    try {
+      std::random_device rd;
+      b ^= ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+    } catch (...) {   // no entropy source: clock and address-space layout (an exception must not cross the C ABI)
+      b ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ (unsigned long long)(size_t)&b;
+    }
+    return b;
   }();
   static std::atomic<unsigned long long> counter{0};
   const unsigned long long v = mix64(base + 0x9E3779B97F4A7C15ull * (counter.fetch_add(1, std::memory_order_relaxed) + 1ull));

@@ -47,6 +47,7 @@
 //
 // Outputs are therefore bit-identical to msae_pre_acts_f32 + msae_topk_f32 whenever the token
 // verifies, and ARE that path's outputs when it does not -- whichever operand type ran step 4.
+#include <new>
 #include <cstddef>
 #include <cstdlib>
 #include <type_traits>
@@ -763,8 +764,10 @@ extern "C" void msae_options_init(msae_options *opts) {
 
 extern "C" int msae_profile_create(int max_steps, void **handle) {
   if (max_steps <= 0 || max_steps > 4096 || !handle) return MSAE_EINVAL;
-  ProfState *pf = new ProfState();
-  pf->ev = new hipEvent_t[(size_t)max_steps * PROF_MARKS];
+  ProfState *pf = new (std::nothrow) ProfState();       // (no exception may cross the C ABI)
+  if (!pf) return (int)hipErrorOutOfMemory;
+  pf->ev = new (std::nothrow) hipEvent_t[(size_t)max_steps * PROF_MARKS];
+  if (!pf->ev) { delete pf; return (int)hipErrorOutOfMemory; }
   for (int i = 0; i < max_steps * PROF_MARKS; ++i) {
     const hipError_t e = hipEventCreate(&pf->ev[i]);
     if (e != hipSuccess) {
