@@ -1,18 +1,5 @@
 #!/bin/bash
-# final-tree counters: rocprof kernel stats, PMC passes (traffic stamped with the csrc hash), then the bench line that quotes them
 cd "$(dirname "$0")/.."
-OUT=gpurun_out
-R=r05
-export TMPDIR=/tmp
-rm -rf $OUT/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $R -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
-find $OUT/prof -name "*kernel_trace*" -size +2M -delete
-timeout 1500 bash tools/gpu_pmc.sh > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log | cut -c1-200
-python tools/pmc_traffic.py $OUT/pmc_summary.json $OUT/pmc_traffic.json $OUT/pmc/p4/p4_kernel_trace.csv > /dev/null 2>&1
-cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench.json 2> $OUT/bench.err; echo "bench exit $?"
-python - <<PY
-import json
-r=json.loads(open('gpurun_out/r05_bench.json').read().strip().splitlines()[-1])
-print(round(r['ms_per_step'],3), {a: round(b,3) for a,b in r['stage_ms'].items()}, r['roofline']['frac'], r['roofline']['counter_pass'].get('stale'))
-PY
+OUT=gpurun_out/r05m
+mkdir -p $OUT
+timeout 1200 python tools/fuzz_ops.py 600 2 > $OUT/fuzz_ops.txt 2>&1; echo "exit $?"; grep -v amdgpu.ids $OUT/fuzz_ops.txt | tail -25 | cut -c1-300
