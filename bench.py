@@ -376,8 +376,8 @@ def main(argv=None, rt=None):
     rt = rt or HipRuntime()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=8192, help="tokens per step (whole job)")
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--batches", type=int, default=4, help="distinct activation batches rotated through the timed loop")
