@@ -257,7 +257,9 @@ int msae_encode_topk_rows(const void *x, int x_dtype, const float *W_enc, const 
  *                            uint64 key[C] (order key of u << 32 | 0x7FFFFFFF - GLOBAL feature id, 0 = empty),
  *                            float z_sigma[C], float tau (largest u any OTHER feature of the shard can have; +inf when
  *                            the shard cannot bound it), float 0.  ws as for msae_encode_topk(T, d, N/G, k) with the
- *                            same options.
+ *                            same options.  MSAE_ENOTIMPL for shapes without the fused pass and for MSAE_COARSE_FP8 (its
+ *                            band reads the f32 weights of the batch's massive-activation dims, which a shard call does
+ *                            not receive): the caller runs msae_encode_topk per shard instead.
  *   (all-to-all / all-gather of the records: rank r needs the records of its tokens from every shard)
  *   msae_rescore_candidates  rank r, its T tokens (T_valid of them real): records[G][T] -> exact top-k against the
  *                            FULL W_enc / b_enc (replicated, 2 GiB of 288 GB), same verification rule as
