@@ -42,6 +42,10 @@
 //   pitch), both 7.3 ms.  Deeper rings (half-size k-tiles x 4 slots), a two-group ping-pong
 //   schedule, s_setprio, an L2 prefetch and issuing the DMA behind the first MFMA group were all
 //   measured equal or worse and are not kept.
+// Round 5 (profiles/r05_ab_stagger_at.txt, r05_ab_supertile.txt, r05_gemm96_prototype.txt): a wave's eight pieces are issued as ONE
+// block (gemm_stage_block: two SGPR bases, the rest immediate offsets that the instruction adds to the global AND the LDS address:
+// ~100 cycles instead of ~700), after which the staggered waves issue behind k-step 0 instead of 1 (-2 %); L2 warming, pre-staging
+// the next tile's second k-tile, other super-tile shapes and a 96-byte / 3-slot ring (tools/tuning/gemm_mfma96.h) all measured equal.
 //
 // Epilogues work on the UPPER value u = v + z*sigma(t, n) of every output, v = coarse pre-activation
 // (value + bias) and z*sigma the width of the error band of the operand type (encode_fused.hip):
