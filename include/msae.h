@@ -33,9 +33,14 @@
  * VERIFIES: all features whose coarse value plus the error band of the pair (token, feature) reaches the exact
  * k-th value were re-scored.  Tokens it cannot verify are reported in `status` and recomputed by the exact path
  * inside the same call.  WHAT THE BAND GUARANTEES depends on the mode (msae_options):
- *   default    int8 operands rounded STOCHASTICALLY with seeds drawn per call / per prepare (`dither`): for EVERY input a
+ *   default    int8 operands rounded STOCHASTICALLY with seeds drawn by the library (`dither`): for EVERY input a
  *              member of the true top-k is missed with probability <= k exp(-z^2 / 2) over the library's own randomness
- *              (Hoeffding; 7e-10 per token at z = 7, k = 32; guard_z = 8: 4e-13).  No assumption about the data.
+ *              (a Chernoff bound of a sum of independent bounded residuals; 7e-10 per token at z = 7, k = 32; guard_z = 8:
+ *              4e-13).  No assumption about the data.  The probability is over the seed of the PREPARE / refresh for the
+ *              weights' residuals and, for batches of more than 256 tokens, for the activations' as well (the subtractive
+ *              dither below: both operands are rounded against per-dim vectors fixed when the operands are prepared); smaller
+ *              batches round the activations with a seed drawn per call.  A long-running job that wants fresh randomness
+ *              re-prepares (msae_encoder_refresh: one sweep over W_enc).
  *   certified  two int8 planes per operand, three MFMA segments, a DETERMINISTIC Cauchy-Schwarz band: no probability
  *              left; ~2.5x the default's step time on large batches (`certified`).
  *   exact      every token through the f32 MFMA path (`exact`); ~20x.
@@ -125,6 +130,25 @@ enum {
  *                 Outputs of verified tokens do not depend on the seeds (they are the exact path's bits); which tokens fall
  *                 back may.  Costs ~sqrt(3) of band width: measured rows re-scored per token and step time in DESIGN.md
  *                 section 5.  Applies to the int8 pass (all batch sizes); the bf16 pass keeps its statistical model.
+ *                 The proxy includes the cross term of the two roundings: the weights' residuals multiply the DEQUANTISED
+ *                 activation, so |a_t| above reads |a_t| + sx_t sqrt(d) (ABI 4 builds before round 6 left it out).
+ *                 SUBTRACTIVE DITHER (round 6; batches of more than 256 tokens, i.e. the 256 x 256-tile MFMA pass).  The
+ *                 sqrt(3) is the price of a residual whose variance f (1 - f) depends on the input.  When the dither is
+ *                 subtracted again -- the operand element is taken as q - (r - 1/2) -- the residual is EXACTLY uniform on
+ *                 (-1/2, 1/2] step for every input, and a uniform variable is sub-Gaussian with its own variance 1/12 as proxy:
+ *                 the same bound k exp(-z^2 / 2) holds with sigma^2 = sw_n^2 (|a_t| + sx_t sqrt(d) / 2)^2 / 12 + sx_t^2 |W_n|^2 / 12,
+ *                 the round-to-nearest band, now a theorem.  Subtracting is affordable because the dither is SHARED: one
+ *                 vector r_x(c) for all tokens, one r_w(c) for all features (independence is needed across the dims of ONE
+ *                 pair only), both derived from the seed of the prepare / refresh.  The corrections are a per-feature constant
+ *                 D_n = sum_c (r_x(c) - 1/2) Wq[n][c] stored with the operands and a per-token integer E_t out of the
+ *                 activation quantiser; the MFMA pass applies both at no cost (E in the multiply-add that scales the outlier
+ *                 tile, D inside the epilogue's fma nesting).  Massive-activation dims keep an exact integer quotient in the
+ *                 outlier tile and their remainder in their own column, so they carry the same one-step residual as every
+ *                 other dim.  Measured: 45 rows re-scored per token instead of 58, re-score 0.88 -> 0.75 ms (DESIGN.md
+ *                 section 5); tests/test_gpu_band.py checks the coarse value, the band and the residuals' variance pair by
+ *                 pair against a numpy restatement.  A buffer prepared with dither OFF and encoded with dither ON has no
+ *                 D_n: such a call computes its tokens by the exact path (status 1) -- prepare and encode with the same mode.
+ *                 Environment MSAE_NO_SUBTRACT=1 keeps the non-subtractive band (A/B runs).
  *   certified     (ABI 4) != 0: msae_encode_topk[_i64] runs the CERTIFIED candidate pass: both operands as two int8 planes
  *                 (15 bits; x_lo.W_hi + x_hi.W_lo, a rounded shift by 7, then x_hi.W_hi in one int32 accumulator -- three
  *                 times the MFMA work of the default pass) and a DETERMINISTIC error band: Cauchy-Schwarz bounds of every
@@ -138,7 +162,8 @@ enum {
  *                 in-call exact path (time, never a wrong answer).  Shapes without the pass (d % 128, N % 8192) run the exact path.
  *   dither_seed   (ABI 4) 0: the library draws a seed per call (process-random base + atomic counter through a 64-bit
  *                 mixer -- the one piece of process state the library keeps); != 0: the seed of THIS call (reproducible
- *                 candidate sets: tests, A/B runs). */
+ *                 candidate sets: tests, A/B runs).  In a prepare / refresh it seeds the weights' rounding and the shared
+ *                 dither vectors of large batches; in an encode, the activations' rounding of batches of <= 256 tokens. */
 enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1, MSAE_COARSE_FP8 = 2 };
 enum { MSAE_DITHER_DEFAULT = 0, MSAE_DITHER_ON = 1, MSAE_DITHER_OFF = 2 };
 typedef struct msae_options {

@@ -40,6 +40,14 @@ struct Prepared {
   // candidate pass is about to read and, when one is missing, hands all its tokens to the exact path (reason 128) -- stale
   // operands cost time, never a wrong top-k, and nothing about them lives on the host.
   unsigned valid;
+  // Round 6, subtractive dither of the large-batch int8 pass (sd_* below): the seed the int8 operands of this buffer were rounded
+  // with (0: round to nearest) -- the activations of a batch are rounded against vectors derived from the SAME seed, so that the
+  // per-feature correction D_n can be computed where the row is quantised -- and off_ds: Ds[n] = sw_n * D_n, f32 [N].
+  unsigned long long dseed;
+  size_t off_ds;
+  // the two dither vectors as a table, h_x(c) << 16 | h_w(c) int32 [d] (sd_h16 of the two keys), and behind it F = sum_c g_w(c) g_x(c)
+  // (int64, 2^-34 units): written by sd_table_kernel in front of every kernel that quantises rows with the seed
+  size_t off_sdtab;
 };
 constexpr unsigned PREP_MAGIC = 0x4D534145u;  // "MSAE"
 constexpr unsigned PREP_BF16 = 1u;   // W_bf16 + bf16 sample rows
@@ -85,6 +93,8 @@ inline Prepared make_prepared(int N, int d) {
   p.off_wqsp = take(q ? (size_t)p.S * d : 0);
   p.off_wqf = take(q ? (size_t)N * d : 0);
   p.off_wqsf = take(q ? (size_t)p.S * d : 0);
+  p.off_ds = take(q ? (size_t)N * 4 : 0);
+  p.off_sdtab = take(q ? (size_t)d * 4 + 24 : 0);
   p.bytes = o;
   return p;
 }
@@ -224,6 +234,71 @@ __device__ __forceinline__ float dither01(unsigned key, unsigned c) {
   h ^= h >> 16;
   return ((float)(h >> 8) + 0.5f) * (1.f / 16777216.f);
 }
+// ---- subtractive dither (round 6) ------------------------------------------------------------------
+// Non-subtractive stochastic rounding q = floor(A + r) leaves a residual of variance f(1 - f) <= 1/4 step^2 that depends on the
+// input, so the every-input band had to use Hoeffding's worst case 1/4 where round to nearest has 1/12 (a sqrt(3) wider band:
+// 58 rows re-scored per token instead of 45).  With the dither SUBTRACTED again -- the operand element is taken as q - (r - 1/2)
+// -- the residual delta = q - (r - 1/2) - A is EXACTLY uniform on (-1/2, 1/2] whatever A is (Schuchman), independent across the
+// dims whose r are independent, and a uniform variable is sub-Gaussian with variance proxy equal to its variance:
+// E exp(l delta) = sinh(l/2) / (l/2) <= exp(l^2 / 24).  The Chernoff bound of the coarse value's error then holds with 1/12 per
+// rounding, for every input, over the library's randomness alone.  Subtracting costs a correction per output,
+//   sum_c (q_c - dx_c)(w^_c - dw_c) = sum q w^  -  D_n  -  E_t + F,   D_n = sum_c dx_c w^_nc,  E_t = sum_c q_tc dw_c,  F = sum dx dw,
+// which is affordable only when the dither is SHARED: dx_c the same for all tokens, dw_c the same for all features (the proof
+// needs independence across the dims c of ONE (token, feature) pair only).  D_n is then a per-feature constant computed where row
+// n is quantised (row_stats_quant_row), E_t - F a per-token integer out of quant_x_kernel, and the candidate GEMM applies both
+// for free: E in the multiply-add that scales the outlier tile (acc = acc * m - E), D inside the epilogue's fma nesting
+// ((acc * sw - sw D) * sx + b).  Both vectors derive from the seed of the prepare / refresh (Prepared::dseed).
+//   r(c) = (2 h(c) + 1) 2^-17 in (0, 1),  h = 16 hash bits;  d(c) = r(c) - 1/2 = g(c) 2^-17,  g = 2 h + 1 - 2^16  (exact integers:
+//   D and E are integer sums -- int32 per thread, int64 across threads -- with no rounding until the final conversion)
+__host__ __device__ inline unsigned sd_key(unsigned long long seed, unsigned side) {   // side 0: activations (dx), 1: weights (dw)
+  return (unsigned)mix64(seed ^ (0x5D17E5ull + 0x9E3779B97F4A7C15ull * (unsigned long long)(side + 1u)));
+}
+__host__ __device__ __forceinline__ int sd_h16(unsigned key, unsigned c) {
+  unsigned h = key ^ (c * 0x9E3779B9u);
+  h ^= h >> 16; h *= 0x7FEB352Du;
+  h ^= h >> 15; h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return (int)(h >> 16);
+}
+__host__ __device__ __forceinline__ float sd_r(int h16) { return (float)(2 * h16 + 1) * (1.f / 131072.f); }   // exact
+__host__ __device__ __forceinline__ int sd_g(int h16) { return 2 * h16 + 1 - (1 << 16); }
+constexpr double SD_UNIT = 1.0 / 131072.0;       // one unit of g
+// one table word per dim: h_x(c) << 16 | h_w(c)
+__host__ __device__ __forceinline__ int sd_hx(int word) { return (int)((unsigned)word >> 16); }
+__host__ __device__ __forceinline__ int sd_hw(int word) { return word & 0xFFFF; }
+// Slack on the variances of the subtractive band (times z^2 / 12):  1.001 for the float roundings of A = v / step;
+// (1 + 0.01 / z)^2 for the integer rounding of E_t - F (<= 1/2 accumulator unit against z sigma >= z sqrt(2 127^2 / 12) units:
+// the largest element of either operand quantises to +-127);  (1 + 2.6e-5 sqrt(d) / z)^2 for the float evaluation of the coarse
+// value itself (int32 -> f32 conversion and two roundings, <= 2e-7 |a . w|, against sigma >= |a| |w| / (127 sqrt(12 d)));
+// (1 + 2.7e-5 sqrt(d) / z)^2 for the 2^-16 grid of r (a uniform residual on a grid carries a mean of <= 2^-17 step per dim:
+// coherently at most sqrt(d) |w| 2^-17 = 2.64e-5 sqrt(d) sigma).
+inline float sd_slack(float z, int d) {
+  const float e = 1.f + (0.01f + 5.3e-5f * __builtin_sqrtf((float)d)) / z;
+  return 1.001f * e * e;
+}
+// (h_x, h_w) of every dim and F = sum_c g_w(c) g_x(c) (int64, 2^-34 units) into the prepared buffer (one workgroup; d is small)
+__global__ __launch_bounds__(1024) void sd_table_kernel(unsigned long long seed, int d, int *__restrict__ tab) {
+  __shared__ long long red[16];
+  const unsigned kx = sd_key(seed, 0u), kw = sd_key(seed, 1u);
+  long long f = 0;
+  for (int c = threadIdx.x; c < d; c += 1024) {
+    const int hx = sd_h16(kx, (unsigned)c), hw = sd_h16(kw, (unsigned)c);
+    tab[c] = (int)(((unsigned)hx << 16) | (unsigned)hw);
+    f += (long long)sd_g(hx) * sd_g(hw);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) f += __shfl_xor(f, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t = 0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *reinterpret_cast<long long *>(tab + ((d + 1) & ~1)) = t;
+  }
+}
+// Largest outlier multiplier whose remainder still fits the token's own column: A = m hi + lo, |lo| <= m / 2 + 1 <= 127.
+constexpr int SD_M_EXACT = 252;
+
 // ---- per-row statistics + int8 operands ---------------------------------------------------------------
 // Tile-major int8 operand of the candidate GEMM (GemmOperands::packed): byte offset of the 16-B chunk at column c
 // (c % 16 == 0) of row r, with the LDS image's chunk permutation applied (gemm_swz).  d % 128 == 0.

@@ -139,6 +139,7 @@ struct FusedPlan {
   size_t off_fmcount, off_fmtarget, off_fmkeys, off_fmpairs, off_fmpre, off_fmdefer;
   size_t off_xhi, off_xlo, off_skeys, off_sviol, off_surv, off_sbound, off_scand, off_stau;
   int Tp, S, r, cap, r_max, fb_cap, fb_chunks;
+  size_t off_rowe, off_cds, off_cds_s, off_cds_p;   // subtractive dither: (E, m) per token, Ds per column in the three column orders
   size_t off_xq, off_xqo, off_rowc, off_refs, off_colc, off_colc_s, off_colc_p, off_colmax, off_odims, off_isout, off_wqo, off_wqos;
   size_t off_xb, off_a32, off_sample, off_tauv, off_taui, off_cnt, off_cand, off_segcnt, off_segcand, off_flag, off_fbdense, off_dense, bytes;
   int segs;   // > 1: the candidate passes append to segmented lists (compact_candidates_kernel joins them)
@@ -187,6 +188,10 @@ inline FusedPlan make_plan(int T, int d, int N, int k, int mode, int shard_C = 0
       p.off_wqos = take((size_t)p.S * MAX_OUT);
     }
     p.off_rowc = take((size_t)p.Tp * 16);
+    p.off_rowe = take(p.i8 ? (size_t)p.Tp * 8 : 0);
+    p.off_cds = take(p.i8 ? (size_t)N * 4 : 0);
+    p.off_cds_s = take(p.i8 ? (size_t)p.S * 4 : 0);
+    p.off_cds_p = take(p.i8 ? (size_t)N * 4 : 0);
     p.off_refs = take(256);
     if (p.small) {
       p.off_xhi = take((size_t)T * d);
@@ -427,7 +432,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
 
   GemmOperands op_main{}, op_samp{};
   // (see run_small; fp8: the band's absolute-grid terms, encode_defs.h)
-  const float z = co.z, zz12 = z * z / 12.f, zzx = pl.f8 ? z * z * FP8_ABS_VAR : z * z * x_round_var(pl.i8 && co.seed != 0ull);
+  float z = co.z, zz12 = z * z / 12.f, zzx = pl.f8 ? z * z * FP8_ABS_VAR : z * z * x_round_var(pl.i8 && co.seed != 0ull);
+  bool sd = false;                 // subtractive dither (encode_defs.h): the large-batch int8 pass under msae_options::dither
   f32x4 *rowc = reinterpret_cast<f32x4 *>(ws + pl.off_rowc);
   const f32x4 *colc, *colc_s;      // error-band column constants of the main / sample pass
   f32x4 *cc_perm = nullptr;        // ... of the main pass in its own column order when it leaves the sample rows out
@@ -463,17 +469,32 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
-    if (shard)   // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
-      hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
-                         valid, need, co.seed);
+    // gemm_mfma.h's passes subtract the shared dither again: both roundings uniform with variance 1/12, for every input
+    sd = co.seed != 0ull && skinny == 0 && getenv("MSAE_NO_SUBTRACT") == nullptr;
+    int2 *rowe = reinterpret_cast<int2 *>(ws + pl.off_rowe);
+    const unsigned long long *dseed_p = reinterpret_cast<const unsigned long long *>(prepared + offsetof(Prepared, dseed));
+    const int *sdtab = reinterpret_cast<const int *>(prepared + pp.off_sdtab);
+    if (sd) { zz12 = z * z / 12.f * sd_slack(z, d); zzx = zz12; }
+    if (shard) {  // no re-score on this rank: quantise straight from x - b_dec, a32 is never written
+      if (sd)
+        hipLaunchKernelGGL((quant_x_kernel<DT, true, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12,
+                           tile_major, valid, need, co.seed, dseed_p, rowe, sdtab);
+      else
+        hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
+                           valid, need, co.seed, dseed_p, rowe);
+    } else if (sd)
+      hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false, true>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, co.seed, dseed_p, rowe, sdtab);
     else
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
-                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, co.seed);
+                         T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, co.seed, dseed_p, rowe);
     skip_sample = MAIN_SKIPS_SAMPLE && w_packed;   // the tile-major main operand holds the non-sample rows only
     cc_perm = reinterpret_cast<f32x4 *>(ws + pl.off_colc_p);
     hipLaunchKernelGGL(gather_wo_kernel, dim3(N / 32), dim3(256), 0, s, wq, N, d, odims,
                        reinterpret_cast<const f32x4 *>(prepared + pp.off_wstat), wqo, wqos, cc_main, cc_samp, cc_perm,
-                       skip_sample ? 1 : 0);
+                       skip_sample ? 1 : 0, sd ? reinterpret_cast<const float *>(prepared + pp.off_ds) : (const float *)nullptr,
+                       reinterpret_cast<float *>(ws + pl.off_cds), reinterpret_cast<float *>(ws + pl.off_cds_s),
+                       reinterpret_cast<float *>(ws + pl.off_cds_p));
     colc = cc_main; colc_s = cc_samp;
     op_main.A = reinterpret_cast<const unsigned char *>(xq); op_main.ldA = d;
     op_main.B = skinny ? prepared + pp.off_wqf : tile_major ? prepared + pp.off_wqp : reinterpret_cast<const unsigned char *>(wq);
@@ -528,6 +549,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.bias = b_enc; ep.bias_stride = SAMPLE_STRIDE; ep.bias_off = SAMPLE_OFF;
     ep.dense = sample; ep.ld_dense = pl.S;
     ep.rowc = rowc; ep.colc = colc_s; ep.refs = refs; ep.zz12 = zzx;
+    if (sd) { ep.row_e = reinterpret_cast<const int2 *>(ws + pl.off_rowe); ep.col_ds = reinterpret_cast<const float *>(ws + pl.off_cds_s); }
     const int grc = skinny == 64    ? gemm_skinny_launch<64, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 128 ? gemm_skinny_launch<128, true>(op_samp, T, d, pl.S, ep, s)
                     : skinny == 256 ? gemm_skinny_launch<256, true>(op_samp, T, d, pl.S, ep, s)
@@ -567,6 +589,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ep.skip_a = set_feature >= 0 ? set_feature : -1;
     ep.skip_b = zero_feature >= 0 ? zero_feature : -1;
     ep.rowc = rowc; ep.colc = skip_sample ? cc_perm : colc; ep.refs = refs; ep.zz12 = zzx;
+    if (sd) {
+      ep.row_e = reinterpret_cast<const int2 *>(ws + pl.off_rowe);
+      ep.col_ds = reinterpret_cast<const float *>(ws + (skip_sample ? pl.off_cds_p : pl.off_cds));
+    }
     if constexpr (msae_tuning::GEMM_TIMELINE != 0) {
       if (!g_timeline) (void)hipMalloc(&g_timeline, 64 * 8 * 8);
       (void)hipMemsetAsync(g_timeline, 0, 64 * 8 * 8, s);
@@ -605,7 +631,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     ra.cnt = cnt; ra.cand = cand; ra.cap = pl.cap;
     ra.T = T; ra.d = d; ra.N = N; ra.k = k; ra.r_max = pl.r_max;
     ra.rowc = rowc; ra.colc = colc; ra.zz12 = zzx; ra.z2 = z * z; ra.i8 = (pl.i8 || pl.f8) ? 1 : 0;   // (fp8: the three-term band as well)
-    ra.zc2 = guard_z_check2(pl.i8 && co.seed != 0ull);
+    // (subtractive dither: the band's sigma is the residuals' actual one again -- 6 sigma, as for round to nearest)
+    ra.zc2 = guard_z_check2(pl.i8 && co.seed != 0ull && !sd);
     ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
     ra.vals = vals; ra.idx = idx.i32; ra.idx64 = idx.i64; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
     ra.fb_cap = T;
@@ -821,6 +848,7 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, un
   Prepared p = make_prepared(N, d);
   // what this call rebuilds is valid, everything else is stale from now on (the weights have changed)
   p.valid = prep_valid_bits(modes, N, d);
+  p.dseed = ((modes & 2) && !(modes & 8) && i8_shape_ok(N, d)) ? seed : 0ull;   // the int8 operands' shared dither (encode_defs.h)
   MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
   if (p.S) {
     if (!msae_aligned(W_enc, 16)) return MSAE_EALIGN;
@@ -832,6 +860,8 @@ int prepare_impl(const float *W_enc, int N, int d, void *prepared, int modes, un
     const bool i8 = i8_shape_ok(N, d);
     RowQuantOut ro = row_quant_out(base, p, modes, i8);
     ro.seed = seed;
+    if (p.dseed != 0ull)
+      hipLaunchKernelGGL(sd_table_kernel, dim3(1), dim3(1024), 0, s, seed, d, reinterpret_cast<int *>(base + p.off_sdtab));
     if ((modes & 2) && i8 && !(modes & 8))   // row statistics (both passes' error bands) + int8 operands
       hipLaunchKernelGGL(row_stats_quant_kernel<true>, dim3(N), dim3(256), 0, s, W_enc, N, d, ro);
     else
@@ -1087,7 +1117,9 @@ int run_rescore_ext(const void *x, const float *W_enc, const float *b_enc, const
   ra.cap = xp.cap;
   ra.T = T_valid; ra.d = d; ra.N = N; ra.k = k; ra.r_max = xp.r_max;
   ra.zz12 = z * z / 12.f; ra.z2 = z * z; ra.i8 = 0;
-  ra.zc2 = guard_z_check2(co.mode == 1 && co.seed != 0ull);   // (the records' z sigma came from shards running with the same options)
+  // (the records' z sigma came from shards running with the same options; large batches subtract the dither there -- actual
+  // sigma --, small ones carry Hoeffding's proxy: 6 of either is the net under operands edited behind the API)
+  ra.zc2 = guard_z_check2(false);
   ra.set_feature = set_feature; ra.set_value = set_value; ra.zero_feature = zero_feature;
   ra.vals = vals; ra.idx = nullptr; ra.idx64 = idx; ra.status = status; ra.flagged = flagged; ra.n_flagged = n_flagged;
   ra.fb_cap = T;

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void prep_small_kernel(const void *__restrict_
   m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
   ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   const float scale = m > 0.f ? m / 16319.f : 1.f;
-  if (threadIdx.x == 0) rowc[t] = f32x4{scale, 1.f, zz12 * ss, 0.f};
+  // (dither: the weights' residuals multiply the DEQUANTISED activation, |A + delta| <= |A| + 1 step per dim -- the cross term of
+  // the two roundings inside the Hoeffding proxy: P = z^2 (|a| + s sqrt(d))^2 / 12, x 3 in Q_n)
+  const float an = __builtin_sqrtf(ss) + (dith ? scale * __builtin_sqrtf((float)d) : 0.f);
+  if (threadIdx.x == 0) rowc[t] = f32x4{scale, 1.f, zz12 * an * an, 0.f};
   const float inv = 1.f / scale;
   for (int c = threadIdx.x * 4; c < d; c += 1024) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(a32 + (size_t)t * d + c);

@@ -80,6 +80,12 @@ struct GemmEpilogue {
   const f32x4 *rowc, *colc;
   const float *refs;             // (Qr, Sir, Sor): the reference feature of the separable bound
   float zz12;                    // z^2 / 12
+  // Subtractive dither (round 6; encode_defs.h): row_e[t] = (E_t, m_t) -- the token's integer correction of the weights' shared
+  // dither and its outlier multiplier: acc = acc_outlier_tile * m - E in the multiply that scales the outlier tile anyway -- and
+  // col_ds[n] = sw_n D_n, the feature's correction of the activations' shared dither: v = (acc sw - Ds) sx + b, the same two
+  // packed instructions as (acc (sx sw) + b).  Both null: no correction (m from rowc[t][1]).  int8 only.
+  const int2 *row_e;
+  const float *col_ds;
   unsigned long long *timeline;  // tuning builds (tuning.h, MSAE_TL): s_memtime stamps of workgroup 0 / wave 0; null in the product
 };
 
@@ -135,9 +141,10 @@ struct GemmCfg {
   // Neither overlaps the ring: the next tile's first k-tile is already landing in it meanwhile.
   // side buffer, one float per thread and slot: tau|bias, sx|sw, m (int, parked early)|Q, P|Si, m|So, B|h
   // (row threads | column threads)
-  static constexpr int SIDE_SLOTS = 6;
+  // slot 6 (round 6): E (int) | Ds
+  static constexpr int SIDE_SLOTS = 7;
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
-  static constexpr int QCAP = 2304;
+  static constexpr int QCAP = 2296;              // (2304 before slot 6: the budget below is the CU's whole LDS)
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
   static_assert(STAGES == 2, "the flat cross-tile k-sequence below is written for a 2-slot ring");
   static_assert(BM + BN <= NT, "one thread per tile row and column fetches the epilogue constants");
@@ -503,12 +510,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
   const float *row_c = side, *col_c = side + C::BM;
   // column constants of this lane's NI columns stay in registers across the row loops
   float c_bias[C::NI], c_sw[C::NI], c_h[C::NI];
+  [[maybe_unused]] float c_ds[C::NI];                  // -sw_n D_n (subtractive dither; 0 otherwise)
   bool c_live[C::NI];
 #pragma unroll
   for (int j = 0; j < C::NI; ++j) {
     const int col = wc * C::TN + j * 32 + l31;         // column inside the tile
     c_bias[j] = col_c[col];
     c_sw[j] = col_c[C::NT + col];
+    if constexpr (C::I8 && !C::CERT) c_ds[j] = -col_c[6 * C::NT + col];
     c_h[j] = col_c[5 * C::NT + col];
     const int feat = gemm_feature(ep, n0 + col);
     c_live[j] = (feat != ep.skip_a) && (feat != ep.skip_b);
@@ -539,7 +548,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
           typedef float f32x2 __attribute__((ext_vector_type(2)));
           const f32x2 tau2 = {tau[e], tau[e + 1]}, rs2 = {rs[e], rs[e + 1]}, bt2 = {bt[e], bt[e + 1]};
           f32x2 v;
-          if constexpr (C::I8) {
+          if constexpr (C::I8 && !C::CERT) {
+            // v = (acc sw_n - sw_n D_n) sx_t + b_n: two packed fmas, as many instructions as acc (sx sw) + b
+            const f32x2 a = {(float)__builtin_bit_cast(i32x16, acc[i][j])[e], (float)__builtin_bit_cast(i32x16, acc[i][j])[e + 1]};
+            const f32x2 sw2 = {c_sw[j], c_sw[j]}, ds2 = {c_ds[j], c_ds[j]}, b2 = {c_bias[j], c_bias[j]};
+            v = __builtin_elementwise_fma(__builtin_elementwise_fma(a, sw2, ds2), rs2, b2);
+          } else if constexpr (C::I8) {
             const f32x2 a = {(float)__builtin_bit_cast(i32x16, acc[i][j])[e], (float)__builtin_bit_cast(i32x16, acc[i][j])[e + 1]};
             v = a * (rs2 * c_sw[j]) + c_bias[j];
           } else if constexpr (C::F8) {
@@ -617,7 +631,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[C::MI][C::NI], const
         for (int e = 0; e < 16; ++e) {
           const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, t = m0 + row;
           float v;
-          if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
+          if constexpr (C::I8 && !C::CERT)
+            v = __builtin_fmaf(__builtin_fmaf((float)__builtin_bit_cast(i32x16, acc[i][j])[e], c_sw[j], c_ds[j]), row_c[C::NT + row], c_bias[j]);
+          else if constexpr (C::I8) v = (float)__builtin_bit_cast(i32x16, acc[i][j])[e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
           else if constexpr (C::F8) v = acc[i][j][e] * (row_c[C::NT + row] * c_sw[j]) + c_bias[j];
           else v = acc[i][j][e] + c_bias[j];
           if (t < T) ep.dense[(size_t)t * ep.ld_dense + n0 + col] = v + __builtin_sqrtf(gemm_band_sq<C>(side, row, col, ep.zz12));
@@ -683,6 +699,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   //   threads [BM, BM+BN)  : bias and (sw, Q, Si, So) of column n0 + tid - BM
   float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
   int side2 = 1;
+  [[maybe_unused]] int side6 = 0;                // E_t (rows, int) | Ds_n (columns, float bits)
   float ref0 = 1.f, ref1 = 1.f, ref2 = 1.f;
   {
     if constexpr (!DENSE) { ref0 = ep.refs[0]; ref1 = ep.refs[1]; ref2 = ep.refs[2]; }   // consumed after the k-loop
@@ -700,6 +717,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
         side4 = 1.f;
         if (C::I8 && op.Ao != nullptr) { side2 = (int)rc[1]; side4 = rc[1]; }
         if constexpr (C::CERT || C::F8) side4 = rc[1];
+        if constexpr (C::I8 && !C::CERT) {
+          if (ep.row_e) { const int2 em = ep.row_e[t]; side6 = em.x; side2 = em.y; }
+        }
       }
     } else if (tid < C::BM + C::BN) {
       const int n = n0 + tid - C::BM;
@@ -710,9 +730,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
       side2 = __float_as_int(cc[1]);
       side3 = cc[2];
       side4 = cc[3];
+      if constexpr (C::I8 && !C::CERT) {
+        if (ep.col_ds) side6 = __float_as_int(ep.col_ds[n]);
+      }
     }
   }
   const bool has_out = C::I8 && op.Ao != nullptr;
+  [[maybe_unused]] const bool sub_e = C::I8 && !C::CERT && ep.row_e != nullptr;   // wave-uniform
   int lead_ks = 4;
   if (has_out && op.n_out != nullptr) lead_ks = (*op.n_out + 31) >> 5;    // wave-uniform scalar load
 
@@ -782,13 +806,15 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     stage(m0, n0, 0, 0);
   }
 
-  int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
+  // (m, -E) of the tile's rows, parked early as int2 [BM] in slot 2 (free until the constants are parked behind the k-loop)
+  int2 *side_me = reinterpret_cast<int2 *>(reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT);
+  static_assert(2 * C::BM <= C::NT, "the (m, -E) pairs fit one side slot");
   auto iteration = [&](int kt, bool park_m = false) {
     MSAE_TLK(kt == 8, 0);
     MSAE_TLK(kt == 9, 5);
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
     if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
-      if (tid_ < C::BM) side_m[tid_] = side2;
+      if (tid_ < C::BM) side_me[tid_] = int2{side2, -side6};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     MSAE_TLK(kt == 8, 1);
@@ -834,11 +860,13 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     for (int i = 0; i < C::MI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = side_m[wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+        const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int2 me = side_me[row];                           // (m, -E): one v_mad_i32_i24 per accumulator (E = 0 without the subtractive dither)
+        const int m = me.x, ee = me.y;
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) {
           i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);
-          v[e] = __mul24(v[e], m);
+          v[e] = __mul24(v[e], m) + ee;
           acc[i][j] = __builtin_bit_cast(f32x16, v);
         }
       }
@@ -848,7 +876,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     if (has_out) {   // peeled: the outlier dims were quantised at scale m[t]*sx[t]
       iteration(0, true);
       kt0 = 1;
-      if (lead_ks > 0) scale_by_m();   // no outlier dim in this batch: the accumulators are still zero
+      if (lead_ks > 0 || sub_e) scale_by_m();   // no outlier dim in this batch: the accumulators are still zero (sub_e: they become -E)
     }
   }
   if constexpr (C::CERT) {
@@ -877,6 +905,7 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
   reinterpret_cast<int *>(side)[2 * C::NT + tid_] = side2;
   side[3 * C::NT + tid_] = side3;
   side[4 * C::NT + tid_] = side4;
+  if constexpr (C::I8 && !C::CERT) reinterpret_cast<int *>(side)[6 * C::NT + tid_] = side6;
   if constexpr (!DENSE) {
     // slot 5 of the separable bound, computed only now: the loads it needs had the whole k-loop to land
     float side5 = 0.f;

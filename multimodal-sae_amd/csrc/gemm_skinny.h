@@ -34,7 +34,7 @@ struct SkinnyCfg {
   static constexpr int PITCH = ADMA ? KC : KC + 16;     // row pitch of the LDS image (16 B pad: rows spread over the banks)
   static constexpr int A_BUF = BM * PITCH;
   static constexpr int LDS_RING_BYTES = 2 * A_BUF;
-  static constexpr int SIDE_SLOTS = 6;
+  static constexpr int SIDE_SLOTS = 7;                  // (slot 6: gemm_mfma.h's subtractive-dither corrections; zero here -- this pass does not subtract)
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 128 * NW_;                // ~0.5 % of BM x BN outputs pass the hot loop's bound
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   reinterpret_cast<int *>(side)[2 * C::NT + tid] = side2;
   side[3 * C::NT + tid] = side3;
   side[4 * C::NT + tid] = side4;
+  side[6 * C::NT + tid] = 0.f;
   if constexpr (!DENSE) {
     float side5 = 0.f;
     if (tid < C::BM) {          // B_t: z sigma of this token against the reference feature

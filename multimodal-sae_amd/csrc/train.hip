@@ -405,10 +405,13 @@ extern "C" int msae_adam_rows_fused_f32(float *W, const float *G, float *M, floa
       const bool i8 = co.mode == 1 && i8_shape_ok(N, d);
       const int modes = (i8 ? 2 : 1) | (T_next > 256 ? 4 : 0);     // as msae_encoder_refresh[_for]
       p.valid = prep_valid_bits(modes, N, d);
+      p.dseed = i8 ? co.seed : 0ull;                                // (the shared dither of the int8 operands, encode_defs.h)
       MSAE_HIP_TRY(hipMemcpyAsync(prepared, &p, sizeof(p), hipMemcpyHostToDevice, s));
       unsigned char *base = static_cast<unsigned char *>(prepared);
       ft.rq = row_quant_out(base, p, modes, i8);
       ft.rq.seed = co.seed;                                        // msae_options::dither: this refresh's own seed
+      if (p.dseed != 0ull)
+        hipLaunchKernelGGL(sd_table_kernel, dim3(1), dim3(1024), 0, s, co.seed, d, reinterpret_cast<int *>(base + p.off_sdtab));
       ft.wb = reinterpret_cast<unsigned short *>(base + p.off_wb);
       ft.ws = reinterpret_cast<unsigned short *>(base + p.off_ws);
       refresh = i8 ? 1 : 2;
