@@ -27,6 +27,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import ops
+from . import utils as _seam
 from .config import SaeConfig
 
 
@@ -239,7 +240,13 @@ class Sae(nn.Module):
 
     def decode(self, top_acts: Tensor, top_indices: Tensor) -> Tensor:
         assert self.W_dec is not None, "Decoder weight was not initialized."
-        return ops.decode(top_indices, top_acts.to(self.dtype), self.W_dec, self.b_dec)
+        # the module-level seam, as the reference (sae.py:190): `decoder_impl(top_indices, top_acts, W_dec.mT) + b_dec`.  The
+        # default implementation is called with the bias inside the kernel (same bits: the kernel adds b_dec behind the
+        # chain; one pass over the [A, d] output instead of two); a rebound decoder_impl gets the reference's call.
+        impl = _seam.decoder_impl
+        if impl is _seam.hip_decode:
+            return ops.decode(top_indices, top_acts.to(self.dtype), self.W_dec, self.b_dec)
+        return impl(top_indices, top_acts.to(self.dtype), self.W_dec.mT) + self.b_dec
 
     def forward(self, x: Tensor, dead_mask: Union[Tensor, None] = None) -> ForwardOutput:
         """Training forward (sae.py:193-247): reconstruction, FVU, AuxK and Multi-TopK terms, fully

