@@ -324,7 +324,9 @@ class HipRuntime:
     def engine(self, *a, **kw):
         from msae.parallel import ShardedSae
 
-        return ShardedSae(*a, **kw)
+        eng = ShardedSae(*a, **kw)
+        eng.reuse_buffers = True      # a streaming loop: the gathered reconstruction is consumed before the ring wraps
+        return eng
 
     def stage_profile(self, steps):
         from msae import ops
@@ -453,7 +455,7 @@ def main(argv=None, rt=None):
             return [x0]
         return [x0] + [rt.make_inputs(dev, T, d, min(N, 8192), seed=seed0 + 7919 * j)[4] for j in range(1, args.batches)]
 
-    rows_buf = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
+    rows_buf = torch.zeros(max(T, 65536), dtype=torch.int32, device=dev)    # (the t65536 record's tokens fit as well)
     sampler_out = {}
 
     def timed(eng, xin, steps, warmup, profile, gather=True):
@@ -610,6 +612,18 @@ def main(argv=None, rt=None):
                                   "rank 0's launch (N_rank %d); sustained_peak = the guide's measured MFMA micro-benchmark "
                                   "ceiling; the kernel runs at the package power limit (profiles/r03_power.txt, r04_gemm4w_power.txt)" % (width, rows),
                            "traffic": traffic, "traffic_source": traffic_src, "launch_ms": float(mean[3])}
+        # The STEP's own roofline: max(T F_tok / P_mfma, (N d s_w + T (d s_x + B_dec)) / BW_hbm) over the
+        # measured step -- what the whole encode + TopK + decode could cost at the peaks of the operand type the pass computes in
+        s_w = 2 if cm == "bf16" else 1
+        f_tok = 2.0 * d * rows + 2.0 * k * d
+        b_dec_tok = k * d * 4 + k * 8 + d * 4
+        t_mfma = T * f_tok / (peak * 1e12)
+        t_hbm = (rows * d * s_w + T * (d * x.element_size() + b_dec_tok)) / (PEAK_HBM_GBS * 1e9)
+        step_ms = res.get("ms_per_step") or float("nan")
+        res["roofline"]["step_floor_ms"] = max(t_mfma, t_hbm) * 1e3
+        res["roofline"]["step_frac"] = max(t_mfma, t_hbm) * 1e3 / step_ms
+        res["roofline"]["step_note"] = ("BASELINE.md section 3: max(T F_tok / P_mfma, (N d s_w + T (d s_x + B_dec)) / BW_hbm) / ms_per_step; "
+                                        "F_tok = 2 d N + 2 k d, B_dec = k d 4 + k 8 + d 4, P_mfma = %g TOP/s, BW_hbm = %g GB/s" % (peak, PEAK_HBM_GBS))
         if pmc_extra:   # from the same committed counter passes: GRBM_GUI_ACTIVE / 8 / the kernel's duration THERE, MFMA-busy share
             res["roofline"]["counter_pass"] = pmc_extra
         res.update(stage_fields(stage, dec_ms, out, k))
@@ -699,7 +713,26 @@ def main(argv=None, rt=None):
                 rec.update(stage_fields(st, dm, o, k))
                 return rec
 
+            def run_tokens(Tn, what):
+                xs_n = [rt.make_inputs(dev, Tn, d, min(N, 8192), seed=101 + 7919 * j)[4] for j in range(len(xs))]
+                el, o, st, dm = timed(engine, xs_n, sec_steps, sec_warm, profile=True)
+                rec = {"tokens_per_step": Tn, "ms_per_step": el / sec_steps * 1e3, "value": Tn * sec_steps / el, "unit": "tokens/s",
+                       "note": what}
+                rec.update(stage_fields(st, dm, o, k))
+                return rec
+
+            def run_sustained():
+                n = 2000
+                el, o, _, _ = timed(engine, xs, n, 0, profile=False)
+                return {"steps": n, "ms_per_step": el / n * 1e3, "value": T * n / el, "unit": "tokens/s", "clock": dict(sampler_out),
+                        "note": "the headline loop for %d steps (~%d s): clock and package power at thermal / power-management "
+                                "equilibrium, sampled beside the loop" % (n, int(el + 0.5))}
+
             record("k256", run_k256)
+            record("t2880", lambda: run_tokens(2880, "one anyres LLaVA-NeXT image per call (~2880 tokens: the reference's --batch_size 1 "
+                                                     "cache run, README.md:46-56): per-call fixed cost counts here"))
+            record("t65536", lambda: run_tokens(65536, "eight bench batches per call"))
+            record("sustained", run_sustained)
             record("coarse_fp8", run_fp8)
             record("zipf", run_zipf)
             record("exact_modes", run_modes)

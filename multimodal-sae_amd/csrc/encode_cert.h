@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void cert_prepare_rows_kernel(const float *__r
 // a32 holds x - b_dec (prep_x_kernel).  rowc[t] = (sx = 128 sxf, M = |dx_t|, P = 3 A_t^2, flag)
 __global__ __launch_bounds__(256) void cert_quant_x_kernel(const float *__restrict__ a32, int T, int d,
                                                            signed char *__restrict__ xp, f32x4 *__restrict__ rowc,
-                                                           const unsigned *__restrict__ magic) {
+                                                           const unsigned *__restrict__ magic, int N) {
   __shared__ float red[4][4];
   const int t = blockIdx.x;
   if (t >= T) {
@@ -210,8 +210,10 @@ __global__ __launch_bounds__(256) void cert_quant_x_kernel(const float *__restri
     const float sd = __builtin_sqrtf((float)d);
     const float A = fmaxf(__builtin_sqrtf(a2), sxf * __builtin_sqrtf(q2)) * CERT_SLACK;
     const float M = (__builtin_sqrtf(e2) + 2e-3f * sd) * CERT_SLACK;
-    // a certified buffer that is not one (wrong pointer, never prepared): every token to the exact path
-    rowc[t] = f32x4{128.f * sxf, M, 3.f * A * A * CERT_SLACK, *magic == CERT_MAGIC ? 0.f : 1.f};
+    // a certified buffer that is not one (wrong pointer, never prepared) or that was built for ANOTHER shape (its header's
+    // N, d: the pass would read planes and constants out of bounds -- ADVICE r5): every token to the exact path
+    const bool mine = magic[0] == CERT_MAGIC && (int)magic[1] == N && (int)magic[2] == d;
+    rowc[t] = f32x4{128.f * sxf, M, 3.f * A * A * CERT_SLACK, mine ? 0.f : 1.f};
   }
 }
 

@@ -684,7 +684,7 @@ int run_cert(const void *x, const float *W_enc, const float *b_enc, const float 
                      (int *)nullptr, (size_t)0);
   hipLaunchKernelGGL(prep_x_kernel<DT>, dim3(2048), dim3(256), 0, s, x, b_dec, T, T, d, (unsigned short *)nullptr, a32);
   hipLaunchKernelGGL(cert_quant_x_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, xp, rowc,
-                     reinterpret_cast<const unsigned *>(cprep));
+                     reinterpret_cast<const unsigned *>(cprep), N);
   hipLaunchKernelGGL(band_refs_kernel, dim3(1), dim3(1024), 0, s, colc_s, pl.S, refs);
   GemmOperands op_main{}, op_samp{};
   op_main.A = reinterpret_cast<const unsigned char *>(xp); op_main.ldA = d; op_main.ldB = d;

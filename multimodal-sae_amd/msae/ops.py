@@ -50,6 +50,7 @@ def release_workspaces() -> None:
     """Drop every cached scratch buffer (they are re-created on demand)."""
     _WS.clear()
     _CERT_CACHE.clear()
+    _OPTS_CACHE.clear()
 
 
 # ---- per-call options of the fused encoder (struct msae_options) ------------------------------------------
@@ -159,14 +160,20 @@ def _opts(coarse_mode: int = -1, guard_z: float = 0.0, status_detail: bool = Fal
     dith = _DITHER_NAME[dither] if dither else _defaults.dither
     seed = dither_seed if dither_seed else _defaults.dither_seed
     prof, rows = _defaults.profile, _defaults.rows_rescored
+    if cert_ops is not None:
+        # a certified call brings its 2 N d-byte operand buffer: built per call and never cached -- a cache entry would pin the
+        # buffer of every weight version a training / evaluation loop has been through; the call is milliseconds
+        o = Options(coarse, z, detail, prof, exact, dith, seed)
+        o.certified, o.certified_operands = True, cert_ops
+        o.rows_rescored = rows
+        return _OptsRef(o)
     key = (coarse, z, detail, id(prof) if prof is not None else 0, exact, rows.data_ptr() if rows is not None else 0,
-           dith, seed, cert_ops.data_ptr() if cert_ops is not None else 0)
+           dith, seed)
     ref = _OPTS_CACHE.get(key)
-    if ref is None or ref.profile is not prof or ref.cert_ops is not cert_ops:
+    if ref is None or ref.profile is not prof:
         if len(_OPTS_CACHE) > 64:
             _OPTS_CACHE.clear()
         o = Options(coarse, z, detail, prof, exact, dith, seed)
-        o.certified, o.certified_operands = cert_ops is not None, cert_ops
         o.rows_rescored = rows
         ref = _OPTS_CACHE[key] = _OptsRef(o)
     return ref
@@ -418,7 +425,9 @@ def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optiona
     key = (dev, W_enc.data_ptr(), W_enc._version, tuple(W_enc.shape), 0 if b_enc is None else b_enc.data_ptr(),
            0 if b_enc is None else b_enc._version)
     hit = _CERT_CACHE.get(key)
-    if hit is not None:
+    # (the entry remembers WHICH tensor objects it was built from, weakly: the key is addresses and version counters, and the
+    # caching allocator hands a freed parameter's address to the next model of the same shape)
+    if hit is not None and hit[1]() is W_enc and (b_enc is None or hit[2]() is b_enc):
         _CERT_CACHE.move_to_end(key)
         return hit[0]
     W, b = _f32c(W_enc), _f32c(b_enc)
@@ -430,12 +439,31 @@ def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optiona
     with torch.cuda.device(dev):
         _hip.check(lib.msae_encoder_prepare_certified(_hip.ptr(W), _hip.ptr(b), N, d, _hip.ptr(buf), _hip.stream_of(W)),
                    "msae_encoder_prepare_certified")
-    # the entry HOLDS the tensors it was built from: while it lives their storage cannot be freed and handed to another
-    # weight matrix with the same (pointer, version) -- a key of pointers alone would then serve the old operands
-    _CERT_CACHE[key] = (buf, W_enc, b_enc)
+    _CERT_CACHE[key] = (buf, weakref.ref(W_enc), weakref.ref(b_enc) if b_enc is not None else None)
     while len(_CERT_CACHE) > 2:
         _CERT_CACHE.popitem(last=False)
     return buf
+
+
+def invalidate_certified(W_enc: Optional[Tensor] = None) -> None:
+    """Forget the certified operand buffers built from `W_enc` (all of them when None).  The cache trusts the tensors' version
+    counters, which an edit through `.data` does not bump: `Sae.invalidate_prepared` calls this, so the documented
+    remedy after such an edit covers `encode(certified=True)` as well -- a stale certified buffer would rank features by
+    the OLD weights and a token could verify with a wrong top-k."""
+    if W_enc is None:
+        _CERT_CACHE.clear()
+        return
+    for key in [k for k in _CERT_CACHE if k[1] == W_enc.data_ptr() or _CERT_CACHE[k][1]() is W_enc]:
+        _CERT_CACHE.pop(key, None)
+
+
+def coarse_in_force() -> str:
+    """The candidate pass's operand type an encode issued NOW would resolve to: the process default, else the environment's
+    MSAE_COARSE, else int8 (the library's rule, csrc/encode_defs.h resolve_opts)."""
+    if _defaults.coarse != "default":
+        return _defaults.coarse
+    e = os.environ.get("MSAE_COARSE", "")[:1]
+    return {"b": "bf16", "f": "fp8"}.get(e, "int8")
 
 
 def set_status_detail(on: bool) -> None:
@@ -495,7 +523,7 @@ def train_operand_buffer(W_enc: Tensor) -> Tensor:
 
 def mark_train_operands_fresh(W_enc: Tensor, tokens_next: int) -> None:
     """The optimiser pass has just rebuilt train_operand_buffer(W_enc) from the updated weight (its version as of now)."""
-    _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, _defaults.coarse, tokens_next <= 256, weakref.ref(W_enc))
+    _TRAIN_FRESH[_train_key(W_enc)] = (W_enc._version, coarse_in_force(), tokens_next <= 256, weakref.ref(W_enc))
 
 
 def invalidate_train_operands(W_enc: Optional[Tensor] = None) -> None:
@@ -517,14 +545,14 @@ def _refresh_train_operands(W_enc: Tensor, tokens: int) -> Tensor:
     version of the weight has already rebuilt it (adam_rows_(refresh=...): no second sweep over W_enc)."""
     key = _train_key(W_enc)
     fresh = _TRAIN_FRESH.get(key) if os.environ.get("MSAE_DEBUG_OPERANDS", "0") in ("", "0") else None
-    if fresh is not None and fresh[:2] == (W_enc._version, _defaults.coarse) and fresh[3]() is W_enc \
+    if fresh is not None and fresh[:2] == (W_enc._version, coarse_in_force()) and fresh[3]() is W_enc \
             and (tokens > 256 or fresh[2]) and key in _TRAIN_PREPARED:
         return _TRAIN_PREPARED[key]
     buf = prepare_encoder(W_enc, _TRAIN_PREPARED.get(key), active_mode_only=True, tokens_next=tokens)
     if len(_TRAIN_PREPARED) > 8 and key not in _TRAIN_PREPARED:
         _TRAIN_PREPARED.clear(); _TRAIN_FRESH.clear()
     _TRAIN_PREPARED[key] = buf
-    _TRAIN_FRESH[key] = (W_enc._version, _defaults.coarse, tokens <= 256, weakref.ref(W_enc))
+    _TRAIN_FRESH[key] = (W_enc._version, coarse_in_force(), tokens <= 256, weakref.ref(W_enc))
     return buf
 
 

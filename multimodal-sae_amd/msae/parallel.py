@@ -174,6 +174,7 @@ class ShardedSae:
         self.decode_event_i = 0
         self._pending = None
         self._recon_bufs: dict = {}
+        self.reuse_buffers = False    # decode(gather=True) returns a copy, not a view into the engine's ring (_gather_recon)
         self._second_round = None     # device-side count of second-round tokens (read by the property only)
         if k_loc is None:
             k_loc = default_k_loc(k, world) if self.collective else k
@@ -305,6 +306,23 @@ class ShardedSae:
         """ONE all-gather of the [T, kk] pairs of every rank, then the canonical merge."""
         return self._merge_gathered(self._gather(vals, idx), vals.shape[0], vals.shape[1])
 
+    def _certified_wanted(self) -> bool:
+        """ops.set_certified(True) asks for the deterministic guarantee.  The candidate exchange has no certified form (its
+        records carry the default pass's upper values): a call under that default takes the per-shard top-k scheme, whose local
+        encodes DO run certified -- instead of silently handing out the probabilistic pass.  The process default is
+        the same on every rank of a job that sets it before the loop, so every rank takes the same turn."""
+        from . import ops
+
+        if not getattr(ops._defaults, "certified", False):
+            return False
+        if not getattr(self, "_certified_noted", False):
+            self._certified_noted = True
+            import warnings
+
+            warnings.warn("ShardedSae(mode='candidates'): ops.set_certified(True) is in force -- the candidate exchange has no "
+                          "certified form, these encodes run the per-shard top-k scheme with certified local passes", stacklevel=3)
+        return True
+
     def _encode_candidates(self, x: Tensor, **ed):
         """-> (join, (own vals, own idx), keep-alive), or None when the shape has no candidate pass (the engine then
         switches to mode="topk" for good: every rank sees the same shapes, so every rank takes the same turn)."""
@@ -352,7 +370,7 @@ class ShardedSae:
         if not self.collective:
             return self._encode(x, self.k, **ed)
         x = self._same_input(x)
-        if self.mode == "candidates":
+        if self.mode == "candidates" and not self._certified_wanted():
             got = self._encode_candidates(x, **ed)
             if got is not None:
                 return got[0]()
@@ -486,7 +504,11 @@ class ShardedSae:
         work = dist.all_gather_into_tensor(full, pad, group=self.group, async_op=async_gather)
         if async_gather:
             self._pending = (work, pad, full)        # keep the buffers alive until joined
-        return full[:T]
+            return full[:T]                          # (valid behind synchronize(), until the second following call)
+        # The ring belongs to the engine: a caller that KEEPS a reconstruction (a cache of hidden states, output_hidden_states)
+        # must not see it overwritten two calls later (the hooks' .to(fp16) copies anyway, an f32 splice did not).
+        # Streaming loops that consume it at once opt in to the view with reuse_buffers (bench.py does).
+        return full[:T] if self.reuse_buffers else full[:T].clone()
 
     def synchronize(self):
         """Join an outstanding asynchronous reconstruction gather (stream-ordered wait)."""

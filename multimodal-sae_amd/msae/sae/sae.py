@@ -181,12 +181,13 @@ class Sae(nn.Module):
         self._prepared_key = None
         if self.encoder.weight.is_cuda:
             ops.invalidate_train_operands(self.encoder.weight)     # the training loop's per-parameter buffer as well
+            ops.invalidate_certified(self.encoder.weight)          # ... and the certified pass's two-plane operands
 
     def _prepared_weights(self) -> Optional[Tensor]:
         w = self.encoder.weight
         # (+ whether the fp8 pass is in force: its operands replace the int8 ones in the buffer)
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device,
-               ops._defaults.coarse == "fp8" or (ops._defaults.coarse == "default" and os.environ.get("MSAE_COARSE", "")[:1] == "f"))
+               ops.coarse_in_force() == "fp8")
         if self._prepared is None or self._prepared_key != key:
             self._prepared = ops.prepare_encoder(w)
             self._prepared_key = key

@@ -179,7 +179,7 @@ class SaeTrainStep:
             is_enc = p is sae.encoder.weight
             if fuse and is_dec and sae.cfg.normalize_decoder:
                 kw["renorm_eps"] = torch.finfo(p.dtype).eps          # sae.py:252
-            if fuse and is_enc and self._chunk_tokens > 0 and ops._defaults.coarse != "fp8":   # (the fused pass builds int8 / bf16 operands)
+            if fuse and is_enc and self._chunk_tokens > 0 and ops.coarse_in_force() != "fp8":   # (the fused pass builds int8 / bf16 operands; MSAE_COARSE=fp8 in the environment counts: ADVICE r5)
                 kw["refresh"], kw["tokens_next"] = ops.train_operand_buffer(p), self._chunk_tokens
             ops.adam_rows_(p.data, p.grad, m, v, self.t, lr, total_sumsq=self._sumsq,
                            max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps,

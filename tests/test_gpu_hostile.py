@@ -498,3 +498,43 @@ def test_magnitude_extremes(dev, coarse, T):
         assert int(((st & 0xFF) >= 2).sum()) == 0
         if T > 8 and coarse != "fp8":       # (fp8: the 1e20 / 3e38 columns crowd the x20 dims out of the batch-wide outlier list)
             assert float(((st & 0xFF)[8:] == 0).float().mean()) > 0.95
+
+
+def test_invalidate_prepared_covers_the_certified_operands_and_nothing_pins_old_buffers(dev):
+    """ADVICE r5.  (1) An edit of the weights through `.data` does not bump the tensor's version; `Sae.invalidate_prepared()` is
+    the documented remedy and must drop the CERTIFIED pass's cached two-plane operands too -- a stale certified buffer ranks
+    the features by the old weights, a member of the new top-k is never re-scored and the token verifies with a wrong answer
+    (the one mode whose contract has no probability in it).  (2) The options cache must not hold certified operand buffers
+    (1 GiB each at C2) of weight versions long gone; release_workspaces() clears what is cached."""
+    from msae import Sae, SaeConfig, ops
+
+    d, N, T, k = 512, 8192, 300, 16
+    W, b, bd = hostile.weights("gauss", N, d, dev, seed=61)
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev).eval()
+    with torch.no_grad():
+        sae.encoder.weight.copy_(W); sae.encoder.bias.copy_(b); sae.b_dec.copy_(bd)
+    sae.invalidate_prepared()
+    x = hostile.activations(T, d, dev, seed=62, kind="gauss")
+    out0 = sae.encode(x, certified=True)
+    ev0, ei0 = _exact(ops, x, sae.encoder.weight, sae.encoder.bias, sae.b_dec, k)
+    assert torch.equal(out0.top_indices, ei0) and torch.equal(out0.top_acts, ev0)
+    # a different encoder behind the same pointer and version counter
+    v_before = sae.encoder.weight._version
+    W2, _, _ = hostile.weights("gauss", N, d, dev, seed=63)
+    sae.encoder.weight.data.copy_(W2)
+    assert sae.encoder.weight._version == v_before, "the construction needs an edit the version counter does not see"
+    sae.invalidate_prepared()
+    out1, st1 = sae.encode(x, certified=True, return_status=True)
+    ev1, ei1 = _exact(ops, x, sae.encoder.weight, sae.encoder.bias, sae.b_dec, k)
+    assert not torch.equal(ei1, ei0)
+    assert torch.equal(out1.top_indices, ei1) and torch.equal(out1.top_acts, ev1)
+    assert float((st1 == 0).float().mean()) > 0.9, "through the certified fast path (fresh operands), not the exact fallback"
+    # nothing cached refers to a certified operand buffer
+    for step in range(4):
+        with torch.no_grad():
+            sae.encoder.weight.mul_(1.0 + 1e-3 * (step + 1))      # bumps the version: a new certified buffer per step
+        sae.encode(x, certified=True)
+    assert all(getattr(v, "cert_ops", None) is None for v in ops._OPTS_CACHE.values())
+    assert len(ops._CERT_CACHE) <= 2
+    ops.release_workspaces()
+    assert len(ops._CERT_CACHE) == 0 and len(ops._OPTS_CACHE) == 0
