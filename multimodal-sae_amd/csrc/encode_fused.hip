@@ -462,10 +462,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const bool w_packed = tile_major == 1 || skinny != 0;   // the W side of the candidate passes reads the tile-major copies
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
-      hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
                          (float *)nullptr, colmax);
     else
-      hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
@@ -482,7 +482,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
       else
         hipLaunchKernelGGL((quant_x_kernel<DT, true>), dim3(pl.Tp), dim3(256), 0, s, x, b_dec, T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major,
                            valid, need, co.seed, dseed_p, rowe);
-    } else if (sd)
+    } else if (sd)   // (from a32: reading the caller's 16-bit x + b_dec instead measured +0.016 ms -- the kernel is bound by its instructions, not its bytes)
       hipLaunchKernelGGL((quant_x_kernel<MSAE_F32, false, true>), dim3(pl.Tp), dim3(256), 0, s, (const void *)a32, (const float *)nullptr,
                          T, d, odims, is_out, xq, xqo, rowc, zz12, tile_major, valid, need, co.seed, dseed_p, rowe, sdtab);
     else
@@ -507,6 +507,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     op_samp = op_main;
     op_samp.B = skinny ? prepared + pp.off_wqsf : tile_major ? prepared + pp.off_wqsp : reinterpret_cast<const unsigned char *>(wqs);
     op_samp.Bo = reinterpret_cast<const unsigned char *>(wqos);
+    if constexpr (msae_tuning::ABL_NOLEAD) { op_main.Ao = nullptr; op_main.Bo = nullptr; }   // (tuning builds; results invalid)
   } else if (pl.f8) {
     // e4m3 operands: x scaled per token, W per feature (prepared), both tile-major like the int8 operands; no outlier tile (the
     // format's own dynamic range takes the massive-activation dims), the main pass over ALL features like the bf16 pass
@@ -516,7 +517,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     unsigned char *is_out = ws + pl.off_isout;
     f32x4 *cc_main = reinterpret_cast<f32x4 *>(ws + pl.off_colc), *cc_samp = reinterpret_cast<f32x4 *>(ws + pl.off_colc_s);
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;
-    hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+    hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
                        colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     hipLaunchKernelGGL(quant_x_fp8_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, (const unsigned char *)is_out, x8,

@@ -79,6 +79,11 @@ constexpr bool ABL_NOFLUSH = true;      // ... drop the LDS queue instead of flu
 #else
 constexpr bool ABL_NOFLUSH = false;
 #endif
+#ifdef MSAE_ABL_NOLEAD
+constexpr bool ABL_NOLEAD = true;       // ... no outlier k-tile and no acc * m - E pass in the MAIN pass (the round-5 verdict's A/B: what the tile costs)
+#else
+constexpr bool ABL_NOLEAD = false;
+#endif
 #ifdef MSAE_ABL_NOFALLBACK
 constexpr bool ABL_NOFALLBACK = true;   // fused encode: no exact fallback launches
 #else

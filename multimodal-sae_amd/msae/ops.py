@@ -46,8 +46,18 @@ def _workspace(dev: torch.device, nbytes: int) -> Tensor:
     return ws
 
 
+_WS_EPOCH = [0]
+
+
+def workspace_epoch() -> int:
+    """Bumped whenever cached scratch buffers are dropped: anything that captured their addresses (a HIP graph of the hooks'
+    S = 1 step) re-captures."""
+    return _WS_EPOCH[0]
+
+
 def release_workspaces() -> None:
     """Drop every cached scratch buffer (they are re-created on demand)."""
+    _WS_EPOCH[0] += 1
     _WS.clear()
     _CERT_CACHE.clear()
     _OPTS_CACHE.clear()
@@ -414,6 +424,7 @@ def set_certified(on: bool) -> None:
 
 
 _CERT_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_CERT_NOTED: set = set()          # shapes whose "no certified pass -> exact path" warning has been given
 
 
 def prepare_encoder_certified(W_enc: Tensor, b_enc: Optional[Tensor]) -> Optional[Tensor]:
@@ -585,6 +596,13 @@ def encode_topk(x: Tensor, W_enc: Tensor, b_enc: Optional[Tensor], b_dec: Option
         cert_ops = prepare_encoder_certified(W_enc, b_enc)
         if cert_ops is None:
             exact = True                 # a shape without the certified pass: the exact path is the certified answer
+            if (N, d) not in _CERT_NOTED:                           # ... and ~20x the time on large batches: say so, once per shape
+                _CERT_NOTED.add((N, d))
+                import warnings
+
+                warnings.warn(f"certified encode: no certified pass for num_latents = {N}, d_in = {d} (it needs num_latents % 8192 "
+                              "== 0 and d_in % 128 == 0, d_in <= 65536); these encodes run the exact f32 path -- the same "
+                              "answer, ~20x slower on large batches (include/msae.h, msae_options::certified)", stacklevel=3)
     opts = _opts(coarse_mode, guard_z, status_detail, exact, dither, dither_seed, cert_ops)
     rows = _defaults.rows_rescored
     if rows is not None and (T > rows.numel() or rows.device != dev):

@@ -472,3 +472,36 @@ def test_sae_decode_goes_through_the_module_level_decoder_impl(dev):
     torch.testing.assert_close(y_eager, y_sparse, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(acts.grad, ga_s, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(sae.W_dec.grad, gW_s, rtol=1e-4, atol=1e-5)
+
+
+def test_steering_hook_replays_its_decode_step_from_a_hip_graph(dev):
+    """Round-5 verdict, item 9: the S = 1 step of the steering hook (features/steering.py:105-124) is captured once and
+    replayed -- bit-identical to the eager hook for every new hidden state, re-captured when the weights change."""
+    from msae import Sae, SaeConfig
+    from msae.features import hooks
+
+    d, N, k = 1024, 16384, 32
+    sae = Sae(d, SaeConfig(num_latents=N, k=k), device=dev).eval()
+    g = torch.Generator(device=dev).manual_seed(9)
+    with torch.no_grad():
+        sae.b_dec.copy_(torch.randn(d, generator=g, device=dev) * 0.1)
+        sae.encoder.bias.copy_(torch.randn(N, generator=g, device=dev) * 0.02)
+    layer_g, layer_e = torch.nn.Identity(), torch.nn.Identity()
+    hg = hooks.clamp_features_max(sae, 123, layer_g, k=10, graph_step=True)
+    he = hooks.clamp_features_max(sae, 123, layer_e, k=10, graph_step=False)
+    try:
+        with torch.no_grad():
+            for step in range(6):
+                h = torch.randn(1, 1, d, generator=g, device=dev).to(torch.float16)
+                a, b = layer_g(h), layer_e(h)
+                assert a.dtype == torch.float16 and a.shape == h.shape and torch.equal(a, b), step
+                if step == 2:                                  # new weights: the graph must not replay the old operands
+                    sae.encoder.weight.mul_(1.01)
+            hp = torch.randn(1, 7, d, generator=g, device=dev).to(torch.float16)       # prefill: the eager path, with the clamp
+            assert torch.equal(layer_g(hp), layer_e(hp))
+        # the graph really was used (and re-captured once)
+        sg = hg[0].step_graph
+        assert sg is not None and sg.graph is not None and not sg.failed and he[0].step_graph is None
+    finally:
+        for hdl in hg + he:
+            hdl.remove()

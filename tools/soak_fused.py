@@ -40,6 +40,9 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--coarse", default="int8")
     ap.add_argument("--z", type=float, default=7.0)
+    ap.add_argument("--reprepare", type=int, default=16,
+                    help="re-prepare the encoder operands every this many batches (a fresh seed for the weights' rounding and, "
+                         "round 6, for the shared dither vectors of large batches); 0 = once")
     ap.add_argument("--out", default=str(REPO / "gpurun_out" / "soak.json"))
     ap.add_argument("--sae_path", default=None, help="real checkpoint dir (cfg.json + sae.safetensors) instead of --kind")
     ap.add_argument("--acts", default=None, help="safetensors file with [T, d] activations instead of synthetic ones")
@@ -79,6 +82,8 @@ def main(argv=None):
             x = x if x.dtype in (torch.bfloat16, torch.float16, torch.float32) else x.float()
         else:
             x = hostile.activations(a.batch, a.d, dev, seed=10_000 + s)
+        if a.reprepare and s and s % a.reprepare == 0 and a.coarse != "certified":
+            prepared = ops.prepare_encoder(W, out=prepared)       # new seeds: the guarantee's randomness is sampled, not fixed
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         v, i, status = ops.encode_topk(x, W, b, bd, prepared, a.k)

@@ -53,6 +53,8 @@ def main(argv=None):
         tot = dict(tokens=0, verified=0, verified_wrong=0, missing_members=0, wrong_after_fallback=0)
         for s in range(nb):
             x = hostile.activations(a.batch, a.d, dev, seed=20_000 + s)
+            # (round 6: the dither vectors of a large batch belong to the PREPARE -- a fresh seed per batch samples them)
+            prepared = ops.prepare_encoder(W, out=prepared)
             v, i, st = ops.encode_topk(x, W, b, bd, prepared, a.k)
             ev, ei = exact[s]
             wrong = (i != ei).any(-1) | (v.view(torch.int32) != ev.view(torch.int32)).any(-1)
