@@ -462,10 +462,10 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     const bool w_packed = tile_major == 1 || skinny != 0;   // the W side of the candidate passes reads the tile-major copies
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;   // ~16 rows per thread: 2048 workgroups at T = 8192
     if (shard)
-      hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, false>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d,
                          (float *)nullptr, colmax);
     else
-      hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+      hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
@@ -517,7 +517,7 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
     unsigned char *is_out = ws + pl.off_isout;
     f32x4 *cc_main = reinterpret_cast<f32x4 *>(ws + pl.off_colc), *cc_samp = reinterpret_cast<f32x4 *>(ws + pl.off_colc_s);
     const int ychunks = T >= 32 ? (T / 16 < 512 ? T / 16 : 512) : 1;
-    hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 8 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
+    hipLaunchKernelGGL((prep_colmax_kernel<DT, true>), dim3((d / 4 + 255) / 256, ychunks), dim3(256), 0, s, x, b_dec, T, d, a32,
                        colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     hipLaunchKernelGGL(quant_x_fp8_kernel, dim3(pl.Tp), dim3(256), 0, s, (const float *)a32, T, d, (const unsigned char *)is_out, x8,

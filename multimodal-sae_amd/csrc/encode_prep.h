@@ -321,31 +321,26 @@ template <int DT, bool WRITE_A32>
 __global__ __launch_bounds__(256) void prep_colmax_kernel(const void *__restrict__ x, const float *__restrict__ b_dec,
                                                           int T, int d, float *__restrict__ a32,
                                                           unsigned *__restrict__ colmax_bits) {
-  // a thread owns EIGHT consecutive columns (d % 8 == 0: every shape with an int8 / fp8 pass): a wave reads 1 KB (16-bit x) and
-  // writes 2 KB per row -- round 6; four columns per thread (512-B pieces) measured 47 us for the bench batch's 201 MB
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  // (round 6: eight columns per thread -- 1-KB row pieces, half the workgroups -- measured 0.166 ms of prep against 0.142: reverted)
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= d) return;
   const int rows_per = (T + gridDim.y - 1) / gridDim.y;
   const int t0 = blockIdx.y * rows_per, t1 = min(T, t0 + rows_per);
-  const f32x4 bd0 = b_dec ? *reinterpret_cast<const f32x4 *>(b_dec + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4 bd1 = b_dec ? *reinterpret_cast<const f32x4 *>(b_dec + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bd = b_dec ? *reinterpret_cast<const f32x4 *>(b_dec + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int t = t0; t < t1; ++t) {
-    f32x4 v0 = load_x4<DT>(x, (size_t)t * d + c), v1 = load_x4<DT>(x, (size_t)t * d + c + 4);
-    if (b_dec) { v0 = v0 - bd0; v1 = v1 - bd1; }
-    if constexpr (WRITE_A32) {
-      *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v0;
-      *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c + 4) = v1;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { m0[e] = fmaxf(m0[e], fabsf(v0[e])); m1[e] = fmaxf(m1[e], fabsf(v1[e])); }
+    f32x4 v = load_x4<DT>(x, (size_t)t * d + c);
+    if (b_dec) v = v - bd;
+    if constexpr (WRITE_A32) *reinterpret_cast<f32x4 *>(a32 + (size_t)t * d + c) = v;
+    m[0] = fmaxf(m[0], fabsf(v[0])); m[1] = fmaxf(m[1], fabsf(v[1]));
+    m[2] = fmaxf(m[2], fabsf(v[2])); m[3] = fmaxf(m[3], fabsf(v[3]));
   }
   // (blockIdx.y % COLMAX_PARTS: one copy of the maxima for all row chunks means T / 16 atomics on every column's word -- hundreds of
   // same-address atomics, ~45 ns each: 20 us of this 60 us kernel at T = 8192; pick_outliers_kernel folds the copies)
   unsigned *cm = colmax_bits + (size_t)(blockIdx.y % COLMAX_PARTS) * d;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { atomicMax(cm + c + e, __float_as_uint(m0[e])); atomicMax(cm + c + 4 + e, __float_as_uint(m1[e])); }  // values >= 0
+  for (int e = 0; e < 4; ++e) atomicMax(cm + c + e, __float_as_uint(m[e]));  // values >= 0
 }
 
 // single workgroup: dims whose column max exceeds 8x the mean column max (threshold raised until
