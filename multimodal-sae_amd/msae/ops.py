@@ -477,6 +477,13 @@ def coarse_in_force() -> str:
     return {"b": "bf16", "f": "fp8"}.get(e, "int8")
 
 
+def dither_in_force() -> bool:
+    """Whether an encode / prepare issued NOW rounds the int8 operands stochastically (process default, else MSAE_DITHER)."""
+    if _defaults.dither != "default":
+        return _defaults.dither == "on"
+    return os.environ.get("MSAE_DITHER", "1")[:1] != "0"
+
+
 def set_status_detail(on: bool) -> None:
     """Diagnostics: tokens recomputed inside the call report 1 | reason << 8 instead of 1."""
     _defaults.status_detail = bool(on)

@@ -185,9 +185,11 @@ class Sae(nn.Module):
 
     def _prepared_weights(self) -> Optional[Tensor]:
         w = self.encoder.weight
-        # (+ whether the fp8 pass is in force: its operands replace the int8 ones in the buffer)
+        # (+ whether the fp8 pass is in force: its operands replace the int8 ones in the buffer; + the dither mode: the
+        # operands of a large batch's subtractive dither are rounded against the seed of the PREPARE, so a buffer prepared
+        # with the dither off cannot serve a dithering encode except through the exact path -- include/msae.h, `dither`)
         key = (w.data_ptr(), w._version, tuple(w.shape), w.device,
-               ops.coarse_in_force() == "fp8")
+               ops.coarse_in_force() == "fp8", ops.dither_in_force())
         if self._prepared is None or self._prepared_key != key:
             self._prepared = ops.prepare_encoder(w)
             self._prepared_key = key
