@@ -37,9 +37,10 @@
  *              member of the true top-k is missed with probability <= k exp(-z^2 / 2) over the library's own randomness
  *              (a Chernoff bound of a sum of independent bounded residuals; 7e-10 per token at z = 7, k = 32; guard_z = 8:
  *              4e-13).  No assumption about the data.  The probability is over the seed of the PREPARE / refresh for the
- *              weights' residuals and, for batches of more than 256 tokens, for the activations' as well (the subtractive
- *              dither below: both operands are rounded against per-dim vectors fixed when the operands are prepared); smaller
- *              batches round the activations with a seed drawn per call.  A long-running job that wants fresh randomness
+ *              weights' residuals and, for every batch that runs an MFMA candidate pass (more than 16 tokens), for the
+ *              activations' as well (the subtractive dither below: both operands are rounded against per-dim vectors fixed
+ *              when the operands are prepared); the weight-stream path of <= 16 tokens rounds the activations with a seed
+ *              drawn per call.  A long-running job that wants fresh randomness
  *              re-prepares (msae_encoder_refresh: one sweep over W_enc).
  *   certified  two int8 planes per operand, three MFMA segments, a DETERMINISTIC Cauchy-Schwarz band: no probability
  *              left; ~2.5x the default's step time on large batches (`certified`).
@@ -132,7 +133,8 @@ enum {
  *                 section 5.  Applies to the int8 pass (all batch sizes); the bf16 pass keeps its statistical model.
  *                 The proxy includes the cross term of the two roundings: the weights' residuals multiply the DEQUANTISED
  *                 activation, so |a_t| above reads |a_t| + sx_t sqrt(d) (ABI 4 builds before round 6 left it out).
- *                 SUBTRACTIVE DITHER (round 6; batches of more than 256 tokens, i.e. the 256 x 256-tile MFMA pass).  The
+ *                 SUBTRACTIVE DITHER (round 6; batches of more than 16 tokens: the MFMA candidate passes of csrc/gemm_mfma.h and
+ *                 csrc/gemm_skinny.h; the <= 16-token weight stream keeps the band above).  The
  *                 sqrt(3) is the price of a residual whose variance f (1 - f) depends on the input.  When the dither is
  *                 subtracted again -- the operand element is taken as q - (r - 1/2) -- the residual is EXACTLY uniform on
  *                 (-1/2, 1/2] step for every input, and a uniform variable is sub-Gaussian with its own variance 1/12 as proxy:
@@ -163,7 +165,8 @@ enum {
  *   dither_seed   (ABI 4) 0: the library draws a seed per call (process-random base + atomic counter through a 64-bit
  *                 mixer -- the one piece of process state the library keeps); != 0: the seed of THIS call (reproducible
  *                 candidate sets: tests, A/B runs).  In a prepare / refresh it seeds the weights' rounding and the shared
- *                 dither vectors of large batches; in an encode, the activations' rounding of batches of <= 256 tokens. */
+ *                 dither vectors of the MFMA candidate passes; in an encode, the activations' rounding of the <= 16-token path
+ *                 (and of every batch under MSAE_NO_SUBTRACT=1). */
 enum { MSAE_COARSE_DEFAULT = -1, MSAE_COARSE_BF16 = 0, MSAE_COARSE_INT8 = 1, MSAE_COARSE_FP8 = 2 };
 enum { MSAE_DITHER_DEFAULT = 0, MSAE_DITHER_ON = 1, MSAE_DITHER_OFF = 2 };
 typedef struct msae_options {

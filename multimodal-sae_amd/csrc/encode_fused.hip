@@ -469,8 +469,8 @@ int run_fast(const void *x, const float *W_enc, const float *b_enc, const float 
                          colmax);
     hipLaunchKernelGGL(pick_outliers_kernel, dim3(1), dim3(1024), 0, s, colmax, d, odims, is_out);
     const unsigned need = skinny ? (PREP_I8 | PREP_FRAG) : PREP_I8;   // operands this call's candidate passes read
-    // gemm_mfma.h's passes subtract the shared dither again: both roundings uniform with variance 1/12, for every input
-    sd = co.seed != 0ull && skinny == 0 && getenv("MSAE_NO_SUBTRACT") == nullptr;
+    // the candidate passes (gemm_mfma.h, gemm_skinny.h) subtract the shared dither again: both roundings uniform with variance 1/12, for every input
+    sd = co.seed != 0ull && getenv("MSAE_NO_SUBTRACT") == nullptr;
     int2 *rowe = reinterpret_cast<int2 *>(ws + pl.off_rowe);
     const unsigned long long *dseed_p = reinterpret_cast<const unsigned long long *>(prepared + offsetof(Prepared, dseed));
     const int *sdtab = reinterpret_cast<const int *>(prepared + pp.off_sdtab);

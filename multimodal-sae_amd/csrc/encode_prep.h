@@ -113,7 +113,8 @@ __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W,
   const float scale = m > 0.f ? m / 127.f : 0.f;          // an all-zero row: coarse value = bias exactly, no band
   const bool dither = o.seed != 0ull || s2 < scale * scale * (float)d;       // every row / rms below one step
   const bool shared = o.seed != 0ull;                                        // (sub-step rows of a round-to-nearest prepare: the fixed per-element hash)
-  int dacc = 0;                                                              // this thread's share of D_n in units of 2^-17 (exact: < 2^30)
+  int dacc = 0;                                                              // 16 dims' share of D_n in units of 2^-17 (< 2^27: flushed per iteration)
+  long long dacc64 = 0;
   const bool samp = (n % SAMPLE_STRIDE) == SAMPLE_OFF;
   if (threadIdx.x == 0) {
     const float q_bf = __builtin_sqrtf(s4);
@@ -164,9 +165,10 @@ __device__ __forceinline__ void row_stats_quant_row(const float *__restrict__ W,
         *reinterpret_cast<i32x4 *>(wqsp + packed_off((size_t)(n / SAMPLE_STRIDE), c, d, layout)) = packed;
         if (wqsf) *reinterpret_cast<i32x4 *>(wqsf + frag_off((size_t)(n / SAMPLE_STRIDE), c, d)) = packed;
       }
+      dacc64 += dacc; dacc = 0;                  // (any d: the 32-bit partial never holds more than 16 products)
     }
     if (o.ds) {                                  // D_n: int64 sum over the workgroup (red[] was consumed above)
-      long long dsum = dacc;
+      long long dsum = dacc64;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
       __syncthreads();
@@ -435,7 +437,8 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
   // (SD: the buffer's seed; 0 = operands rounded to nearest behind a dithering call -- the stale-operand bit below sends the
   // call to the exact path in that case, see run_fast)
   [[maybe_unused]] const unsigned long long dseed = SD ? *dseed_p : 0ull;
-  [[maybe_unused]] int e1 = 0;                     // this thread's share of sum g_w Aq over the token's own columns (2^-17 units; < 2^30)
+  [[maybe_unused]] int e1 = 0;                     // 16 dims' share of sum g_w Aq over the token's own columns (2^-17 units; flushed per iteration)
+  [[maybe_unused]] long long e1_64 = 0;
   [[maybe_unused]] long long e_out = 0;            // ... of the outlier tile's entries (g_w hi m)
   const float *__restrict__ row32 = static_cast<const float *>(x) + (size_t)t * d;   // SRC == MSAE_F32 && !FROM_X: a32
   auto load4 = [&](int c) {
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
       packed[q] = (int)w;
     }
     *reinterpret_cast<i32x4 *>(xq_at(c)) = packed;
+    if constexpr (SD) { e1_64 += e1; e1 = 0; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) e0 += __shfl_xor(e0, off, 64);
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256) void quant_x_kernel(const void *__restrict__ x
     xqo[(size_t)t * MAX_OUT + threadIdx.x] = (signed char)iv;
   }
   if constexpr (SD) {
-    long long es = (long long)e1 + e_out;
+    long long es = e1_64 + e_out;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) es += __shfl_xor(es, off, 64);
     if ((threadIdx.x & 63) == 0) { red64[threadIdx.x >> 6] = es; red_e0[threadIdx.x >> 6] = e0; }   // (arrays of their own: ONE barrier)

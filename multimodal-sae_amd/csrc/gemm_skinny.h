@@ -34,7 +34,7 @@ struct SkinnyCfg {
   static constexpr int PITCH = ADMA ? KC : KC + 16;     // row pitch of the LDS image (16 B pad: rows spread over the banks)
   static constexpr int A_BUF = BM * PITCH;
   static constexpr int LDS_RING_BYTES = 2 * A_BUF;
-  static constexpr int SIDE_SLOTS = 7;                  // (slot 6: gemm_mfma.h's subtractive-dither corrections; zero here -- this pass does not subtract)
+  static constexpr int SIDE_SLOTS = 7;                  // (slot 6: gemm_mfma.h's subtractive-dither corrections)
   static constexpr int SIDE_BYTES = SIDE_SLOTS * NT * 4;
   static constexpr int QCAP = 128 * NW_;                // ~0.5 % of BM x BN outputs pass the hot loop's bound
   static constexpr int LDS_BYTES = LDS_RING_BYTES + SIDE_BYTES + 16 + QCAP * 8;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   // ---- epilogue constants of this tile's rows / columns (registers now, LDS after the k-loop; as gemm_kernel)
   float side0 = 0.f, side1 = 0.f, side3 = 0.f, side4 = 0.f;
   int side2 = 1;
+  int side6 = 0;                                       // subtractive dither (gemm_mfma.h): E_t (rows) | float bits of Ds_n (columns)
   float ref0 = 1.f, ref1 = 1.f, ref2 = 1.f;
   if constexpr (!DENSE) { ref0 = ep.refs[0]; ref1 = ep.refs[1]; ref2 = ep.refs[2]; }
   const bool has_out = op.Ao != nullptr;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
       side3 = rc[2];
       side4 = 1.f;
       if (has_out) { side2 = (int)rc[1]; side4 = rc[1]; }
+      if (ep.row_e) { const int2 em = ep.row_e[m0 + t]; side6 = em.x; side2 = em.y; }
     }
   } else if (tid < C::BM + C::BN) {
     const int n = n0 + tid - C::BM;
@@ -88,10 +90,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
     side2 = __float_as_int(cc[1]);
     side3 = cc[2];
     side4 = cc[3];
+    if (ep.col_ds) side6 = __float_as_int(ep.col_ds[n]);
   }
   float *side = reinterpret_cast<float *>(smem + C::LDS_RING_BYTES);
-  int *side_m = reinterpret_cast<int *>(side) + 2 * C::NT;
-  if (tid < C::BM) side_m[tid] = side2;                // the rows' outlier multipliers (read by scale_by_m below)
+  // (m, -E) of the rows as int2 in slot 2 (free until the constants are parked behind the k-loop): acc = acc * m - E below
+  int2 *side_me = reinterpret_cast<int2 *>(reinterpret_cast<int *>(side) + 2 * C::NT);
+  static_assert(2 * C::BM <= C::NT, "the (m, -E) pairs fit one side slot");
+  if (tid < C::BM) side_me[tid] = int2{side2, -side6};
+  const bool sub_e = ep.row_e != nullptr;              // (wave-uniform)
 
   // v_mfma_i32_16x16x64_i8: A = 16 tokens x 64 B of k, B = 16 features x 64 B of k (lane l: row l % 16, bytes 16 (l / 16) ..),
   // C[token 4 (l / 16) + r][feature l % 16] in 4 registers.  A wave owns 32 features = 2 feature groups, the tile's BM tokens
@@ -204,15 +210,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
       for (int tg = 0; tg < TG; ++tg)
         mfma(tg, *reinterpret_cast<const i32x4 *>(op.Ao + (size_t)(tg * 16 + l15) * 128 + ks * 64 + lg * 16), b);
     }
-    __syncthreads();                                   // side_m written
-    if (lead_ks > 0) {                                 // |acc| < 2^21 and m <= 1040 (quant_x_kernel: larger multipliers send the token to the exact path): the product fits int32
+    __syncthreads();                                   // side_me written
+    if (lead_ks > 0 || sub_e) {                        // |acc| < 2^21 and m <= 1040 (quant_x_kernel: larger multipliers send the token to the exact path): the product fits int32
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = side_m[tg * 16 + lg * 4 + r];
-          acc16[tg][0][r] = __mul24(acc16[tg][0][r], m);
-          acc16[tg][1][r] = __mul24(acc16[tg][1][r], m);
+          const int2 me = side_me[tg * 16 + lg * 4 + r];
+          acc16[tg][0][r] = __mul24(acc16[tg][0][r], me.x) + me.y;
+          acc16[tg][1][r] = __mul24(acc16[tg][1][r], me.x) + me.y;
         }
     }
   }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmOperands op, i
   reinterpret_cast<int *>(side)[2 * C::NT + tid] = side2;
   side[3 * C::NT + tid] = side3;
   side[4 * C::NT + tid] = side4;
-  side[6 * C::NT + tid] = 0.f;
+  reinterpret_cast<int *>(side)[6 * C::NT + tid] = side6;
   if constexpr (!DENSE) {
     float side5 = 0.f;
     if (tid < C::BM) {          // B_t: z sigma of this token against the reference feature

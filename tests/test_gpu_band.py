@@ -12,7 +12,7 @@ candidates of every token):
     corrections the derivation says they are (a wrong sign would be a 1-sigma discrepancy on every pair);
   * (z sigma)^2 >= z^2 / 12 * sum_c [ sw^2 (|a_c| + sx / 2)^2 + sx^2 w_c^2 ]  -- the per-element variance proxy INCLUDING the
     cross term of the two roundings (the weights' residuals multiply the dequantised activation), and not more than 5 % above it;
-  * the measured (p - c) / sigma over ~130 k pairs has standard deviation ~1 and no outlier: 1/12 is the residuals' variance.
+  * the measured (p - c) / sigma over 50-130 k pairs has standard deviation ~1 and no outlier: 1/12 is the residuals' variance.
 Reference semantics of the quantity being selected: /root/reference/sae_auto_interp/sae/sae.py:172-185.
 """
 from __future__ import annotations
@@ -92,10 +92,13 @@ def _emulate(x: torch.Tensor, bd: torch.Tensor, tab: np.ndarray, F: int):
     return a, Aq, scale, m, E, gx, out
 
 
-def test_subtractive_dither_band_is_the_elementwise_bound(dev):
+@pytest.mark.parametrize("T,d", [(512, 512), (200, 1024)], ids=["mfma-tiles", "weight-stream"])
+def test_subtractive_dither_band_is_the_elementwise_bound(dev, T, d):
+    """(512 tokens: the 256 x 256-tile MFMA pass, csrc/gemm_mfma.h; 200 tokens at d % 1024 == 0: the weight-stream pass of
+    17 ... 256 tokens, csrc/gemm_skinny.h -- both subtract the dither.)"""
     from msae import ops
 
-    d, N, T, k, C, z = 512, 8192, 512, 32, 256, 7.0
+    N, k, C, z = 8192, 32, 256, 7.0
     W, b, bd = hostile.weights("lognorm", N, d, dev, seed=41)
     x = hostile.activations(T, d, dev, seed=42)            # four x20 dims: the outlier tile and the remainder plane are in play
     ops.set_dither("on", seed=0xD17E5EED)
@@ -151,7 +154,7 @@ def test_subtractive_dither_band_is_the_elementwise_bound(dev):
     ratio = (p - c_em) / (np.sqrt(proxy) / z)
     print(f"\nsubtractive dither: {ratio.size} pairs, (p - c) / sigma: mean {ratio.mean():+.4f}, std {ratio.std():.4f}, "
           f"max |.| {np.abs(ratio).max():.2f}; band / proxy {float((band2 / proxy).min()):.4f} .. {float((band2 / proxy).max()):.4f}")
-    assert 0.9 < ratio.std() < 1.03 and abs(ratio.mean()) < 0.05 and np.abs(ratio).max() < 6.0
+    assert 0.9 < ratio.std() < 1.04 and abs(ratio.mean()) < 0.05 and np.abs(ratio).max() < 6.0
 
 
 def test_token_with_a_huge_outlier_multiplier_keeps_the_coarse_outlier_steps(dev):
