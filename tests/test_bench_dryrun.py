@@ -82,3 +82,15 @@ def test_bench_line_survives_a_failing_or_wedged_leg(tmp_path, fault):
     assert "error" in res and res["value"] > 0
     assert res["headline"] == "feature-sharded: per_shard_topk"          # the leg that completed before the faulty one
     assert res["shard_modes"]["per_shard_topk"]["bit_identical_256"] is True
+
+
+def test_numa_pinned_cpu_baseline_leg_runs_and_reports():
+    """bench.py's cpu_baseline also times the reference port pinned to one NUMA node (oracle/cpu_baseline_worker.py, a process of
+    its own so that the affinity mask precedes torch's thread pool); here: a tiny shape, the JSON it must hand back."""
+    import bench
+
+    rec = bench.numa_pinned_baseline(256, 2048, 8, 32, 2)
+    assert "error" not in rec, rec
+    if "skipped" in rec:
+        return
+    assert rec["tokens_per_s"] > 0 and rec["threads"] >= 1 and rec["affinity"] >= rec["threads"] and rec["node"] == 0
