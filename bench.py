@@ -718,7 +718,7 @@ def main(argv=None, rt=None):
             roofline_fields(stage, dec_ms, out, N, T, with_traffic=True)
         # ---- secondary records (same batches; never the headline).  Each is guarded: a failure is recorded, not raised.
         if not args.no_secondary and not (args.sae_path or args.acts) and world == 1:
-            sec_steps, sec_warm = max(3, min(args.steps, 10)), 2
+            sec_steps, sec_warm = max(3, min(args.steps, 10)), 2      # (each record: the instrumented pass, then the timed one -- as the headline)
 
             def record(name, fn):
                 try:
@@ -728,7 +728,7 @@ def main(argv=None, rt=None):
 
             def run_k256():
                 e2 = rt.engine(W_enc, b_enc, W_dec, b_dec, 256)
-                el, o, st, dm = timed(e2, xs, sec_steps, sec_warm, profile=True)
+                el, o, st, dm, _ = timed_clean(e2, xs, sec_steps, sec_warm)
                 rec = {"k": 256, "ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
                        "note": "the released 131k checkpoint's k (train/sae/README.md:33-45); same batches"}
                 rec.update(stage_fields(st, dm, o, 256))
@@ -737,7 +737,7 @@ def main(argv=None, rt=None):
             def run_zipf():
                 bz = zipf_bias(xs[0], b_dec, N, k, dev)
                 e3 = rt.engine(W_enc, bz, W_dec, b_dec, k)
-                el, o, st, dm = timed(e3, xs, sec_steps, sec_warm, profile=True)
+                el, o, st, dm, _ = timed_clean(e3, xs, sec_steps, sec_warm)
                 idx = o["top_indices"]
                 counts = torch.bincount(idx.flatten(), minlength=N).float()
                 top1 = counts.sort(descending=True).values[: max(1, N // 100)].sum() / max(1.0, float(counts.sum()))
@@ -767,7 +767,7 @@ def main(argv=None, rt=None):
             def run_dither_off():
                 with rt.options(dither="off"):
                     e4 = rt.engine(W_enc, b_enc, W_dec, b_dec, k)      # (its operands are prepared under the option)
-                    el, o, st, dm = timed(e4, xs, sec_steps, sec_warm, profile=True)
+                    el, o, st, dm, _ = timed_clean(e4, xs, sec_steps, sec_warm)
                 rec = {"ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
                        "note": "msae_options::dither = OFF: round-to-nearest int8 operands, the statistical contract of ABI 3"}
                 rec.update(stage_fields(st, dm, o, k))
@@ -776,7 +776,7 @@ def main(argv=None, rt=None):
             def run_fp8():
                 with rt.options(coarse="fp8"):
                     e5 = rt.engine(W_enc, b_enc, W_dec, b_dec, k)      # (prepared under the mode: e4m3 operands)
-                    el, o, st, dm = timed(e5, xs, sec_steps, sec_warm, profile=True)
+                    el, o, st, dm, _ = timed_clean(e5, xs, sec_steps, sec_warm)
                 rec = {"ms_per_step": el / sec_steps * 1e3, "value": T * sec_steps / el, "unit": "tokens/s",
                        "note": "MSAE_COARSE_FP8: the candidate pass on e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8) -- BASELINE "
                                "configs[4]'s 'fp8 MFMA encoder path'; same exact outputs, a ~5x wider band than int8"}
@@ -785,7 +785,7 @@ def main(argv=None, rt=None):
 
             def run_tokens(Tn, what):
                 xs_n = [rt.make_inputs(dev, Tn, d, min(N, 8192), seed=101 + 7919 * j)[4] for j in range(len(xs))]
-                el, o, st, dm = timed(engine, xs_n, sec_steps, sec_warm, profile=True)
+                el, o, st, dm, _ = timed_clean(engine, xs_n, sec_steps, sec_warm)
                 rec = {"tokens_per_step": Tn, "ms_per_step": el / sec_steps * 1e3, "value": Tn * sec_steps / el, "unit": "tokens/s",
                        "note": what}
                 rec.update(stage_fields(st, dm, o, k))

@@ -963,8 +963,13 @@ inline bool fm_pays(int T, int k, int N, int d, int esize) {
   const int force = e ? atoi(e) : -1;
   if (force >= 0) return force != 0;
   const double m = 1.36 * (double)T * k / N;
-  if (m < 1.0) return false;
-  const double gain_ps = d * (4.0 / 6.2 - (esize + 4.0 / m) / 8.0);   // per pair
+  if (m < 0.6) return false;
+  // Round 6 (tools/fm_midsize.py, profiles/r06_fm_midsize.txt): below ~2 tokens per feature the batch is small enough for the
+  // token-major kernel to be latency-bound -- it reaches ~4.2 TB/s, not the 6.2 of a full batch -- and the feature-major route
+  // already wins from ~1 token per feature: T = 2880 (one anyres image, m = 0.96) 2.11 -> 2.05 ms, 4096 (m = 1.36) 2.67 -> 2.56;
+  // T = 2048 (m = 0.68) is a tie, 1024 stays token-major.
+  const double tm_rate = m >= 2.0 ? 6.2 : 4.2;
+  const double gain_ps = d * (4.0 / tm_rate - (esize + 4.0 / m) / 8.0);   // per pair
   return gain_ps >= 500.0;
 }
 // lanes per feature group of fm_dot_kernel: 16 when a feature has >= ~12 pairs (k = 256 at 8192 tokens: 22), else 4
