@@ -34,9 +34,10 @@ anyres image per call, eight bench batches per call), "sustained" (2000 steps: c
 "roofline" the STEP's own fraction of BASELINE.md section 3's max(...) ("step_frac").
 
 Timing protocol (round 6): the headline's K steps run on the UN-instrumented loop; the stage clocks / re-score statistics come
-from a pass of the same W + K steps with the HIP events on that runs FIRST ("ms_per_step_instrumented"; "timing_order" says so in
-the line).  The first heavy loop of the process runs 1-2 % slower than any later one (power management settling after the
-set-up phase: profiles/r06_warmup_transient.txt), so the order is part of what is reported.
+from a pass of the same W + K steps with the HIP events on that runs first ("ms_per_step_instrumented"; "timing_order" says so in
+the line; the events cost 0.02-0.03 ms per step).  The wall clock of a timed loop is read INSIDE the clock sampler's context: until
+round 6 the region enclosed the sampler's exit -- a join on a thread sitting in a sleep or an hwmon read, 0-4 ms per loop
+(profiles/r06_timing_harness.txt).
 
 `main(argv, rt)`: everything device-specific goes through a small runtime object (HipRuntime below); tests/test_bench_dryrun.py
 drives the same control flow -- legs, watchdog, JSON schema -- on CPU over gloo at world 8 with injected kernels, so the first real
@@ -528,15 +529,19 @@ def main(argv=None, rt=None):
         sampler = rt.clock_sampler(dev)
         # (an un-instrumented loop carries neither the stage events nor the per-token statistics store)
         ctx_a, ctx_b = rt.contexts(prof, rows_buf) if profile else (contextlib.nullcontext(), contextlib.nullcontext())
-        t0 = time.perf_counter()
+        # The clock starts INSIDE the contexts and stops before they exit: the sampler's thread start and, above all, its join --
+        # the thread sits in a 2-ms sleep or in an hwmon read (the SMU's power query takes milliseconds) when it is told to stop --
+        # are harness time, not step time.  (Until round 6 they were inside the timed region: ~2 ms per timed loop, i.e. 0.1 ms per
+        # step of a 20-step loop, 0.2 ms of a 10-step secondary record; the 2000-step record was the only clean one.)
         with sampler, ctx_a, ctx_b:
+            t0 = time.perf_counter()
             for i in range(steps):
                 out = eng.forward(xs[i % len(xs)], async_gather=eng.collective, gather=gather)
             eng.synchronize()
             rt.sync()
-        if ddp:
-            dist.barrier()
-        el = time.perf_counter() - t0
+            if ddp:
+                dist.barrier()
+            el = time.perf_counter() - t0
         sampler_out.clear()
         sampler_out.update(sampler.summary())
         stage, dec_ms = np.zeros((0, 6)), float("nan")
@@ -555,11 +560,9 @@ def main(argv=None, rt=None):
     def timed_clean(eng, xin, steps, warmup, gather=True):
         """Two passes of the SAME protocol (W warm-up steps, then K timed steps between barriers + synchronisations):
         first the INSTRUMENTED one (stage events, per-token re-score statistics: what the roofline fields are computed from),
-        then the un-instrumented one, whose time is the headline -- an instrument must not sit inside the number it decorates.
-        Order matters and is stated in the line ("timing_order"): the first heavy loop after the process's set-up runs ~1-2 %
-        slower than any later one (profiles/r06_warmup_transient.txt: 5.93 ms with 5 warm-up steps on a cold box, 5.82-5.85 with
-        50-800, 5.84 in a third 5-step run right behind a long one; a 2000-step loop 5.72 on a box whose first 20 steps took
-        5.96) -- the package's power management settling, not the kernels.  Both passes' times are reported.
+        then the un-instrumented one, whose time is the headline -- an instrument must not sit inside the number it decorates
+        (the events cost 0.02-0.03 ms per step; the order of the passes does not matter: tools/pass_order.py,
+        profiles/r06_timing_harness.txt).  Both passes' times are reported, and the order is named in the line ("timing_order").
         -> (elapsed, out, stage, dec_ms, elapsed_instrumented)"""
         el_i, out_i, stage, dec_ms = timed(eng, xin, steps, warmup, profile=True, gather=gather)
         el, out, _, _ = timed(eng, xin, steps, warmup, profile=False, gather=gather)
