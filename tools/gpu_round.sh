@@ -4,7 +4,7 @@
 # real-input runner.  Everything lands in gpurun_out/ (merged back by gpurun); each step has its own timeout.
 cd "$(dirname "$0")/.."
 OUT=gpurun_out
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 mkdir -p $OUT
 export TMPDIR=/tmp
 (nproc; grep -m1 "model name" /proc/cpuinfo; free -g | head -2; rocm-smi --showproductname 2>/dev/null | head -8) > $OUT/host.txt 2>&1
