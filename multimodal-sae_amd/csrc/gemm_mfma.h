@@ -806,15 +806,21 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
     stage(m0, n0, 0, 0);
   }
 
-  // (m, -E) of the tile's rows, parked early as int2 [BM] in slot 2 (free until the constants are parked behind the k-loop)
-  int2 *side_me = reinterpret_cast<int2 *>(reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT);
-  static_assert(2 * C::BM <= C::NT, "the (m, -E) pairs fit one side slot");
+  // m and -E of the tile's rows are parked EARLY (in front of the tile's first barrier), i.e. while slower waves of this persistent
+  // workgroup may still be in the PREVIOUS tile's epilogue: they may only go where that epilogue does not read -- the ROW parts of
+  // slots 2 and 6 (its rows' m comes from slot 4, E is not an epilogue input; the COLUMN part of slot 2 is Q_n, read by every
+  // gemm_band_sq).  Round 6 first packed the two as int2 across the whole of slot 2: a fast wave's next-tile pairs overwrote Q_n under
+  // the slow waves' band computations -- sample features' upper values went wrong at N = 262144 (four sample tiles per workgroup;
+  // 0.23 % of the tokens verified-and-wrong in tools/soak_fused.py, all missing features = 13 mod 32), found by the wide soak.
+  int *side_m = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 2 * C::NT;
+  [[maybe_unused]] int *side_e = reinterpret_cast<int *>(smem + C::LDS_RING_BYTES) + 6 * C::NT;
+  static_assert(C::BM + C::BN <= C::NT, "row part | column part of a side slot");
   auto iteration = [&](int kt, bool park_m = false) {
     MSAE_TLK(kt == 8, 0);
     MSAE_TLK(kt == 9, 5);
     wait_vmcnt<0>();               // this wave's pieces of k-tile kt (and the side constants) landed
     if (park_m) {                  // outlier multipliers of the tile's rows -> LDS (read after this k-tile)
-      if (tid_ < C::BM) side_me[tid_] = int2{side2, -side6};
+      if (tid_ < C::BM) { side_m[tid_] = side2; if constexpr (C::I8 && !C::CERT) side_e[tid_] = -side6; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     MSAE_TLK(kt == 8, 1);
@@ -861,8 +867,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmOperands op, int T, int
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = wr * C::TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int2 me = side_me[row];                           // (m, -E): one v_mad_i32_i24 per accumulator (E = 0 without the subtractive dither)
-        const int m = me.x, ee = me.y;
+        const int m = side_m[row];
+        int ee = 0;
+        if constexpr (C::I8 && !C::CERT) ee = side_e[row];     // -E (0 without the subtractive dither): one v_mad_i32_i24 per accumulator either way
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) {
           i32x16 v = __builtin_bit_cast(i32x16, acc[i][j]);

@@ -560,3 +560,34 @@ def test_certified_on_a_shape_without_the_pass_says_so_once(dev):
     assert len(notes) == 1 and "8192" in str(notes[0].message)
     ev, ei = _exact(ops, x, W, b, bd, k)
     assert torch.equal(i, ei) and torch.equal(v, ev)
+
+
+@pytest.mark.parametrize("kind", ["trained_like", "gauss"])
+def test_many_sample_tiles_per_workgroup_at_width_262144(dev, kind):
+    """Regression for an LDS race of round 6 (csrc/gemm_mfma.h: "parked EARLY").  The candidate GEMM's workgroups are persistent;
+    a fast wave entering its next output tile parks that tile's outlier multipliers (and, since round 6, the dither's -E) in the
+    side buffer while slower waves of the workgroup may still be in the previous tile's epilogue.  For one commit those pairs
+    were packed across ALL of side slot 2, whose column half holds Q_n -- an input of every upper value of the DENSE (sample)
+    epilogue: sample features' upper values went wrong, and tokens verified with a sample feature (index = 13 mod 32) of their
+    top-k missing.  It needed several sample tiles per workgroup to show: N = 262144 at 8192 tokens (32 x 32 tiles on 256
+    workgroups) gave 0.23 % wrong tokens where every test and a 16.8 M-token soak at N = 131072 had been clean.  Every token of
+    two full batches against the exact path."""
+    from msae import ops
+
+    d, N, T, k = 4096, 262144, 8192, 32
+    W, b, bd = hostile.weights(kind, N, d, dev, seed=41)
+    prepared = ops.prepare_encoder(W)
+    wrong_total = 0
+    for s in range(2):
+        x = hostile.activations(T, d, dev, seed=10_000 + s)
+        v, i, st = ops.encode_topk(x, W, b, bd, prepared, k, coarse_mode=1)
+        ev, ei = _exact(ops, x, W, b, bd, k, chunk=1024)
+        wrong = (i != ei).any(-1) | (v.view(torch.int32) != ev.view(torch.int32)).any(-1)
+        if bool(wrong.any()):
+            t = int(wrong.nonzero()[0])
+            missing = [f for f in ei[t].tolist() if f not in i[t].tolist()]
+            print(f"token {t}: status {int(st[t])}, missing {missing} (mod 32: {[f % 32 for f in missing]})")
+        wrong_total += int(wrong.sum())
+    assert wrong_total == 0
+    del W, prepared
+    torch.cuda.empty_cache()
