@@ -34,6 +34,7 @@ timeout 200 python tools/cluster_rows.py 2>&1 | grep cluster > $OUT/${R}_cluster
 echo "== soak =="
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 32768 --d 1024 --out $OUT/${R}_soak_1M_trained_like_n32768.json > $OUT/soak.log 2>&1; echo "soak exit $?"; tail -1 $OUT/soak.log | cut -c1-400
 timeout 900 python tools/soak_fused.py --tokens 4194304 --N 131072 --d 4096 --out $OUT/${R}_soak_4M_trained_like_c2.json >> $OUT/soak.log 2>&1; echo "soak c2 exit $?"
+timeout 900 python tools/soak_fused.py --tokens 2097152 --N 262144 --d 4096 --out $OUT/${R}_soak_2M_trained_like_n262144.json >> $OUT/soak.log 2>&1; echo "soak N=262144 exit $?"
 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --coarse bf16 --out $OUT/${R}_soak_1M_trained_like_c2_bf16.json >> $OUT/soak.log 2>&1; echo "soak c2 bf16 exit $?"
 timeout 900 python tools/soak_fused.py --tokens 524288 --N 131072 --d 4096 --coarse certified --out $OUT/${R}_soak_512k_trained_like_c2_certified.json >> $OUT/soak.log 2>&1; echo "soak c2 certified exit $?"
 MSAE_DITHER=0 timeout 900 python tools/soak_fused.py --tokens 1048576 --N 131072 --d 4096 --out $OUT/${R}_soak_1M_trained_like_c2_dither_off.json >> $OUT/soak.log 2>&1; echo "soak c2 dither-off exit $?"
