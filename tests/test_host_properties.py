@@ -64,3 +64,51 @@ def test_split_indices_follow_the_reference_rule(width, n_splits):
     got = fc._generate_split_indices(n_splits)
     b = torch.linspace(0, width, steps=n_splits + 1).long()
     assert [(int(s), int(e)) for s, e in got] == list(zip(b[:-1].tolist(), (b[1:] - 1).tolist()))
+
+
+def test_subtractive_dither_identities_and_residual_distribution():
+    """The arithmetic behind the large-batch int8 pass's band (csrc/encode_defs.h "subtractive dither"),
+    restated in numpy -- no GPU: (1) with shared dither vectors the subtracted product equals the integer accumulator minus a
+    per-feature constant D_n, a per-token constant E_t, plus a scalar F -- exactly, in integers of 2^-34; (2) the residual of a
+    subtractively dithered element is uniform on (-1/2, 1/2] WHATEVER the value is (here: values chosen adversarially at
+    k + 1/2, where round to nearest is worst and stochastic rounding has its largest variance); (3) the error of a coarse value
+    is exactly sum_c (A_c + delta_c) eps_c + delta_c W_c -- the cross term of the two roundings sits inside the first sum; (4) its
+    standard deviation is that of the band's sigma (1/12 per rounding)."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    d, T, N = 2048, 48, 64
+    hx, hw = rng.integers(0, 1 << 16, d), rng.integers(0, 1 << 16, d)
+    gx, gw = 2 * hx + 1 - (1 << 16), 2 * hw + 1 - (1 << 16)            # units of 2^-17: the dither minus one half
+    rx, rw = (2 * hx + 1) / 131072.0, (2 * hw + 1) / 131072.0
+    A = rng.normal(0, 30, (T, d))
+    A[0] = np.floor(A[0]) + 0.5                                        # adversarial token: every element half way between two steps
+    W = rng.normal(0, 30, (N, d))
+    q = np.floor(A + rx).astype(np.int64)
+    w = np.floor(W + rw).astype(np.int64)
+    acc = q @ w.T
+    D = (w @ gx)                                                       # [N], units 2^-17
+    E = (q @ gw)                                                       # [T], units 2^-17
+    F = int((gx * gw).sum())                                           # units 2^-34
+    # (1) the identity, in exact integer arithmetic (everything scaled by 2^34)
+    lhs = ((q * 131072 - gx).astype(object) @ (w * 131072 - gw).astype(object).T)
+    rhs = acc.astype(object) * (1 << 34) - D.astype(object)[None, :] * (1 << 17) - E.astype(object)[:, None] * (1 << 17) + F
+    assert (lhs == rhs).all()
+    # (2) residuals: in (-1/2, 1/2], mean ~0, variance 1/12 -- also on the adversarial token
+    delta = q - (rx - 0.5) - A
+    eps = w - (rw - 0.5) - W
+    for r in (delta, delta[0], eps):
+        assert r.min() > -0.5 - 1e-9 and r.max() <= 0.5 + 1e-9
+        assert abs(r.mean()) < 0.02 and abs(r.var() - 1.0 / 12.0) < 0.01
+    # (3) the error decomposition, to float accuracy
+    coarse = lhs.astype(np.float64) / float(1 << 34)
+    exact = A @ W.T
+    err = coarse - exact
+    pred = (A + delta) @ eps.T + delta @ W.T
+    assert np.allclose(err, pred, rtol=0, atol=1e-6 * np.abs(exact).max())
+    # (4) its scale: sigma^2 = (|A + delta|^2 + |W|^2) / 12 per pair
+    sig = np.sqrt((((A + delta) ** 2).sum(1)[:, None] + (W ** 2).sum(1)[None, :]) / 12.0)
+    ratio = err / sig
+    assert 0.9 < ratio.std() < 1.1 and np.abs(ratio).max() < 5.0
+    # non-subtractive stochastic rounding of the SAME adversarial token: variance 1/4 per element, three times as much
+    assert abs((q[0] - A[0]).var() - 0.25) < 0.01
