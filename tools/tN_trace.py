@@ -5,7 +5,7 @@ import bench
 from msae import ops
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device('cuda:0'); d, N, k = 4096, 131072, 32
-W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, 256, d, N)
+W_enc, b_enc, W_dec, b_dec, x = bench.make_inputs(dev, max(256, T), d, N)
 prep = ops.prepare_encoder(W_enc)
 xs = x[:T].contiguous()
 for _ in range(5): v, i, s = ops.encode_topk(xs, W_enc, b_enc, b_dec, prep, k)
