@@ -899,8 +899,13 @@ inline void rescore_shape(int T, int k, int &nw, int &lpr) {
   lpr = 1;
   if (k <= 64) {
     const long lanes = (long)T * (k + 13);
-    if (lanes * 4 <= 131072) lpr = 4;
-    else if (lanes * 2 <= 131072) lpr = 2;
+    // Round 6 (profiles/r06_ab_rescore_lpr.txt): a workgroup of lpr waves per token is alone on its CU up to 256 tokens; one token
+    // more and the kernel ends with the CU that holds TWO four-wave workgroups (0.078 -> 0.135 ms from 256 to 257 tokens) -- two
+    // waves per token then beat four up to ~640 tokens (257: 0.099, 512: 0.123 against 0.152), a lane per row beyond (768: 0.157
+    // against 0.235 / 0.207, 1024: 0.189 against 0.297 / 0.230).  The old rule asked only whether the lanes fill the chip.
+    if (T <= 256 && lanes * 4 <= 131072) lpr = 4;
+    else if (T <= 640 && lanes * 2 <= 131072) lpr = 2;
+    if (const char *e = getenv("MSAE_LPR")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) lpr = v; }   // (A/B runs)
     nw = lpr;
   }
 }
