@@ -286,6 +286,18 @@ __global__ __launch_bounds__(64 * NW) void select_rescore_kernel(RescoreArgs p, 
     }
     if (presorted) { __syncthreads(); return; }
     if constexpr (NW == 4 && !EXT) {
+      if (np <= 1024 && kcap >= 1024) {                    // (round 6) half of the k = 256 tokens have <= 1024 candidates: 4 keys per thread, 55 stages instead of 66
+        __syncthreads();
+        unsigned long long v4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = lane * 4 + r < np ? keys[lane * 4 + r] : 0ull;
+        wg_sort_desc_u64_regs<4, 4>(v4, lane, keys);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keys[lane * 4 + r] = v4[r];
+        __syncthreads();
+        return;
+      }
       if (np <= 2048 && kcap >= 2048) {                    // wave-uniform: 8 keys per thread, sorted in registers (keys[] = the exchange buffer: 2048 slots)
         __syncthreads();
         unsigned long long v8[8];
