@@ -577,7 +577,7 @@ def main(argv=None, rt=None):
                     " MFMA candidate select + f32 exact re-score/decode (outputs f32-exact)",
            "data": data,
            "dither": "off (round to nearest: statistical contract)" if os.environ.get("MSAE_DITHER", "1")[0] == "0" else
-                     "on (default: stochastically rounded int8 operands, per-call seeds -- the miss bound holds for every input)"}
+                     "on (default: stochastically rounded int8 operands, the dither subtracted again by the candidate passes -- the miss bound k exp(-z^2/2) holds for every input at round to nearest's band; seeds drawn by the library at prepare)"}
     if rt.dry_run:
         res["dry_run"] = "CPU / gloo with injected kernels: control flow only, no number in this line is a measurement"
     if ddp:
