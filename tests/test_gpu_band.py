@@ -157,16 +157,17 @@ def test_subtractive_dither_band_is_the_elementwise_bound(dev, T, d):
     assert 0.9 < ratio.std() < 1.04 and abs(ratio.mean()) < 0.05 and np.abs(ratio).max() < 6.0
 
 
-def test_token_with_a_huge_outlier_multiplier_keeps_the_coarse_outlier_steps(dev):
+@pytest.mark.parametrize("T,d", [(512, 512), (200, 1024)], ids=["mfma-tiles", "weight-stream"])
+def test_token_with_a_huge_outlier_multiplier_keeps_the_coarse_outlier_steps(dev, T, d):
     """A token whose massive dims exceed its ordinary ones by more than SD_M_EXACT = 252 has no remainder plane (it would not
     fit int8): its outlier dims keep coarse steps and their own band term (M_t = sqrt(3) m).  Its coarse values still lie inside
     their band, and the encode is exact on it and on its neighbours."""
     from msae import ops
 
-    d, N, T, k, C = 512, 8192, 512, 32, 256
+    N, k, C = 8192, 32, 256
     W, b, bd = hostile.weights("gauss", N, d, dev, seed=43)
     x = hostile.activations(T, d, dev, seed=44).float()
-    big = [7, 300]
+    big = [7, 150]
     for t in big:                                           # ~400x its ordinary dims' maximum, on two of the batch's outlier dims
         x[t, 13] = 2000.0 * x[t].abs().median()
         x[t, (977 + 13) % d] = -1900.0 * x[t].abs().median()
