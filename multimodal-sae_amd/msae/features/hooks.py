@@ -90,15 +90,16 @@ class _DecodeStepGraph:
     def _capture(self, sae, h: Tensor, key) -> None:
         body = lambda t: sae_reconstruct(sae, t, out_dtype=torch.float16)
         x = h.clone()
-        side = torch.cuda.Stream(device=h.device)
-        side.wait_stream(torch.cuda.current_stream(h.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):                       # workspaces and the prepared operands exist before the capture
-                body(x)
-        torch.cuda.current_stream(h.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            out = body(x)
+        with torch.cuda.device(h.device):            # (a hook on a layer of another device than the current one)
+            side = torch.cuda.Stream(device=h.device)
+            side.wait_stream(torch.cuda.current_stream(h.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):                   # workspaces and the prepared operands exist before the capture
+                    body(x)
+            torch.cuda.current_stream(h.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                out = body(x)
         self.graph, self.x, self.out, self.key = g, x, out, key
         # what the graph captured by address stays alive as long as the graph does: the operand buffer and the side stream's
         # scratch buffer (ops._workspace keeps only the most recently used streams' buffers)
